@@ -1,0 +1,180 @@
+/* lr2ppo_hip.h -- C ABI of the MI355X (gfx950) kernels behind the LR2PPO hot path.
+ *
+ * The reference (ChazzyGordon/LR2PPO) is pure Python/PyTorch and has no FFI of its own:
+ * every entry point below replaces a group of ATen/cuBLAS ops that the reference reaches through
+ * nn.Module calls.  The "replaces" note on each function cites that reference call site
+ * (paths relative to the reference repo root).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions: raw device pointers + sizes; `stream` is a hipStream_t passed as void*; every call is
+ * stream-ordered and asynchronous (no internal sync, no allocation, graph-capturable); no ownership is
+ * transferred; return 0 on success or a negative LR2_ERR_* code (no exceptions cross the ABI).
+ * All tensors are fp32 in HBM exactly as in the reference (indices int64/int32); bf16 exists only inside
+ * the GEMM kernel (LDS images of split operands).  All reductions/accumulators are fp32.
+ */
+#ifndef LR2PPO_HIP_H
+#define LR2PPO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LR2_ERR_ARG (-1)    /* null pointer / inconsistent arguments */
+#define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
+#define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
+
+#define LR2_ABI_VERSION 1
+int lr2_abi_version(void);
+/* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
+int lr2_device_info(char* name, int len);
+
+/* Fused GEMM epilogue, applied per element (m, n) in this order:
+ *   v = acc*alpha (+bias[n]); act==1: z=v (stored to out_z if set), v=gelu_erf(v);
+ *   drop_p>0: v = keep(seed,site,m*N+n) ? v/(1-p) : 0;  act==2: v *= gelu_erf'(aux_z[m,n]);
+ *   resid: v += resid[m,n];  accumulate: v += out[m,n];  out[m,n] = v.   All pointers fp32. */
+typedef struct lr2_epilogue {
+  const void* bias;   /* [N] or NULL */
+  const void* resid;  /* [M, ld_resid] or NULL */
+  const void* aux_z;  /* [M, ld_aux], required when act == 2 */
+  void* out;          /* [M, ld_out] */
+  void* out_z;        /* [M, ld_z] pre-activation (act == 1) or NULL */
+  int32_t ld_resid, ld_aux, ld_out, ld_z;
+  int32_t act;        /* 0 none, 1 GELU(erf), 2 multiply by GELU'(aux_z) */
+  int32_t accumulate; /* 1: out += result */
+  float alpha;
+  float drop_p;       /* 0 disables dropout */
+  uint32_t drop_site;
+  uint32_t _pad;
+  uint64_t drop_seed;
+} lr2_epilogue;
+
+/* C[M,N] = op(A).op(B), fp32 in / fp32 out, computed on bf16 MFMA with fp32 accumulation.
+ *   passes=3: split-bf16 (x = hi + lo; lo*hi + hi*lo + hi*hi): fp32-grade results (rel. err ~2^-17)
+ *   passes=1: single bf16 pass (inputs rounded to bf16)
+ *   trans_a=0: A is [M][K] (lda>=K);  trans_a=1: A is [K][M] (lda>=M)
+ *   trans_b=0: B is [N][K] (nn.Linear weight);  trans_b=1: B is [K][N]
+ * Supported forms: (0,0) forward, (0,1) input gradient, (1,1) weight gradient.
+ * Constraints: N%128==0; K%64==0 unless both operands are strided (1,1); lda,ldb %4==0; buffers < 4 GiB.
+ * a_bytes/b_bytes: bytes addressable from A/B (rows past the end read as zero: ragged M, ragged K in (1,1)).
+ * splits>1 uses split-K through splitk_ws (fp32 [splits][M][N]).  block_m: 128 or 64.
+ * replaces: nn.Linear / F.linear + bias + nn.GELU + nn.Dropout + residual add in
+ *   finetune/ppo.py:164-170 (Mlp), finetune/xit.py:103-110,118-122,147,
+ *   tencentpretrain/layers/{multi_headed_attn.py:55-58,75, position_ffn.py:12-15} and their autograd backward. */
+int lr2_gemm(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int trans_a, int trans_b,
+             uint64_t a_bytes, uint64_t b_bytes, const lr2_epilogue* epi, void* splitk_ws, int splits, int block_m,
+             int passes, void* stream);
+
+/* Row gather: dst[b, j, :] = src[b, index[b, j], :]  (rows of row_elems fp32; strides in elements).
+ * replaces: text_emb[batch_index, index] / img_emb[batch_index, index] (finetune/ppo.py:268-271,321-324). */
+int lr2_gather_rows(const void* src, const int64_t* index, void* dst, int B, int t_in, int t_out, uint64_t row_elems,
+                    uint64_t src_bstride, uint64_t src_tstride, void* stream);
+/* Scatter-add of row gradients: dsrc[b, index[b,j], :] += ddst[b, j, :]  (dsrc must be zero-initialised). */
+int lr2_gather_rows_bwd(const void* ddst, const int64_t* index, void* dsrc, int B, int t_in, int t_out,
+                        uint64_t row_elems, void* stream);
+/* Strided row copy: dst[(r / group)*dst_gstride + (r % group)*D + dst_off + c] = src[r*D + c].
+ * replaces: torch.cat([x, img_feature], dim=1) (finetune/ppo.py:224). */
+int lr2_copy_rows(const void* src, void* dst, int rows, int D, int group, uint64_t dst_gstride, uint64_t dst_off,
+                  void* stream);
+
+/* LayerNorm forward over rows of length D (D%4==0, D<=1024).
+ *   mode 0: nn.LayerNorm (biased variance, eps inside sqrt)      -- finetune/xit.py:37,74,93-94
+ *   mode 1: TencentPretrain LayerNorm gamma*(x-mu)/(std_unbiased+eps)+beta -- tencentpretrain/layers/layer_norm.py:16-21
+ * Output row r is written at out + (r / group)*group_stride + (r % group)*D (group<=0: dense), which lets the
+ * final XiT LayerNorm write straight into the concat buffer of finetune/ppo.py:224.
+ * mean/rstd (fp32 [rows]) may be NULL when no backward is needed. */
+int lr2_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* out, void* mean, void* rstd, int rows,
+                      int D, float eps, int mode, int group, uint64_t group_stride, void* stream);
+
+/* LayerNorm backward (mode 0).  dy uses the same (group, stride) row mapping as the forward output.
+ * dx = LN'(dy) (+ resid_grad) -> dx (fp32); optional dx_masked = dropout_mask(dx)/(1-p) (the gradient of
+ * y = dropout(a) + res with respect to a, finetune/xit.py:34,40).  dgamma/dbeta are accumulated per block
+ * into partials [nblocks][2][D]; finish with lr2_colsum_partials_finish.
+ * replaces: autograd of nn.LayerNorm + the in-place residual adds of finetune/xit.py:45-55,77-86. */
+int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_stride, const void* x, const void* gamma,
+                      const void* mean, const void* rstd, const void* resid_grad, void* dx, void* dx_masked,
+                      float drop_p, uint64_t drop_seed, uint32_t drop_site, void* partials, int nblocks, int rows,
+                      int D, void* stream);
+/* out[c] = sum_b partials[b*ld + c] for c < cols (deterministic second stage of column reductions). */
+int lr2_colsum_partials_finish(const void* partials, int nblocks, int cols, int ld, void* out, int accumulate,
+                               void* stream);
+/* Column sums of a fp32 [rows, cols] matrix -> [cols] (bias gradients); partials: workspace [nblocks][cols].
+ * replaces: autograd of the nn.Linear bias add. */
+int lr2_colsum(const void* x, int rows, int cols, int ld, void* partials, int nblocks, void* out, void* stream);
+
+/* XiT multi-head attention core, per (sequence b, head h): S = Q K^T (no pre-scale), P = softmax(S) * post_scale,
+ * O = P V.  Q/O: [batch*Lq, heads*hd]; K/V: [batch*Lk, heads*hd].  Lq<=256, Lk<=16, hd<=96, hd%4==0.
+ * replaces: finetune/xit.py:133-146 (einsum, softmax, "/ scaling", einsum). */
+int lr2_xattn_fwd(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int Lq, int Lk,
+                  int head_dim, float post_scale, void* stream);
+/* Backward of lr2_xattn_fwd: recomputes P; writes dQ [batch*Lq, E], dK, dV [batch*Lk, E]. */
+int lr2_xattn_bwd(const void* Q, const void* K, const void* V, const void* dO, void* dQ, void* dK, void* dV,
+                  int batch, int heads, int Lq, int Lk, int head_dim, float post_scale, void* stream);
+
+/* TencentPretrain self-attention core, per (sequence, head): S = Q K^T * scale + (seg[key]>0 ? 0 : -10000),
+ * P = softmax(S), O = P V.  Q,K,V,O [batch*L, heads*hd]; seg int64 [batch*L]; L <= 256, hd == 64.
+ * replaces: tencentpretrain/layers/multi_headed_attn.py:61-74 and the mask of encoders/transformer_encoder.py:62-68. */
+int lr2_self_attn_fwd(const void* Q, const void* K, const void* V, const int64_t* seg, void* O, int batch, int heads,
+                      int L, int head_dim, float scale, void* stream);
+
+/* y[r] = dot(x[row(r)], w) + b for r < rows, row(r) = r*row_step + row_off.
+ * replaces: self.head = nn.Linear(768, 1) and the last-position select (finetune/ppo.py:228-232,293-295). */
+int lr2_head_fwd(const void* x, const void* w, const void* b, void* y, int rows, int D, int row_step, int row_off,
+                 void* stream);
+/* dx[total_rows, D] = 0 except dx[row(r)] = dy[r]*w;  dw = sum_r dy[r]*x[row(r)];  db = sum_r dy[r]. */
+int lr2_head_bwd(const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, int rows, int D,
+                 int row_step, int row_off, int total_rows, void* stream);
+
+/* out[r, :] = x[r, :] + table[r % period, :].  replaces: x + pos_emb (finetune/ppo.py:286-289,339-342). */
+int lr2_add_period_rows(const void* x, const void* table, void* out, int rows, int D, int period, void* stream);
+/* dtable[t, :] = sum over rows r with r % period == t of dy[r, :]  (t < period; other rows of dtable untouched). */
+int lr2_period_rows_grad(const void* dy, void* dtable, int rows, int D, int period, void* stream);
+
+/* Fused PPO losses + analytic gradients for one minibatch (T = tags per item, T <= 8, B <= 1024).
+ * Inputs fp32: scores[B,T] (new), old_scores[B,T], rewards[B], old_value[B], value[B]; int64 next_state[B,ns_len]
+ * (its last rank_len entries give the actor's descending order; the reference hard-codes 2, ppo.py:565-567).
+ * Outputs fp32:
+ *   scalars[0]=policy loss, [1]=value loss, [2]=rank loss, [3]=positive-hinge count;
+ *   per_item[4][B] = kl, entropy, rewards (r - w_kl*kl), advantages; dscores[B,T]; dvalue[B].
+ * replaces: finetune/ppo.py:544-584 (KL, entropy, advantage, flipped order, RankLoss :43-55, clipped value
+ * loss :494-498) and their autograd backward. */
+int lr2_ppo_loss(const void* scores, const void* old_scores, const void* rewards, const void* old_value,
+                 const void* value, const int64_t* next_state, int ns_len, int rank_len, int B, int T, float kl_w,
+                 float ent_w, float value_clip, float margin, float adv_eps, void* scalars, void* per_item,
+                 void* dscores, void* dvalue, void* stream);
+
+/* SmoothL1(beta) mean loss + gradient (dpred may be NULL).  replaces: nn.SmoothL1Loss(beta=0.3) (finetune/ppo.py:236). */
+int lr2_smooth_l1(const void* pred, const void* target, int n, float beta, void* loss, void* dpred, void* stream);
+
+/* One chunk of the multi-tensor AdamW: `count` fp32 elements starting at p/g/m/v. */
+typedef struct lr2_adamw_chunk {
+  void* p;
+  const void* g;
+  void* m;
+  void* v;
+  uint64_t count;
+  float weight_decay;
+  float _pad;
+} lr2_adamw_chunk;
+/* table: DEVICE array of n_chunks lr2_adamw_chunk (one workgroup per chunk).  Update (correct_bias=False):
+ *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * m/(sqrt(v)+eps); then p -= lr*wd*p.
+ * replaces: tencentpretrain/utils/optimizers.py:344-402 (AdamW.step), including its decay-after-update order. */
+int lr2_adamw_multi(const lr2_adamw_chunk* table_dev, int n_chunks, double lr, double beta1, double beta2,
+                    double eps, void* stream);
+
+/* Tokens -> embeddings: out[r,:] = word[src[r]] + pos[r % L] + seg_table[seg[r]].
+ * replaces: tencentpretrain/embeddings/{word,pos,seg}_embedding.py forward sums (embedding.py:19-30). */
+int lr2_text_embed(const int64_t* src, const int64_t* seg, const void* word, const void* pos, const void* seg_table,
+                   void* out, int rows, int L, int D, void* stream);
+/* Image -> patch rows: out[(b*P + p), c*ps*ps + i*ps + j] = img[b, c, py*ps+i, px*ps+j].
+ * replaces: the unfold implied by nn.Conv2d(k=s=patch) in tencentpretrain/embeddings/patch_embedding.py:18,27. */
+int lr2_patchify(const void* img, void* out, int B, int C, int H, int W, int ps, void* stream);
+/* ViT embedding assembly: out[b,0,:] = cls + pos[0]; out[b,1+p,:] = patch_proj[b*P+p,:] + pos[1+p].
+ * replaces: patch_embedding.py:28-29 (cls concat) + pos_embedding.py:30-35 + embedding.py:27-30. */
+int lr2_vit_assemble(const void* patch_proj, const void* cls, const void* pos, void* out, int B, int P, int D,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LR2PPO_HIP_H */

@@ -1,0 +1,295 @@
+// Attention cores for gfx950.
+//  * XiT cross-attention (finetune/xit.py:125-148): Lq = 196 text tokens against Lk = 16 image tokens, 8 heads
+//    of 96; softmax(Q K^T) with NO pre-scale, probabilities divided by sqrt(768) afterwards; the "causal" mask
+//    of the reference is a no-op (xit.py:140) and is therefore not implemented.  K/V of one (sequence, head)
+//    are 2 x 6 KiB and live in LDS; one lane owns one query row, the 16 scores stay in registers, softmax
+//    needs no cross-lane traffic at all.
+//  * TencentPretrain self-attention (layers/multi_headed_attn.py:61-74): L <= 256, head 64, additive
+//    -10000 key mask from `seg` applied after the 1/sqrt(d) scale.
+#include "common.h"
+#include "lr2ppo_hip.h"
+
+namespace {
+
+constexpr int MAX_LK = 16;
+constexpr int MAX_HD = 96;
+
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                        const float* __restrict__ V, float* __restrict__ O, int heads,
+                                                        int Lq, int Lk, int hd, float post_scale) {
+  __shared__ __attribute__((aligned(16))) float sK[MAX_LK][MAX_HD];
+  __shared__ __attribute__((aligned(16))) float sV[MAX_LK][MAX_HD];
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int E = heads * hd;
+  const int t = threadIdx.x;
+  for (int idx = t; idx < MAX_LK * hd; idx += 256) {
+    const int j = idx / hd, d = idx % hd;
+    float kv = 0.f, vv = 0.f;
+    if (j < Lk) {
+      const size_t o = ((size_t)b * Lk + j) * E + (size_t)h * hd + d;
+      kv = K[o];
+      vv = V[o];
+    }
+    sK[j][d] = kv;
+    sV[j][d] = vv;
+  }
+  __syncthreads();
+  if (t >= Lq) return;
+  const float* q = Q + ((size_t)b * Lq + t) * E + (size_t)h * hd;
+  float s[MAX_LK];
+#pragma unroll
+  for (int j = 0; j < MAX_LK; ++j) s[j] = 0.f;
+  for (int d = 0; d < hd; d += 4) {
+    const float4 q4 = *reinterpret_cast<const float4*>(q + d);
+#pragma unroll
+    for (int j = 0; j < MAX_LK; ++j) {
+      const float4 k4 = *reinterpret_cast<const float4*>(&sK[j][d]);
+      s[j] += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < MAX_LK; ++j) mx = (j < Lk) ? fmaxf(mx, s[j]) : mx;
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAX_LK; ++j) {
+    s[j] = (j < Lk) ? expf(s[j] - mx) : 0.f;
+    sum += s[j];
+  }
+  const float inv = post_scale / sum;
+#pragma unroll
+  for (int j = 0; j < MAX_LK; ++j) s[j] *= inv;
+  float* o = O + ((size_t)b * Lq + t) * E + (size_t)h * hd;
+  for (int d = 0; d < hd; d += 4) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < MAX_LK; ++j) {
+      const float4 v4 = *reinterpret_cast<const float4*>(&sV[j][d]);
+      a.x += s[j] * v4.x; a.y += s[j] * v4.y; a.z += s[j] * v4.z; a.w += s[j] * v4.w;
+    }
+    *reinterpret_cast<float4*>(o + d) = a;
+  }
+}
+
+// Backward.  O = sum_j (c p_j) V_j, p = softmax(S), S = Q K^T, c = post_scale:
+//   dPs_j = c (dO . V_j);  dS_j = p_j (dPs_j - sum_j' p_j' dPs_j');  dQ = sum_j dS_j K_j
+//   dK_j = sum_q dS_qj Q_q;  dV_j = sum_q c p_qj dO_q
+__global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                        const float* __restrict__ V, const float* __restrict__ dO,
+                                                        float* __restrict__ dQ, float* __restrict__ dK,
+                                                        float* __restrict__ dV, int heads, int Lq, int Lk, int hd,
+                                                        float post_scale) {
+  extern __shared__ __attribute__((aligned(16))) float bwd_smem[];
+  typedef float RowK[MAX_HD];
+  typedef float RowP[MAX_LK];
+  typedef float RowA[MAX_HD + 1];
+  RowK* sK = reinterpret_cast<RowK*>(bwd_smem);                              // [MAX_LK][MAX_HD]
+  RowK* sV = sK + MAX_LK;                                                    // [MAX_LK][MAX_HD]
+  RowP* sP = reinterpret_cast<RowP*>(sV + MAX_LK);                           // [256][MAX_LK]  c * p
+  RowP* sS = sP + 256;                                                       // [256][MAX_LK]  dS
+  RowA (*sAcc)[2 * MAX_LK] = reinterpret_cast<RowA (*)[2 * MAX_LK]>(sS + 256);  // [2][2*MAX_LK][MAX_HD+1]
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int E = heads * hd;
+  const int t = threadIdx.x;
+  for (int idx = t; idx < MAX_LK * hd; idx += 256) {
+    const int j = idx / hd, d = idx % hd;
+    float kv = 0.f, vv = 0.f;
+    if (j < Lk) {
+      const size_t o = ((size_t)b * Lk + j) * E + (size_t)h * hd + d;
+      kv = K[o];
+      vv = V[o];
+    }
+    sK[j][d] = kv;
+    sV[j][d] = vv;
+  }
+  __syncthreads();
+  if (t < Lq) {
+    const size_t ro = ((size_t)b * Lq + t) * E + (size_t)h * hd;
+    float s[MAX_LK], dp[MAX_LK];
+#pragma unroll
+    for (int j = 0; j < MAX_LK; ++j) { s[j] = 0.f; dp[j] = 0.f; }
+    for (int d = 0; d < hd; d += 4) {
+      const float4 q4 = *reinterpret_cast<const float4*>(Q + ro + d);
+      const float4 g4 = *reinterpret_cast<const float4*>(dO + ro + d);
+#pragma unroll
+      for (int j = 0; j < MAX_LK; ++j) {
+        const float4 k4 = *reinterpret_cast<const float4*>(&sK[j][d]);
+        const float4 v4 = *reinterpret_cast<const float4*>(&sV[j][d]);
+        s[j] += q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+        dp[j] += g4.x * v4.x + g4.y * v4.y + g4.z * v4.z + g4.w * v4.w;
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MAX_LK; ++j) mx = (j < Lk) ? fmaxf(mx, s[j]) : mx;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_LK; ++j) {
+      s[j] = (j < Lk) ? expf(s[j] - mx) : 0.f;
+      sum += s[j];
+    }
+    const float inv = 1.0f / sum;
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAX_LK; ++j) {
+      s[j] *= inv;                 // p_j
+      dp[j] *= post_scale;         // dL/dp_j
+      dot += s[j] * dp[j];
+    }
+#pragma unroll
+    for (int j = 0; j < MAX_LK; ++j) {
+      const float ds = s[j] * (dp[j] - dot);
+      sS[t][j] = ds;
+      sP[t][j] = s[j] * post_scale;
+      dp[j] = ds;
+    }
+    for (int d = 0; d < hd; d += 4) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int j = 0; j < MAX_LK; ++j) {
+        const float4 k4 = *reinterpret_cast<const float4*>(&sK[j][d]);
+        a.x += dp[j] * k4.x; a.y += dp[j] * k4.y; a.z += dp[j] * k4.z; a.w += dp[j] * k4.w;
+      }
+      *reinterpret_cast<float4*>(dQ + ro + d) = a;
+    }
+  }
+  __syncthreads();
+  // dK / dV: thread <-> (column d, half of the query rows); 16 + 16 accumulators per thread
+  {
+    const int d = t & 127, part = t >> 7;
+    const int half = (Lq + 1) / 2;
+    const int q0 = part * half;
+    const int q1 = (q0 + half < Lq) ? q0 + half : Lq;
+    float ak[MAX_LK], av[MAX_LK];
+#pragma unroll
+    for (int j = 0; j < MAX_LK; ++j) { ak[j] = 0.f; av[j] = 0.f; }
+    if (d < hd) {
+      for (int q = q0; q < q1; ++q) {
+        const size_t ro = ((size_t)b * Lq + q) * E + (size_t)h * hd + d;
+        const float x = Q[ro], y = dO[ro];
+#pragma unroll
+        for (int j4 = 0; j4 < MAX_LK; j4 += 4) {
+          const float4 ds4 = *reinterpret_cast<const float4*>(&sS[q][j4]);
+          const float4 p4 = *reinterpret_cast<const float4*>(&sP[q][j4]);
+          ak[j4 + 0] += ds4.x * x; ak[j4 + 1] += ds4.y * x; ak[j4 + 2] += ds4.z * x; ak[j4 + 3] += ds4.w * x;
+          av[j4 + 0] += p4.x * y; av[j4 + 1] += p4.y * y; av[j4 + 2] += p4.z * y; av[j4 + 3] += p4.w * y;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < MAX_LK; ++j) {
+        sAcc[part][j][d] = ak[j];
+        sAcc[part][MAX_LK + j][d] = av[j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = t; idx < Lk * hd; idx += 256) {
+    const int j = idx / hd, d = idx % hd;
+    const size_t o = ((size_t)b * Lk + j) * E + (size_t)h * hd + d;
+    dK[o] = sAcc[0][j][d] + sAcc[1][j][d];
+    dV[o] = sAcc[0][MAX_LK + j][d] + sAcc[1][MAX_LK + j][d];
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Encoder self-attention, head_dim 64.  One workgroup per (sequence, head); K and V of the head in LDS
+// (2 x L x 64 fp32 <= 128 KiB of the CU's 160 KiB); one lane owns one query row and runs an online softmax.
+constexpr int SA_HD = 64;
+__global__ __launch_bounds__(256) void self_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                            const float* __restrict__ V, const int64_t* __restrict__ seg,
+                                                            float* __restrict__ O, int heads, int L, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sK = smem;                 // [L][64]
+  float* sV = smem + (size_t)L * SA_HD;
+  float* sM = sV + (size_t)L * SA_HD;  // [L] additive mask
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int E = heads * SA_HD;
+  const int t = threadIdx.x;
+  for (int idx = t; idx < L * (SA_HD / 4); idx += 256) {
+    const int j = idx / (SA_HD / 4), d4 = idx % (SA_HD / 4);
+    const size_t o = ((size_t)b * L + j) * E + (size_t)h * SA_HD + d4 * 4;
+    *reinterpret_cast<float4*>(sK + j * SA_HD + d4 * 4) = *reinterpret_cast<const float4*>(K + o);
+    *reinterpret_cast<float4*>(sV + j * SA_HD + d4 * 4) = *reinterpret_cast<const float4*>(V + o);
+  }
+  for (int j = t; j < L; j += 256) sM[j] = (seg[(size_t)b * L + j] > 0) ? 0.f : -10000.0f;
+  __syncthreads();
+  if (t >= L) return;
+  const size_t ro = ((size_t)b * L + t) * E + (size_t)h * SA_HD;
+  float4 q[SA_HD / 4], acc[SA_HD / 4];
+#pragma unroll
+  for (int i = 0; i < SA_HD / 4; ++i) {
+    q[i] = *reinterpret_cast<const float4*>(Q + ro + i * 4);
+    acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int j = 0; j < L; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < SA_HD / 4; ++i) {
+      const float4 k4 = *reinterpret_cast<const float4*>(sK + j * SA_HD + i * 4);
+      s += q[i].x * k4.x + q[i].y * k4.y + q[i].z * k4.z + q[i].w * k4.w;
+    }
+    s = s * scale + sM[j];
+    const float mn = fmaxf(m, s);
+    const float alpha = expf(m - mn), p = expf(s - mn);
+    l = l * alpha + p;
+    m = mn;
+#pragma unroll
+    for (int i = 0; i < SA_HD / 4; ++i) {
+      const float4 v4 = *reinterpret_cast<const float4*>(sV + j * SA_HD + i * 4);
+      acc[i].x = acc[i].x * alpha + p * v4.x;
+      acc[i].y = acc[i].y * alpha + p * v4.y;
+      acc[i].z = acc[i].z * alpha + p * v4.z;
+      acc[i].w = acc[i].w * alpha + p * v4.w;
+    }
+  }
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int i = 0; i < SA_HD / 4; ++i) {
+    float4 o4 = make_float4(acc[i].x * inv, acc[i].y * inv, acc[i].z * inv, acc[i].w * inv);
+    *reinterpret_cast<float4*>(O + ro + i * 4) = o4;
+  }
+}
+
+}  // namespace
+
+extern "C" int lr2_xattn_fwd(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int Lq, int Lk,
+                             int head_dim, float post_scale, void* stream) {
+  if (!Q || !K || !V || !O || batch <= 0 || heads <= 0) return LR2_ERR_ARG;
+  if (Lq < 1 || Lq > 256 || Lk < 1 || Lk > MAX_LK || head_dim > MAX_HD || head_dim % 4 != 0) return LR2_ERR_SHAPE;
+  hipLaunchKernelGGL(xattn_fwd_kernel, dim3(batch * heads), dim3(256), 0, (hipStream_t)stream, (const float*)Q,
+                     (const float*)K, (const float*)V, (float*)O, heads, Lq, Lk, head_dim, post_scale);
+  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+}
+
+extern "C" int lr2_xattn_bwd(const void* Q, const void* K, const void* V, const void* dO, void* dQ, void* dK, void* dV,
+                             int batch, int heads, int Lq, int Lk, int head_dim, float post_scale, void* stream) {
+  if (!Q || !K || !V || !dO || !dQ || !dK || !dV || batch <= 0 || heads <= 0) return LR2_ERR_ARG;
+  if (Lq < 1 || Lq > 256 || Lk < 1 || Lk > MAX_LK || head_dim > MAX_HD || head_dim % 4 != 0) return LR2_ERR_SHAPE;
+  const size_t lds = sizeof(float) * ((size_t)2 * MAX_LK * MAX_HD + 2 * 256 * MAX_LK + 2 * 2 * MAX_LK * (MAX_HD + 1));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)xattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(xattn_bwd_kernel, dim3(batch * heads), dim3(256), lds, (hipStream_t)stream, (const float*)Q,
+                     (const float*)K, (const float*)V, (const float*)dO, (float*)dQ, (float*)dK, (float*)dV, heads, Lq,
+                     Lk, head_dim, post_scale);
+  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+}
+
+extern "C" int lr2_self_attn_fwd(const void* Q, const void* K, const void* V, const int64_t* seg, void* O, int batch,
+                                 int heads, int L, int head_dim, float scale, void* stream) {
+  if (!Q || !K || !V || !seg || !O || batch <= 0 || heads <= 0) return LR2_ERR_ARG;
+  if (head_dim != SA_HD || L < 1 || L > 256) return LR2_ERR_SHAPE;
+  const size_t lds = ((size_t)2 * L * SA_HD + L) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)self_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(self_attn_fwd_kernel, dim3(batch * heads), dim3(256), lds, (hipStream_t)stream, (const float*)Q,
+                     (const float*)K, (const float*)V, seg, (float*)O, heads, L, scale);
+  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+}

@@ -1,0 +1,105 @@
+// Shared device helpers for the lr2ppo gfx950 kernels (CDNA4: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits in HBM / LDS
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// Counter-based dropout mask: keep(idx) is a pure function of (seed, site, flat element index).
+// The reference uses torch's Philox stream (nn.Dropout in finetune/xit.py:34,40,108), which cannot be
+// reproduced across backends; oracle/lr2ppo_oracle.py::dropout_keep_mask restates THIS function.
+__device__ __forceinline__ uint64_t dropout_key(uint64_t seed, uint32_t site) {
+  return (((uint64_t)site) << 40) ^ (seed * 0x9E3779B97F4A7C15ull);
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t key, uint64_t idx, uint32_t thr) {
+  uint64_t x = (idx ^ key) + 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x = x ^ (x >> 31);
+  return (uint32_t)(x >> 32) >= thr;
+}
+static inline uint32_t dropout_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  if (t < 0) t = 0;
+  return (uint32_t)t;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused GEMM epilogue description (shared by the MFMA kernel and the split-K reducer).
+// Applied per output element (m, n), in this order:
+//   v = acc * alpha (+ bias[n])
+//   act == 1 : z = v (optionally stored in out_z) ; v = gelu_erf(v)
+//   drop_p>0 : v = keep(m*N+n) ? v/(1-p) : 0
+//   act == 2 : v *= gelu_erf'(aux_z[m,n])            (backward through GELU; aux is the saved z)
+//   resid    : v += resid[m,n]                         (residual stream)
+//   accumulate: v += out[m,n]
+//   store out[m,n]
+// ---------------------------------------------------------------------------------------------
+struct Epilogue {
+  const float* bias;
+  const float* resid;
+  const float* aux_z;
+  float* out;
+  float* out_z;
+  int ld_resid, ld_aux, ld_out, ld_z;
+  int act;
+  int accumulate;
+  float alpha;
+  float drop_scale;      // 1/(1-p) or 0 when dropout is off
+  uint32_t drop_thr;
+  uint64_t drop_key;
+};
+
+__device__ __forceinline__ void epilogue_apply(const Epilogue& e, float acc, int m, int n, int N) {
+  float v = acc * e.alpha;
+  if (e.bias) v += e.bias[n];
+  if (e.act == 1) {
+    if (e.out_z) e.out_z[(size_t)m * e.ld_z + n] = v;
+    v = gelu_erf(v);
+  }
+  if (e.drop_scale != 0.0f) {
+    v = dropout_keep(e.drop_key, (uint64_t)m * (uint64_t)N + (uint64_t)n, e.drop_thr) ? v * e.drop_scale : 0.0f;
+  }
+  if (e.act == 2) v *= gelu_erf_grad(e.aux_z[(size_t)m * e.ld_aux + n]);
+  if (e.resid) v += e.resid[(size_t)m * e.ld_resid + n];
+  float* p = e.out + (size_t)m * e.ld_out + n;
+  if (e.accumulate) v += *p;
+  *p = v;
+}

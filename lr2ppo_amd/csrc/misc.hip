@@ -1,0 +1,519 @@
+// Small HBM-bound kernels of the LR2PPO hot path on gfx950: row gather / concat copies, the 768->1 head,
+// position-embedding add, the fused PPO loss (forward + analytic backward), SmoothL1, multi-tensor AdamW,
+// and the TencentPretrain embedding front-ends (word+pos+seg sum, patchify, ViT cls/pos assembly).
+#include "common.h"
+#include "lr2ppo_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ index,
+                                                          float* __restrict__ dst, int t_in, int t_out, uint64_t row_elems,
+                                                          uint64_t bstride, uint64_t tstride) {
+  const int row = blockIdx.y;  // b * t_out + j
+  const int b = row / t_out, j = row % t_out;
+  int64_t src_t = index ? index[(size_t)b * t_out + j] : j;
+  if (src_t < 0) src_t = 0;
+  if (src_t >= t_in) src_t = t_in - 1;
+  const float4* s = reinterpret_cast<const float4*>(src + (size_t)b * bstride + (size_t)src_t * tstride);
+  float4* d = reinterpret_cast<float4*>(dst + (size_t)row * row_elems);
+  const uint64_t n4 = row_elems / 4;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) d[i] = s[i];
+}
+
+// dsrc[b, t, :] = sum over j with index[b, j] == t of ddst[b, j, :]   (deterministic, no atomics)
+__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __restrict__ ddst, const int64_t* __restrict__ index,
+                                                              float* __restrict__ dsrc, int t_in, int t_out,
+                                                              uint64_t row_elems) {
+  const int row = blockIdx.y;  // b * t_in + t
+  const int b = row / t_in, t = row % t_in;
+  float4* d = reinterpret_cast<float4*>(dsrc + (size_t)row * row_elems);
+  const uint64_t n4 = row_elems / 4;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < t_out; ++j) {
+      const int64_t st = index ? index[(size_t)b * t_out + j] : j;
+      if (st == t) {
+        const float4 v = reinterpret_cast<const float4*>(ddst + ((size_t)b * t_out + j) * row_elems)[i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+    }
+    d[i] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,
+                                                        int D, int group, uint64_t gstride, uint64_t off) {
+  const int d4 = D / 4;
+  const size_t total = (size_t)rows * d4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / d4), c = (int)(i % d4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * D + c);
+    *reinterpret_cast<float4*>(dst + (size_t)(r / group) * gstride + (size_t)(r % group) * D + off + c) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ y, int rows, int D,
+                                                       int row_step, int row_off) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + ((size_t)r * row_step + row_off) * D;
+  float s = 0.f;
+  for (int e = lane * 4; e < D; e += 256) {
+    const float4 a = *reinterpret_cast<const float4*>(xr + e);
+    const float4 ww = *reinterpret_cast<const float4*>(w + e);
+    s += a.x * ww.x + a.y * ww.y + a.z * ww.z + a.w * ww.w;
+  }
+  s = wave_sum(s);
+  if (lane == 0) y[r] = s + b[0];
+}
+
+__global__ __launch_bounds__(256) void head_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int D, int row_step, int row_off,
+                                                          int total_rows) {
+  const int d4 = D / 4;
+  const size_t total = (size_t)total_rows * d4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / d4), c = (int)(i % d4) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row % row_step == row_off) {
+      const float g = dy[row / row_step];
+      const float4 ww = *reinterpret_cast<const float4*>(w + c);
+      v = make_float4(g * ww.x, g * ww.y, g * ww.z, g * ww.w);
+    }
+    *reinterpret_cast<float4*>(dx + (size_t)row * D + c) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dw, float* __restrict__ db, int rows, int D,
+                                                          int row_step, int row_off) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < D) {
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += dy[r] * x[((size_t)r * row_step + row_off) * D + c];
+    dw[c] = s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += dy[r];
+    db[0] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void add_period_rows_kernel(const float* __restrict__ x, const float* __restrict__ table,
+                                                              float* __restrict__ out, int rows, int D, int period) {
+  const int d4 = D / 4;
+  const size_t total = (size_t)rows * d4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / d4), c = (int)(i % d4) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(x + (size_t)r * D + c);
+    const float4 t = *reinterpret_cast<const float4*>(table + (size_t)(r % period) * D + c);
+    *reinterpret_cast<float4*>(out + (size_t)r * D + c) = make_float4(a.x + t.x, a.y + t.y, a.z + t.z, a.w + t.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void period_rows_grad_kernel(const float* __restrict__ dy, float* __restrict__ dtable,
+                                                               int rows, int D, int period) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= period * D) return;
+  const int t = idx / D, c = idx % D;
+  float s = 0.f;
+  for (int r = t; r < rows; r += period) s += dy[(size_t)r * D + c];
+  dtable[(size_t)t * D + c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused PPO loss, one workgroup, one thread per item (finetune/ppo.py:544-584).
+constexpr int PPO_MAX_T = 8;
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+__device__ __forceinline__ float clamped_log(float t) { return logf(fmaxf(t, 1e-20f)); }
+
+__global__ __launch_bounds__(1024) void ppo_loss_kernel(const float* __restrict__ scores, const float* __restrict__ old_scores,
+                                                        const float* __restrict__ rewards, const float* __restrict__ old_value,
+                                                        const float* __restrict__ value, const int64_t* __restrict__ next_state,
+                                                        int ns_len, int rank_len, int B, int T, float kl_w, float ent_w, float clip,
+                                                        float margin, float adv_eps, float* __restrict__ scalars,
+                                                        float* __restrict__ per_item, float* __restrict__ dscores,
+                                                        float* __restrict__ dvalue) {
+  __shared__ float red[16];
+  const int i = threadIdx.x;
+  const bool act = i < B;
+  float s[PPO_MAX_T], p[PPO_MAX_T], qo[PPO_MAX_T], dR[PPO_MAX_T];
+  int order[PPO_MAX_T];
+  float kl = 0.f, ent = 0.f, r = 0.f, adv = 0.f, hsum = 0.f, hcnt = 0.f, vl = 0.f, dv = 0.f;
+#pragma unroll
+  for (int t = 0; t < PPO_MAX_T; ++t) { s[t] = 0.f; p[t] = 0.f; qo[t] = 0.f; dR[t] = 0.f; order[t] = 0; }
+  if (act) {
+    float mx = -INFINITY, mo = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < PPO_MAX_T; ++t)
+      if (t < T) {
+        s[t] = scores[(size_t)i * T + t];
+        qo[t] = old_scores[(size_t)i * T + t];
+        mx = fmaxf(mx, s[t]);
+        mo = fmaxf(mo, qo[t]);
+      }
+    float zs = 0.f, zo = 0.f;
+#pragma unroll
+    for (int t = 0; t < PPO_MAX_T; ++t)
+      if (t < T) {
+        p[t] = expf(s[t] - mx);
+        qo[t] = expf(qo[t] - mo);
+        zs += p[t];
+        zo += qo[t];
+      }
+#pragma unroll
+    for (int t = 0; t < PPO_MAX_T; ++t)
+      if (t < T) {
+        p[t] /= zs;
+        qo[t] /= zo;
+        if (kl_w > 0.f) kl += qo[t] * (clamped_log(qo[t]) - clamped_log(p[t]));
+        if (ent_w > 0.f) ent -= p[t] * clamped_log(p[t]);
+      }
+    r = rewards[i] - kl * kl_w;
+    adv = r - old_value[i];
+    const bool keep = adv >= adv_eps;
+    // target order = the last rank_len entries of next_state (the reference hard-codes [-2:], finetune/ppo.py:565-567)
+#pragma unroll
+    for (int t = 0; t < PPO_MAX_T; ++t)
+      if (t < rank_len) {
+        const int src = keep ? t : (rank_len - 1 - t);
+        order[t] = (int)next_state[(size_t)i * ns_len + (ns_len - rank_len) + src];
+      }
+    // pairwise hinge over positions a < b of the target order (RankLoss, finetune/ppo.py:43-55)
+#pragma unroll
+    for (int a = 0; a < PPO_MAX_T; ++a)
+#pragma unroll
+      for (int bq = 0; bq < PPO_MAX_T; ++bq)
+        if (a < bq && bq < rank_len) {
+          float sa = 0.f, sb = 0.f;
+#pragma unroll
+          for (int t = 0; t < PPO_MAX_T; ++t) {
+            sa = (order[a] == t) ? s[t] : sa;
+            sb = (order[bq] == t) ? s[t] : sb;
+          }
+          const float hgap = margin - (sa - sb);
+          if (hgap > 0.f) {
+            hsum += hgap;
+            hcnt += 1.f;
+#pragma unroll
+            for (int t = 0; t < PPO_MAX_T; ++t) {
+              dR[t] += (order[a] == t) ? -1.f : 0.f;
+              dR[t] += (order[bq] == t) ? 1.f : 0.f;
+            }
+          }
+        }
+    // clipped value loss (finetune/ppo.py:494-498) with r' detached (:583)
+    const float v = value[i], ov = old_value[i];
+    const float dlt = v - ov;
+    const float cl = fminf(fmaxf(dlt, -clip), clip);
+    const float vc = ov + cl;
+    const float l1 = (vc - r) * (vc - r), l2 = (v - r) * (v - r);
+    vl = fmaxf(l1, l2);
+    const float g1 = (dlt >= -clip && dlt <= clip) ? 2.f * (vc - r) : 0.f;
+    const float g2 = 2.f * (v - r);
+    dv = (l1 > l2) ? g1 : ((l1 == l2) ? 0.5f * (g1 + g2) : g2);
+  }
+  const float HS = block_sum_1024(hsum, red);
+  const float CNT = block_sum_1024(hcnt, red);
+  const float ABS = block_sum_1024(fabsf(adv), red);
+  const float ENT = block_sum_1024(ent, red);
+  const float VL = block_sum_1024(vl, red);
+  const float invB = 1.0f / (float)B;
+  const float R = (CNT > 0.f) ? HS / CNT : 0.f;
+  if (threadIdx.x == 0) {
+    scalars[0] = R * ABS * invB - ent_w * ENT * invB;
+    scalars[1] = VL * invB;
+    scalars[2] = R;
+    scalars[3] = CNT;
+  }
+  if (act) {
+    per_item[0 * (size_t)B + i] = kl;
+    per_item[1 * (size_t)B + i] = ent;
+    per_item[2 * (size_t)B + i] = r;
+    per_item[3 * (size_t)B + i] = adv;
+    const float sgn = (adv > 0.f) ? 1.f : ((adv < 0.f) ? -1.f : 0.f);
+    const float invC = (CNT > 0.f) ? 1.0f / CNT : 0.f;
+#pragma unroll
+    for (int t = 0; t < PPO_MAX_T; ++t)
+      if (t < T) {
+        float gsc = ABS * invB * invC * dR[t];
+        if (kl_w > 0.f) gsc += R * invB * sgn * (-kl_w) * (p[t] - qo[t]);
+        if (ent_w > 0.f) gsc += ent_w * invB * p[t] * (clamped_log(p[t]) + ent);
+        dscores[(size_t)i * T + t] = gsc;
+      }
+    dvalue[i] = dv * invB;
+  }
+}
+
+__global__ __launch_bounds__(1024) void smooth_l1_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, int n,
+                                                         float beta, float* __restrict__ loss, float* __restrict__ dpred) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float d = pred[i] - tgt[i], a = fabsf(d);
+    acc += (a < beta) ? 0.5f * d * d / beta : a - 0.5f * beta;
+    if (dpred) dpred[i] = ((a < beta) ? d / beta : ((d > 0.f) ? 1.f : -1.f)) / (float)n;
+  }
+  const float s = block_sum_1024(acc, red);
+  if (threadIdx.x == 0) loss[0] = s / (float)n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdamW, correct_bias=False, decay applied after the Adam update with the same lr
+// (tencentpretrain/utils/optimizers.py:381-400).  28 B of HBM traffic per parameter.
+struct AdamChunk {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  uint64_t count;
+  float wd;
+  float pad;
+};
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict__ table, float lr, float b1, float b2,
+                                                    float ob1, float ob2, float eps) {
+  const AdamChunk c = table[blockIdx.x];
+  const uint64_t n4 = c.count / 4;
+  const float decay = lr * c.wd;
+  float4* p4 = reinterpret_cast<float4*>(c.p);
+  const float4* g4 = reinterpret_cast<const float4*>(c.g);
+  float4* m4 = reinterpret_cast<float4*>(c.m);
+  float4* v4 = reinterpret_cast<float4*>(c.v);
+#define ADAM1(P, G, M, V)                     \
+  {                                           \
+    M = M * b1 + G * ob1;                     \
+    V = V * b2 + G * G * ob2;                 \
+    P = P - lr * (M / (sqrtf(V) + eps));      \
+    if (c.wd > 0.f) P = P + P * (-decay);     \
+  }
+  for (uint64_t i = threadIdx.x; i < n4; i += 256) {
+    float4 p = p4[i], g = g4[i], m = m4[i], v = v4[i];
+    ADAM1(p.x, g.x, m.x, v.x) ADAM1(p.y, g.y, m.y, v.y) ADAM1(p.z, g.z, m.z, v.z) ADAM1(p.w, g.w, m.w, v.w)
+    p4[i] = p; m4[i] = m; v4[i] = v;
+  }
+  for (uint64_t i = n4 * 4 + threadIdx.x; i < c.count; i += 256) {
+    float p = c.p[i], g = c.g[i], m = c.m[i], v = c.v[i];
+    ADAM1(p, g, m, v)
+    c.p[i] = p; c.m[i] = m; c.v[i] = v;
+  }
+#undef ADAM1
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ seg,
+                                                         const float* __restrict__ word, const float* __restrict__ pos,
+                                                         const float* __restrict__ seg_table, float* __restrict__ out,
+                                                         int rows, int L, int D) {
+  const int d4 = D / 4;
+  const size_t total = (size_t)rows * d4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / d4), c = (int)(i % d4) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(word + (size_t)src[r] * D + c);
+    const float4 b = *reinterpret_cast<const float4*>(pos + (size_t)(r % L) * D + c);
+    const float4 s = *reinterpret_cast<const float4*>(seg_table + (size_t)seg[r] * D + c);
+    // same association as the reference: (word + pos) + seg   (embeddings/embedding.py:24-30)
+    *reinterpret_cast<float4*>(out + (size_t)r * D + c) =
+        make_float4((a.x + b.x) + s.x, (a.y + b.y) + s.y, (a.z + b.z) + s.z, (a.w + b.w) + s.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int C,
+                                                       int H, int W, int ps) {
+  const int px = W / ps, py = H / ps, P = px * py, Kd = C * ps * ps;
+  const size_t total = (size_t)B * P * Kd;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % Kd);
+    const size_t bp = i / Kd;
+    const int p = (int)(bp % P), b = (int)(bp / P);
+    const int c = k / (ps * ps), ij = k % (ps * ps), ii = ij / ps, jj = ij % ps;
+    const int y = (p / px) * ps + ii, x = (p % px) * ps + jj;
+    out[i] = img[(((size_t)b * C + c) * H + y) * W + x];
+  }
+}
+
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ proj, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, float* __restrict__ out, int B,
+                                                           int P, int D) {
+  const int d4 = D / 4;
+  const size_t total = (size_t)B * (P + 1) * d4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % d4) * 4;
+    const size_t bt = i / d4;
+    const int t = (int)(bt % (P + 1)), b = (int)(bt / (P + 1));
+    const float4 a = (t == 0) ? *reinterpret_cast<const float4*>(cls + c)
+                              : *reinterpret_cast<const float4*>(proj + ((size_t)b * P + (t - 1)) * D + c);
+    const float4 pe = *reinterpret_cast<const float4*>(pos + (size_t)t * D + c);
+    *reinterpret_cast<float4*>(out + bt * D + c) = make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, a.w + pe.w);
+  }
+}
+
+inline int grid_for(size_t work_items, int cap = 4096) {
+  size_t b = (work_items + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > (size_t)cap) b = cap;
+  return (int)b;
+}
+#define CHECK_LAUNCH() return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH
+
+}  // namespace
+
+extern "C" int lr2_abi_version(void) { return LR2_ABI_VERSION; }
+
+extern "C" int lr2_device_info(char* name, int len) {
+  hipDeviceProp_t prop;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return LR2_ERR_LAUNCH;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return LR2_ERR_LAUNCH;
+  if (name && len > 0) {
+    int i = 0;
+    for (; i < len - 1 && prop.gcnArchName[i]; ++i) name[i] = prop.gcnArchName[i];
+    name[i] = 0;
+  }
+  return prop.multiProcessorCount;
+}
+
+extern "C" int lr2_gather_rows(const void* src, const int64_t* index, void* dst, int B, int t_in, int t_out,
+                               uint64_t row_elems, uint64_t src_bstride, uint64_t src_tstride, void* stream) {
+  if (!src || !dst || B <= 0 || t_in <= 0 || t_out <= 0) return LR2_ERR_ARG;
+  if (row_elems % 4 || src_bstride % 4 || src_tstride % 4) return LR2_ERR_SHAPE;
+  dim3 grid(grid_for(row_elems / 4, 64), B * t_out);
+  hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, index, (float*)dst,
+                     t_in, t_out, row_elems, src_bstride, src_tstride);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_gather_rows_bwd(const void* ddst, const int64_t* index, void* dsrc, int B, int t_in, int t_out,
+                                   uint64_t row_elems, void* stream) {
+  if (!ddst || !dsrc || B <= 0 || t_in <= 0 || t_out <= 0) return LR2_ERR_ARG;
+  if (row_elems % 4) return LR2_ERR_SHAPE;
+  dim3 grid(grid_for(row_elems / 4, 64), B * t_in);
+  hipLaunchKernelGGL(gather_rows_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)ddst, index,
+                     (float*)dsrc, t_in, t_out, row_elems);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_copy_rows(const void* src, void* dst, int rows, int D, int group, uint64_t dst_gstride,
+                             uint64_t dst_off, void* stream) {
+  if (!src || !dst || rows <= 0 || D <= 0 || group <= 0) return LR2_ERR_ARG;
+  if (D % 4 || dst_gstride % 4 || dst_off % 4) return LR2_ERR_SHAPE;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((size_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)src, (float*)dst, rows, D, group, dst_gstride, dst_off);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_head_fwd(const void* x, const void* w, const void* b, void* y, int rows, int D, int row_step,
+                            int row_off, void* stream) {
+  if (!x || !w || !b || !y || rows <= 0 || row_step <= 0) return LR2_ERR_ARG;
+  if (D % 4) return LR2_ERR_SHAPE;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                     (const float*)w, (const float*)b, (float*)y, rows, D, row_step, row_off);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_head_bwd(const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, int rows, int D,
+                            int row_step, int row_off, int total_rows, void* stream) {
+  if (!x || !w || !dy || rows <= 0 || row_step <= 0) return LR2_ERR_ARG;
+  if (D % 4) return LR2_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dx) {
+    hipLaunchKernelGGL(head_bwd_dx_kernel, dim3(grid_for((size_t)total_rows * D / 4)), dim3(256), 0, s, (const float*)w,
+                       (const float*)dy, (float*)dx, D, row_step, row_off, total_rows);
+    if (hipGetLastError() != hipSuccess) return LR2_ERR_LAUNCH;
+  }
+  if (dw && db) {
+    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((D + 255) / 256), dim3(256), 0, s, (const float*)x, (const float*)dy,
+                       (float*)dw, (float*)db, rows, D, row_step, row_off);
+  }
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_add_period_rows(const void* x, const void* table, void* out, int rows, int D, int period,
+                                   void* stream) {
+  if (!x || !table || !out || rows <= 0 || period <= 0) return LR2_ERR_ARG;
+  if (D % 4) return LR2_ERR_SHAPE;
+  hipLaunchKernelGGL(add_period_rows_kernel, dim3(grid_for((size_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)x, (const float*)table, (float*)out, rows, D, period);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_period_rows_grad(const void* dy, void* dtable, int rows, int D, int period, void* stream) {
+  if (!dy || !dtable || rows <= 0 || period <= 0) return LR2_ERR_ARG;
+  hipLaunchKernelGGL(period_rows_grad_kernel, dim3((period * D + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)dy, (float*)dtable, rows, D, period);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_ppo_loss(const void* scores, const void* old_scores, const void* rewards, const void* old_value,
+                            const void* value, const int64_t* next_state, int ns_len, int rank_len, int B, int T,
+                            float kl_w, float ent_w, float value_clip, float margin, float adv_eps, void* scalars,
+                            void* per_item, void* dscores, void* dvalue, void* stream) {
+  if (!scores || !old_scores || !rewards || !old_value || !value || !next_state || !scalars || !per_item || !dscores ||
+      !dvalue)
+    return LR2_ERR_ARG;
+  if (B < 1 || B > 1024 || T < 1 || T > PPO_MAX_T || rank_len < 1 || rank_len > T || ns_len < rank_len) return LR2_ERR_SHAPE;
+  const int threads = ((B + 63) / 64) * 64;
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, (const float*)scores,
+                     (const float*)old_scores, (const float*)rewards, (const float*)old_value, (const float*)value,
+                     next_state, ns_len, rank_len, B, T, kl_w, ent_w, value_clip, margin, adv_eps, (float*)scalars,
+                     (float*)per_item, (float*)dscores, (float*)dvalue);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_smooth_l1(const void* pred, const void* target, int n, float beta, void* loss, void* dpred,
+                             void* stream) {
+  if (!pred || !target || !loss || n <= 0 || beta <= 0.f) return LR2_ERR_ARG;
+  hipLaunchKernelGGL(smooth_l1_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)pred,
+                     (const float*)target, n, beta, (float*)loss, (float*)dpred);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_adamw_multi(const lr2_adamw_chunk* table_dev, int n_chunks, double lr, double beta1, double beta2,
+                               double eps, void* stream) {
+  static_assert(sizeof(lr2_adamw_chunk) == sizeof(AdamChunk), "chunk layout");
+  if (!table_dev || n_chunks <= 0) return LR2_ERR_ARG;
+  // (1 - beta) is formed in double like the reference's Python scalars, then rounded once to fp32
+  hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)table_dev,
+                     (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_text_embed(const int64_t* src, const int64_t* seg, const void* word, const void* pos,
+                              const void* seg_table, void* out, int rows, int L, int D, void* stream) {
+  if (!src || !seg || !word || !pos || !seg_table || !out || rows <= 0 || L <= 0) return LR2_ERR_ARG;
+  if (D % 4) return LR2_ERR_SHAPE;
+  hipLaunchKernelGGL(text_embed_kernel, dim3(grid_for((size_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream, src,
+                     seg, (const float*)word, (const float*)pos, (const float*)seg_table, (float*)out, rows, L, D);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_patchify(const void* img, void* out, int B, int C, int H, int W, int ps, void* stream) {
+  if (!img || !out || B <= 0 || C <= 0 || ps <= 0) return LR2_ERR_ARG;
+  if (H % ps || W % ps) return LR2_ERR_SHAPE;
+  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)img, (float*)out, B, C, H, W, ps);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_vit_assemble(const void* patch_proj, const void* cls, const void* pos, void* out, int B, int P, int D,
+                                void* stream) {
+  if (!patch_proj || !cls || !pos || !out || B <= 0 || P <= 0) return LR2_ERR_ARG;
+  if (D % 4) return LR2_ERR_SHAPE;
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for((size_t)B * (P + 1) * D / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)patch_proj, (const float*)cls, (const float*)pos, (float*)out, B, P, D);
+  CHECK_LAUNCH();
+}

@@ -1,0 +1,234 @@
+// LayerNorm forward/backward and column reductions for gfx950.
+// One 64-lane wavefront per row: D = 768 is 3 float4 per lane; mean/variance by wave shuffles
+// (no LDS), HBM-bound.  replaces nn.LayerNorm (finetune/xit.py:37,74,93-94) and the TencentPretrain
+// LayerNorm (tencentpretrain/layers/layer_norm.py:5-21) plus their autograd backward.
+#include "common.h"
+#include "lr2ppo_hip.h"
+
+namespace {
+
+constexpr int MAXV = 4;  // float4 per lane -> D <= 1024
+
+__device__ __forceinline__ size_t mapped_row_offset(int r, int group, uint64_t group_stride, int D) {
+  return (size_t)(r / group) * group_stride + (size_t)(r % group) * D;
+}
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ out,
+                                                            float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, int rows, int D, float eps,
+                                                            int mode, int group, uint64_t group_stride) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* xr = x + (size_t)r * D;
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int e = (i * 64 + lane) * 4;
+    if (e < D) {
+      v[i] = *reinterpret_cast<const float4*>(xr + e);
+      s += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int e = (i * 64 + lane) * 4;
+    if (e < D) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + b * b + c * c + d * d;
+    }
+  }
+  q = wave_sum(q);
+  float rstd;
+  if (mode == 0) rstd = 1.0f / sqrtf(q / (float)D + eps);
+  else rstd = 1.0f / (sqrtf(q / (float)(D - 1)) + eps);
+  if (lane == 0) {
+    if (mean_out) mean_out[r] = mean;
+    if (rstd_out) rstd_out[r] = rstd;
+  }
+  const size_t off = mapped_row_offset(r, group, group_stride, D);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int e = (i * 64 + lane) * 4;
+    if (e < D) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + e);
+      const float4 b = *reinterpret_cast<const float4*>(beta + e);
+      float4 y;
+      y.x = (v[i].x - mean) * rstd * g.x + b.x;
+      y.y = (v[i].y - mean) * rstd * g.y + b.y;
+      y.z = (v[i].z - mean) * rstd * g.z + b.z;
+      y.w = (v[i].w - mean) * rstd * g.w + b.w;
+      *reinterpret_cast<float4*>(out + off + e) = y;
+    }
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma     (nn.LayerNorm backward)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int group, uint64_t group_stride,
+                                                            const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                            const float* __restrict__ resid_grad, float* __restrict__ dx_f32,
+                                                            float* __restrict__ dx_masked, float drop_scale, uint32_t drop_thr,
+                                                            uint64_t drop_key, float* __restrict__ partials, int rows, int D) {
+  __shared__ float red[4][2][MAXV * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 dg[MAXV], db[MAXV], gam[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int e = (i * 64 + lane) * 4;
+    gam[i] = (e < D) ? *reinterpret_cast<const float4*>(gamma + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    const float mean = mean_in[r], rstd = rstd_in[r];
+    const size_t doff = mapped_row_offset(r, group, group_stride, D);
+    float4 xh[MAXV], g[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      if (e < D) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * D + e);
+        const float4 dyv = *reinterpret_cast<const float4*>(dy + doff + e);
+        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        g[i] = make_float4(dyv.x * gam[i].x, dyv.y * gam[i].y, dyv.z * gam[i].z, dyv.w * gam[i].w);
+        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+        dg[i].x += dyv.x * xh[i].x; dg[i].y += dyv.y * xh[i].y; dg[i].z += dyv.z * xh[i].z; dg[i].w += dyv.w * xh[i].w;
+        db[i].x += dyv.x; db[i].y += dyv.y; db[i].z += dyv.z; db[i].w += dyv.w;
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      if (e < D) {
+        float4 d;
+        d.x = rstd * (g[i].x - c1 - xh[i].x * c2);
+        d.y = rstd * (g[i].y - c1 - xh[i].y * c2);
+        d.z = rstd * (g[i].z - c1 - xh[i].z * c2);
+        d.w = rstd * (g[i].w - c1 - xh[i].w * c2);
+        const size_t o = (size_t)r * D + e;
+        if (resid_grad) {
+          const float4 rg = *reinterpret_cast<const float4*>(resid_grad + o);
+          d.x += rg.x; d.y += rg.y; d.z += rg.z; d.w += rg.w;
+        }
+        if (dx_f32) *reinterpret_cast<float4*>(dx_f32 + o) = d;
+        if (dx_masked) {
+          float4 m = d;
+          if (drop_scale != 0.f) {
+            m.x = dropout_keep(drop_key, o + 0, drop_thr) ? d.x * drop_scale : 0.f;
+            m.y = dropout_keep(drop_key, o + 1, drop_thr) ? d.y * drop_scale : 0.f;
+            m.z = dropout_keep(drop_key, o + 2, drop_thr) ? d.z * drop_scale : 0.f;
+            m.w = dropout_keep(drop_key, o + 3, drop_thr) ? d.w * drop_scale : 0.f;
+          }
+          *reinterpret_cast<float4*>(dx_masked + o) = m;
+        }
+      }
+    }
+  }
+  // block reduce dgamma / dbeta over the 4 waves, then one partial row per block
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int e = (i * 64 + lane) * 4;
+    red[wave][0][e + 0] = dg[i].x; red[wave][0][e + 1] = dg[i].y; red[wave][0][e + 2] = dg[i].z; red[wave][0][e + 3] = dg[i].w;
+    red[wave][1][e + 0] = db[i].x; red[wave][1][e + 1] = db[i].y; red[wave][1][e + 2] = db[i].z; red[wave][1][e + 3] = db[i].w;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a += red[w][0][c];
+      b += red[w][1][c];
+    }
+    partials[(size_t)blockIdx.x * 2 * D + c] = a;
+    partials[(size_t)blockIdx.x * 2 * D + D + c] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void partials_finish_kernel(const float* __restrict__ partials, int nblocks, int cols,
+                                                              int ld, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * ld + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// thread <-> 4 adjacent columns, block <-> 1024 columns x one row chunk
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int rows, int cols, int ld,
+                                                     float* __restrict__ partials) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= cols) return;
+  const int chunk = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * chunk;
+  int r1 = r0 + chunk;
+  if (r1 > rows) r1 = rows;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = r0; r < r1; ++r) {
+    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ld + c);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4*>(partials + (size_t)blockIdx.y * cols + c) = s;
+}
+
+}  // namespace
+
+extern "C" int lr2_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* out, void* mean, void* rstd,
+                                 int rows, int D, float eps, int mode, int group, uint64_t group_stride, void* stream) {
+  if (!x || !gamma || !beta || !out || rows <= 0) return LR2_ERR_ARG;
+  if (D % 4 != 0 || D > MAXV * 256 || D < 4) return LR2_ERR_SHAPE;
+  if (group <= 0) { group = rows; group_stride = 0; }
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                     (const float*)gamma, (const float*)beta, (float*)out, (float*)mean, (float*)rstd, rows, D, eps,
+                     mode, group, group_stride);
+  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+}
+
+extern "C" int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_stride, const void* x, const void* gamma,
+                                 const void* mean, const void* rstd, const void* resid_grad, void* dx, void* dx_masked,
+                                 float drop_p, uint64_t drop_seed, uint32_t drop_site, void* partials, int nblocks,
+                                 int rows, int D, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !partials || (!dx && !dx_masked) || rows <= 0 || nblocks <= 0)
+    return LR2_ERR_ARG;
+  if (D % 4 != 0 || D > MAXV * 256 || D < 4) return LR2_ERR_SHAPE;
+  if (group <= 0) { group = rows; group_stride = 0; }
+  float scale = 0.f;
+  uint32_t thr = 0;
+  uint64_t key = 0;
+  if (drop_p > 0.f) {
+    scale = 1.0f / (1.0f - drop_p);
+    thr = dropout_threshold(drop_p);
+    key = (((uint64_t)drop_site) << 40) ^ (drop_seed * 0x9E3779B97F4A7C15ull);
+  }
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, group,
+                     group_stride, (const float*)x, (const float*)gamma, (const float*)mean, (const float*)rstd,
+                     (const float*)resid_grad, (float*)dx, (float*)dx_masked, scale, thr, key, (float*)partials, rows, D);
+  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+}
+
+extern "C" int lr2_colsum_partials_finish(const void* partials, int nblocks, int cols, int ld, void* out, int accumulate,
+                                          void* stream) {
+  if (!partials || !out || nblocks <= 0 || cols <= 0) return LR2_ERR_ARG;
+  hipLaunchKernelGGL(partials_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)partials, nblocks, cols, ld, (float*)out, accumulate);
+  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+}
+
+extern "C" int lr2_colsum(const void* x, int rows, int cols, int ld, void* partials, int nblocks, void* out,
+                          void* stream) {
+  if (!x || !partials || !out || rows <= 0 || cols <= 0 || nblocks <= 0) return LR2_ERR_ARG;
+  if (cols % 4 != 0 || ld % 4 != 0) return LR2_ERR_SHAPE;
+  if (nblocks > rows) nblocks = rows;
+  dim3 grid((cols + 1023) / 1024, nblocks);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, cols, ld,
+                     (float*)partials);
+  if (hipGetLastError() != hipSuccess) return LR2_ERR_LAUNCH;
+  return lr2_colsum_partials_finish(partials, nblocks, cols, cols, out, 0, stream);
+}

@@ -1,0 +1,253 @@
+"""Thin torch-tensor wrappers over the C ABI (include/lr2ppo_hip.h).
+
+PyTorch is used for device memory and streams only: every wrapper passes raw device pointers and the
+current HIP stream to the native library.  All tensors are fp32, contiguous, on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _native as _nat
+
+# GEMM precision: 3 = split-bf16 (fp32-grade, parity mode, default); 1 = single bf16 pass.
+_PASSES = 3
+
+
+def set_gemm_passes(p: int):
+    global _PASSES
+    if p not in (1, 3):
+        raise ValueError("passes must be 1 or 3")
+    _PASSES = p
+
+
+def get_gemm_passes() -> int:
+    return _PASSES
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise TypeError(f"expected a float32 HIP tensor, got {t.dtype} on {t.device}")
+
+
+class Drop:
+    """Dropout spec for one site: p, seed, site id (see csrc/common.h::dropout_keep)."""
+    __slots__ = ("p", "seed", "site")
+
+    def __init__(self, p: float, seed: int, site: int):
+        self.p, self.seed, self.site = float(p), int(seed), int(site)
+
+
+def choose_tiling(M: int, N: int, K: int, trans_a: bool):
+    """(block_m, splits): fill the 256 CUs (>= ~2 workgroups each) using split-K for skinny GEMMs."""
+    bm = 64 if (M <= 64 and not trans_a) else 128
+    tiles = ((M + bm - 1) // bm) * (N // 128)
+    k_tiles = (K + 63) // 64
+    splits = 1
+    if tiles < 256 and k_tiles >= 8:
+        splits = min(max(1, k_tiles // 4), (512 + tiles - 1) // tiles)
+    return bm, splits
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, trans_a=False, trans_b=False,
+         lda: Optional[int] = None, ldb: Optional[int] = None, ld_out: Optional[int] = None,
+         bias: Optional[torch.Tensor] = None, act: int = 0, out_z: Optional[torch.Tensor] = None,
+         aux_z: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, drop: Optional[Drop] = None,
+         accumulate: bool = False, alpha: float = 1.0, splitk_ws: Optional[torch.Tensor] = None,
+         splits: Optional[int] = None, block_m: Optional[int] = None, passes: Optional[int] = None):
+    """out[M,N] = op(a) @ op(b) with the fused epilogue; see lr2_gemm in include/lr2ppo_hip.h."""
+    _chk_f32(a, b, out, bias, out_z, aux_z, resid)
+    if lda is None:
+        lda = M if trans_a else K
+    if ldb is None:
+        ldb = N if trans_b else K
+    if ld_out is None:
+        ld_out = N
+    bm, sp = choose_tiling(M, N, K, trans_a)
+    if block_m is not None:
+        bm = block_m
+    if splits is not None:
+        sp = splits
+    if sp > 1:
+        need = sp * M * N
+        if splitk_ws is None or splitk_ws.numel() < need:
+            raise ValueError(f"split-K workspace too small: need {need} floats")
+    e = _nat.Epilogue()
+    e.bias, e.resid, e.aux_z, e.out, e.out_z = _ptr(bias), _ptr(resid), _ptr(aux_z), _ptr(out), _ptr(out_z)
+    e.ld_resid, e.ld_aux, e.ld_out, e.ld_z = _ld(resid, N), _ld(aux_z, N), ld_out, _ld(out_z, N)
+    e.act, e.accumulate, e.alpha = act, 1 if accumulate else 0, alpha
+    if drop is not None and drop.p > 0.0:
+        e.drop_p, e.drop_seed, e.drop_site = drop.p, drop.seed, drop.site
+    a_bytes, b_bytes = a.numel() * 4, b.numel() * 4
+    rc = _nat.lib().lr2_gemm(a.data_ptr(), b.data_ptr(), M, N, K, lda, ldb, 1 if trans_a else 0, 1 if trans_b else 0,
+                          a_bytes, b_bytes, C.byref(e), _ptr(splitk_ws), sp, bm, passes or _PASSES, _stream())
+    _nat.check(rc, f"lr2_gemm(M={M},N={N},K={K},ta={trans_a},tb={trans_b})")
+    return out
+
+
+def _ld(t: Optional[torch.Tensor], default: int) -> int:
+    return default if t is None else t.shape[-1]
+
+
+def layernorm_fwd(x, gamma, beta, out, mean=None, rstd=None, *, rows, D, eps=1e-5, mode=0, group=0, group_stride=0):
+    _chk_f32(x, gamma, beta, out, mean, rstd)
+    rc = _nat.lib().lr2_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), _ptr(mean),
+                                   _ptr(rstd), rows, D, eps, mode, group, group_stride, _stream())
+    _nat.check(rc, "lr2_layernorm_fwd")
+    return out
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partials, dgamma, dbeta, *, rows, D, group=0, group_stride=0,
+                  resid_grad=None, dx_masked=None, drop: Optional[Drop] = None, nblocks=256):
+    _chk_f32(dy, x, gamma, mean, rstd, dx, partials, dgamma, dbeta, resid_grad, dx_masked)
+    nb = min(nblocks, (rows + 3) // 4)
+    if partials.numel() < nb * 2 * D:
+        raise ValueError("layernorm_bwd partials workspace too small")
+    p, seed, site = (drop.p, drop.seed, drop.site) if drop is not None else (0.0, 0, 0)
+    L = _nat.lib()
+    rc = L.lr2_layernorm_bwd(dy.data_ptr(), group, group_stride, x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                             rstd.data_ptr(), _ptr(resid_grad), _ptr(dx), _ptr(dx_masked), p, seed, site,
+                             partials.data_ptr(), nb, rows, D, _stream())
+    _nat.check(rc, "lr2_layernorm_bwd")
+    _nat.check(L.lr2_colsum_partials_finish(partials.data_ptr(), nb, D, 2 * D, dgamma.data_ptr(), 0, _stream()), "finish")
+    _nat.check(L.lr2_colsum_partials_finish(partials.data_ptr() + 4 * D, nb, D, 2 * D, dbeta.data_ptr(), 0, _stream()),
+            "finish")
+
+
+def colsum(x, out, partials, *, rows, cols, ld=None, nblocks=128):
+    _chk_f32(x, out, partials)
+    nb = min(nblocks, rows)
+    if partials.numel() < nb * cols:
+        raise ValueError("colsum partials workspace too small")
+    rc = _nat.lib().lr2_colsum(x.data_ptr(), rows, cols, ld or cols, partials.data_ptr(), nb, out.data_ptr(), _stream())
+    _nat.check(rc, "lr2_colsum")
+    return out
+
+
+def xattn_fwd(q, k, v, o, *, batch, heads, Lq, Lk, head_dim, post_scale):
+    _chk_f32(q, k, v, o)
+    _nat.check(_nat.lib().lr2_xattn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), batch, heads, Lq, Lk, head_dim,
+                                  post_scale, _stream()), "lr2_xattn_fwd")
+    return o
+
+
+def xattn_bwd(q, k, v, do, dq, dk, dv, *, batch, heads, Lq, Lk, head_dim, post_scale):
+    _chk_f32(q, k, v, do, dq, dk, dv)
+    _nat.check(_nat.lib().lr2_xattn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                  dv.data_ptr(), batch, heads, Lq, Lk, head_dim, post_scale, _stream()), "lr2_xattn_bwd")
+
+
+def self_attn_fwd(q, k, v, seg, o, *, batch, heads, L, head_dim, scale):
+    _chk_f32(q, k, v, o)
+    if seg.dtype != torch.int64:
+        raise TypeError("seg must be int64")
+    _nat.check(_nat.lib().lr2_self_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), seg.data_ptr(), o.data_ptr(), batch, heads,
+                                      L, head_dim, scale, _stream()), "lr2_self_attn_fwd")
+    return o
+
+
+def gather_rows(src, index, dst, *, B, t_in, t_out, row_elems, src_bstride=None, src_tstride=None):
+    _chk_f32(src, dst)
+    if index is not None and index.dtype != torch.int64:
+        raise TypeError("index must be int64")
+    _nat.check(_nat.lib().lr2_gather_rows(src.data_ptr(), _ptr(index), dst.data_ptr(), B, t_in, t_out, row_elems,
+                                    src_bstride if src_bstride is not None else t_in * row_elems,
+                                    src_tstride if src_tstride is not None else row_elems, _stream()), "lr2_gather_rows")
+    return dst
+
+
+def gather_rows_bwd(ddst, index, dsrc, *, B, t_in, t_out, row_elems):
+    _chk_f32(ddst, dsrc)
+    _nat.check(_nat.lib().lr2_gather_rows_bwd(ddst.data_ptr(), _ptr(index), dsrc.data_ptr(), B, t_in, t_out, row_elems,
+                                        _stream()), "lr2_gather_rows_bwd")
+    return dsrc
+
+
+def copy_rows(src, dst, *, rows, D, group, dst_gstride, dst_off):
+    _chk_f32(src, dst)
+    _nat.check(_nat.lib().lr2_copy_rows(src.data_ptr(), dst.data_ptr(), rows, D, group, dst_gstride, dst_off, _stream()),
+            "lr2_copy_rows")
+    return dst
+
+
+def head_fwd(x, w, b, y, *, rows, D, row_step=1, row_off=0):
+    _chk_f32(x, w, b, y)
+    _nat.check(_nat.lib().lr2_head_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), rows, D, row_step, row_off,
+                                 _stream()), "lr2_head_fwd")
+    return y
+
+
+def head_bwd(x, w, dy, dx, dw, db, *, rows, D, row_step=1, row_off=0, total_rows=None):
+    _chk_f32(x, w, dy, dx, dw, db)
+    _nat.check(_nat.lib().lr2_head_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _ptr(dx), _ptr(dw), _ptr(db), rows, D,
+                                 row_step, row_off, total_rows if total_rows is not None else rows * row_step, _stream()),
+            "lr2_head_bwd")
+
+
+def add_period_rows(x, table, out, *, rows, D, period):
+    _chk_f32(x, table, out)
+    _nat.check(_nat.lib().lr2_add_period_rows(x.data_ptr(), table.data_ptr(), out.data_ptr(), rows, D, period, _stream()),
+            "lr2_add_period_rows")
+    return out
+
+
+def period_rows_grad(dy, dtable, *, rows, D, period):
+    _chk_f32(dy, dtable)
+    _nat.check(_nat.lib().lr2_period_rows_grad(dy.data_ptr(), dtable.data_ptr(), rows, D, period, _stream()),
+            "lr2_period_rows_grad")
+    return dtable
+
+
+def ppo_loss(scores, old_scores, rewards, old_value, value, next_state, scalars, per_item, dscores, dvalue, *, B, T,
+             kl_w, ent_w, value_clip, margin=0.01, adv_eps=-0.1, rank_len=2):
+    _chk_f32(scores, old_scores, rewards, old_value, value, scalars, per_item, dscores, dvalue)
+    if next_state.dtype != torch.int64 or not next_state.is_contiguous():
+        raise TypeError("next_state must be contiguous int64")
+    _nat.check(_nat.lib().lr2_ppo_loss(scores.data_ptr(), old_scores.data_ptr(), rewards.data_ptr(), old_value.data_ptr(),
+                                 value.data_ptr(), next_state.data_ptr(), next_state.shape[1], rank_len, B, T, kl_w, ent_w,
+                                 value_clip, margin, adv_eps, scalars.data_ptr(), per_item.data_ptr(), dscores.data_ptr(),
+                                 dvalue.data_ptr(), _stream()), "lr2_ppo_loss")
+
+
+def smooth_l1(pred, target, loss, dpred=None, *, n, beta=0.3):
+    _chk_f32(pred, target, loss, dpred)
+    _nat.check(_nat.lib().lr2_smooth_l1(pred.data_ptr(), target.data_ptr(), n, beta, loss.data_ptr(), _ptr(dpred), _stream()),
+            "lr2_smooth_l1")
+    return loss
+
+
+def adamw_multi(table_dev: torch.Tensor, n_chunks: int, lr: float, beta1: float, beta2: float, eps: float):
+    _nat.check(_nat.lib().lr2_adamw_multi(table_dev.data_ptr(), n_chunks, lr, beta1, beta2, eps, _stream()), "lr2_adamw_multi")
+
+
+def text_embed(src, seg, word, pos, seg_table, out, *, rows, L, D):
+    _chk_f32(word, pos, seg_table, out)
+    _nat.check(_nat.lib().lr2_text_embed(src.data_ptr(), seg.data_ptr(), word.data_ptr(), pos.data_ptr(), seg_table.data_ptr(),
+                                   out.data_ptr(), rows, L, D, _stream()), "lr2_text_embed")
+    return out
+
+
+def patchify(img, out, *, B, Cc, H, W, ps):
+    _chk_f32(img, out)
+    _nat.check(_nat.lib().lr2_patchify(img.data_ptr(), out.data_ptr(), B, Cc, H, W, ps, _stream()), "lr2_patchify")
+    return out
+
+
+def vit_assemble(proj, cls, pos, out, *, B, P, D):
+    _chk_f32(proj, cls, pos, out)
+    _nat.check(_nat.lib().lr2_vit_assemble(proj.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), B, P, D, _stream()),
+            "lr2_vit_assemble")
+    return out

@@ -1,0 +1,459 @@
+"""Generate tests/golden/* by IMPORTING THE REFERENCE (build container only).
+
+Run:  python -B oracle/gen_golden.py [--only NAME ...]
+
+The reference lives at /root/reference and never travels to the GPU box; this script freezes its
+outputs on seeded inputs as small data fixtures (inputs are rebuilt from seeds by
+oracle/lr2ppo_oracle.py, so only outputs / sampled weights are stored).  Recipe:
+cwd=/root/reference, sys.path += [".", "finetune"], stub `h5py` (only used by the MovieNet dataset),
+no-op Tensor.cuda (the reference hard-codes .cuda()), single-rank gloo group for train_model's
+logging all-reduces.  Nothing is written into the reference tree (python -B).
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(REPO, "tests", "golden")
+REF = "/root/reference"
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+os.chdir(REF)
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "finetune"))
+sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+
+from oracle import lr2ppo_oracle as O  # noqa: E402
+
+HEAD_ARGS = dict(mode="reg", labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768)
+
+
+def _ns(**kw):
+    return argparse.Namespace(**kw)
+
+
+def _load(model, params):
+    sd = {k: v.clone() for k, v in params.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=True), None
+    return model
+
+
+def _spec_of(model):
+    return [[n, list(p.shape)] for n, p in model.named_parameters()]
+
+
+def _save(name, **arrays):
+    path = os.path.join(GOLD, name)
+    np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
+    print("wrote", path, os.path.getsize(path + ("" if path.endswith(".npz") else ".npz")) // 1024, "KiB")
+
+
+# ------------------------------------------------------------------------------------------
+def gen_keys():
+    import ppo
+    from tencentpretrain.embeddings import Embedding, str2embedding
+    from tencentpretrain.encoders import str2encoder
+    args = _ns(**HEAD_ARGS)
+    out = {}
+    for kind, cls in (("actor", ppo.Actor), ("critic", ppo.Critic), ("reward", ppo.Reward)):
+        m = cls(args, None)
+        out[kind] = _spec_of(m)
+        assert [(n, tuple(s)) for n, s in out[kind]] == O.head_param_spec(kind), kind
+    ac = ppo.ActorCritic(args, None)
+    out["actor_critic_prefixes"] = sorted({k.split(".")[0] for k in ac.state_dict()})
+    for name, cfg in (("vit", "models/vit/base-16-224_config.json"), ("roberta", "models/xlm-roberta/base_config.json")):
+        a = _encoder_args(cfg)
+        emb = Embedding(a)
+        for e in a.embedding:
+            emb.update(str2embedding[e](a, 50265), e)
+        enc = str2encoder[a.encoder](a)
+        out[name + "_embedding"] = _spec_of(emb)
+        out[name + "_encoder"] = _spec_of(enc)
+    pre = out["vit_encoder"]
+    assert [(n, tuple(s)) for n, s in pre] == O.encoder_param_spec(12, 768, 3072, True)
+    assert [(n, tuple(s)) for n, s in out["roberta_encoder"]] == O.encoder_param_spec(12, 768, 3072, False)
+    assert [(n, tuple(s)) for n, s in out["vit_embedding"]] == O.vit_embedding_spec(768, 3, 16, 197)
+    assert [(n, tuple(s)) for n, s in out["roberta_embedding"]] == O.text_embedding_spec(768, 50265, 514)
+    with open(os.path.join(GOLD, "keys.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote keys.json")
+
+
+def _encoder_args(cfg_path, **over):
+    """argparse defaults of finetune_opts + JSON config, as load_hyperparam composes them
+    (tencentpretrain/opts.py, utils/config.py:6-23)."""
+    from tencentpretrain.opts import finetune_opts, tokenizer_opts
+    p = argparse.ArgumentParser()
+    finetune_opts(p)
+    tokenizer_opts(p)
+    a = p.parse_args(["--train_path", "x", "--dev_path", "x"]) if _needs_paths(p) else p.parse_args([])
+    with open(cfg_path) as f:
+        cfg = json.load(f)
+    d = vars(a)
+    d.update(cfg)
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+def _needs_paths(parser):
+    return any(a.required for a in parser._actions)
+
+
+# ------------------------------------------------------------------------------------------
+def gen_xit_small():
+    import xit as RX
+    torch.manual_seed(11)
+    d = 64
+    for mask in ("fully_visiable", "causal"):
+        pass
+    m_full = RX.XiT(feat_size=d).eval()
+    spec = [(n, tuple(p.shape)) for n, p in m_full.named_parameters()]
+    assert spec == [(n[len("xit."):], s) for n, s in O._xit_spec("xit", d)], "xit key order"
+    params = O.seeded_params(spec, seed=101, std=0.2)
+    m_full.load_state_dict(params, strict=True)
+    m_causal = RX.XiT(feat_size=d, attention_mask="causal").eval()
+    m_causal.load_state_dict(params, strict=True)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 7, d, generator=g)
+    y = torch.randn(3, 4, d, generator=g)
+    xs = torch.randn(3, 4, d, generator=g)
+    with torch.no_grad():
+        out = m_full((x.clone(), y.clone()))
+        out_self_full = m_full((xs.clone(), xs.clone()))
+        out_self_causal = m_causal((xs.clone(), xs.clone()))
+    assert torch.equal(out_self_full, out_self_causal), "causal mask is expected to be a no-op"
+    # gradients of sum(out * w) wrt inputs and params (dropout off)
+    m_full.zero_grad()
+    xg = x.clone().requires_grad_(True)
+    yg = y.clone().requires_grad_(True)
+    w = torch.randn(3, 7, d, generator=g)
+    (m_full((xg * 1.0, yg * 1.0)) * w).sum().backward()
+    grads = {"grad." + n: p.grad for n, p in m_full.named_parameters()}
+    _save("xit_small.npz", x=x, y=y, xs=xs, out=out, out_self=out_self_full, w=w, dx=xg.grad, dy=yg.grad,
+          causal_equals_full=np.array(1), **{"param." + k: v for k, v in params.items()}, **grads)
+
+
+def gen_losses():
+    import ppo
+    cases = {}
+    s = torch.tensor([[.3, .1], [.2, .5]])
+    o = torch.tensor([[0, 1], [0, 1]])
+    cases["hand_scores"], cases["hand_order"] = s, o
+    cases["hand_rank"] = ppo.RankLoss(0.01)(s, o)
+    s2 = torch.tensor([[.5, .1], [.9, .2]])
+    cases["zero_scores"], cases["zero_order"] = s2, o
+    cases["zero_rank"] = ppo.RankLoss(0.01)(s2, o)            # no positive hinge -> 0
+    g = torch.Generator().manual_seed(3)
+    rs = torch.randn(16, 2, generator=g) * 0.05
+    ro = torch.stack([torch.randperm(2, generator=g) for _ in range(16)])
+    cases["rand_scores"], cases["rand_order"] = rs, ro
+    cases["rand_rank"] = ppo.RankLoss(0.01)(rs, ro)
+    r5 = torch.randn(6, 5, generator=g)
+    o5 = torch.stack([torch.randperm(5, generator=g) for _ in range(6)])
+    cases["rand5_scores"], cases["rand5_order"] = r5, o5
+    cases["rand5_rank"] = ppo.RankLoss(1.0)(r5, o5)
+    v, r, ov = (torch.randn(16, generator=g) for _ in range(3))
+    cases["v"], cases["r"], cases["ov"] = v, r, ov
+    cases["vloss_05"] = ppo.clipped_value_loss(v, r, ov, 0.5)
+    cases["vloss_02"] = ppo.clipped_value_loss(v, r, ov, 0.2)
+    t = torch.randn(33, generator=g)
+    cases["norm_in"], cases["norm_out"] = t, ppo.masked_normalize(t)
+    _save("losses.npz", **cases)
+
+
+def gen_adamw_sched():
+    from tencentpretrain.utils.optimizers import AdamW, get_linear_schedule_with_warmup
+    g = torch.Generator().manual_seed(9)
+    shapes = [(5, 7), (7,), (3, 4, 2)]
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    p0 = [p.detach().clone() for p in ps]
+    opt = AdamW([{"params": [ps[0], ps[2]], "weight_decay": 0.01}, {"params": [ps[1]], "weight_decay": 0.0}],
+                lr=1e-2, correct_bias=False)
+    arrays = {}
+    for i, p in enumerate(p0):
+        arrays[f"p0_{i}"] = p
+    for step in range(3):
+        gs = [torch.randn(s, generator=g) * (10.0 ** (-step)) for s in shapes]
+        for p, gr in zip(ps, gs):
+            p.grad = gr.clone()
+        opt.step()
+        for i, (p, gr) in enumerate(zip(ps, gs)):
+            arrays[f"g{step}_{i}"] = gr
+            arrays[f"p{step + 1}_{i}"] = p.detach().clone()
+            arrays[f"m{step + 1}_{i}"] = opt.state[p]["exp_avg"].clone()
+            arrays[f"v{step + 1}_{i}"] = opt.state[p]["exp_avg_sq"].clone()
+    _save("adamw.npz", **arrays)
+    # schedule table
+    dummy = torch.nn.Parameter(torch.zeros(1))
+    o2 = AdamW([dummy], lr=1e-3, correct_bias=False)
+    train_steps, warm = 57, 57 * 0.1
+    sch = get_linear_schedule_with_warmup(o2, warm, train_steps)
+    lrs = [o2.param_groups[0]["lr"]]
+    for _ in range(60):
+        o2.step()
+        sch.step()
+        lrs.append(o2.param_groups[0]["lr"])
+    with open(os.path.join(GOLD, "sched.json"), "w") as f:
+        json.dump({"base_lr": 1e-3, "train_steps": train_steps, "warmup_steps": warm, "lrs": lrs}, f)
+    print("wrote sched.json")
+
+
+def gen_ndcg():
+    from ndcg import AverageNDCGMeter
+    meter = AverageNDCGMeter()
+    g = torch.Generator().manual_seed(21)
+    arrays = {}
+    n_cases = 0
+    for T in (2, 5, 12, 20, 20, 20):
+        scores = torch.randn(T, generator=g)
+        gold = torch.randint(0, 3, (T,), generator=g)
+        if n_cases == 1:
+            gold = torch.zeros(T, dtype=torch.long)       # ideal DCG == 0 -> NDCG := 1 branch
+        _, idx = torch.sort(scores, dim=-1, descending=True)
+        tr, _ = torch.sort(gold, dim=-1, descending=True)
+        out = meter.return_ndcg_at_k(gold[idx], tr).to(torch.float32)
+        arrays[f"scores_{n_cases}"], arrays[f"gold_{n_cases}"], arrays[f"ndcg_{n_cases}"] = scores, gold, out
+        n_cases += 1
+    arrays["n_cases"] = np.array(n_cases)
+    _save("ndcg.npz", **arrays)
+
+
+def gen_head_fwd():
+    """Full-size Actor / Critic / Reward forwards (eval) on seeded weights + inputs."""
+    import ppo
+    args = _ns(**HEAD_ARGS)
+    arrays = {}
+    bs, tags = 3, 2
+    text, img, tgts = O.seeded_head_inputs(1234, bs, tags)
+    with torch.no_grad():
+        pa = O.seeded_params(O.head_param_spec("actor"), seed=7)
+        actor = _load(ppo.Actor(args, None).eval(), pa)
+        loss, logits = actor(text, img, tgts.float())
+        arrays["actor_loss"], arrays["actor_logits"] = loss, logits
+        del actor, pa
+        pc = O.seeded_params(O.head_param_spec("critic"), seed=8)
+        critic = _load(ppo.Critic(args, None).eval(), pc)
+        state = torch.arange(tags).unsqueeze(0).repeat(bs, 1)
+        arrays["critic_value"] = critic(text, img, tgts, state)
+        flipped = state.flip(dims=[-1])
+        arrays["critic_value_flipped"] = critic(text, img, tgts, flipped)
+        del critic, pc
+        pr = O.seeded_params(O.head_param_spec("reward"), seed=9)
+        reward = _load(ppo.Reward(args, None).eval(), pr)
+        nxt = O.rollout_next_state(logits.view(bs, tags), state)
+        arrays["next_state"] = nxt
+        arrays["reward"] = reward(text, img, tgts, nxt)
+        del reward, pr
+        # eval-style: one item, 5 tags (evaluate(), finetune/ppo.py:629-645)
+        text5, img5, tg5 = O.seeded_head_inputs(4321, 1, 5)
+        pa = O.seeded_params(O.head_param_spec("actor"), seed=7)
+        actor = _load(ppo.Actor(args, None).eval(), pa)
+        _, lg5 = actor(text5, img5, tg5.float())
+        arrays["actor_logits_eval5"] = lg5
+    _save("head_fwd.npz", bs=np.array(bs), tags=np.array(tags), **arrays)
+
+
+def gen_train_step():
+    """Two consecutive train_model calls (cycle 1 runs at lr=0, cycle 2 at lr/warm), dropout off."""
+    import ppo
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    bs, tags = 4, 2
+    args = _ns(**HEAD_ARGS, is_master=False, kl_div_loss_weight=0.001, entropy_weight=0.001, value_clip=0.5,
+               optimizer="adamw", scheduler="linear", learning_rate=1e-3, critic_learning_rate=1e-3,
+               train_steps=41, warmup=0.1, device=torch.device("cpu"))
+    model = ppo.ActorCritic(args, None)
+    _load(model.actor, O.seeded_params(O.head_param_spec("actor"), seed=7))
+    _load(model.critic, O.seeded_params(O.head_param_spec("critic"), seed=8))
+    reward = _load(ppo.Reward(args, None).eval(), O.seeded_params(O.head_param_spec("reward"), seed=9))
+    opt, copt, sch, csch = ppo.build_optimizer(args, model)
+    model.eval()          # dropout off; train_model itself never toggles the mode
+    arrays = {"bs": np.array(bs), "tags": np.array(tags)}
+    sample_names = ["actor.text_proj.fc1.weight", "actor.xit.0.0.0.fn.1.queries.weight", "actor.out_layer.fc1.weight",
+                    "actor.out_layer.fc1.bias", "actor.xit.1.0.weight", "actor.head.weight",
+                    "critic.out_layer.fc1.weight", "critic.xitt.0.0.1.fn.1.0.weight", "critic.pos_emb.weight",
+                    "critic.head.bias", "critic.img_proj.fc2.weight"]
+    named = dict(model.named_parameters())
+    gi = torch.Generator().manual_seed(77)
+    sample_idx = {n: torch.randint(0, named[n].numel(), (64,), generator=gi) for n in sample_names}
+    for n in sample_names:
+        arrays["idx." + n] = sample_idx[n]
+    for cycle in range(2):
+        arrays[f"lr_{cycle}"] = np.array([opt.param_groups[0]["lr"], copt.param_groups[0]["lr"]])
+        memories = []
+        for mb in range(2):
+            text, img, tgts = O.seeded_head_inputs(1000 + 10 * cycle + mb, bs, tags)
+            with torch.no_grad():
+                state = torch.arange(tags).unsqueeze(0).repeat(bs, 1)
+                _, logits = model.actor(text, img, tgts)
+                value = model.critic(text, img, tgts, state)
+                scores = logits.view(bs, tags)
+                nxt = O.rollout_next_state(scores, state)
+                r = reward(text, img, tgts, nxt)
+            arrays[f"c{cycle}_mb{mb}_scores"], arrays[f"c{cycle}_mb{mb}_value"] = scores.clone(), value.clone()
+            arrays[f"c{cycle}_mb{mb}_reward"], arrays[f"c{cycle}_mb{mb}_next_state"] = r.clone(), nxt.clone()
+            memories.append([state.clone(), nxt.clone(), scores.clone(), r.clone(), value.clone(),
+                             text.clone(), img.clone(), tgts.clone()])
+        if cycle == 1:
+            # capture the first-minibatch gradients of cycle 2 by re-running its math with hooks
+            pass
+        out = ppo.train_model(args, model, opt, copt, sch, csch, memories, 1)
+        arrays[f"metrics_{cycle}"] = torch.stack([torch.as_tensor(float(x)) for x in out])
+        for n in sample_names:
+            arrays[f"w{cycle}." + n] = named[n].detach().flatten()[sample_idx[n]].clone()
+            if named[n].grad is not None:
+                arrays[f"g{cycle}." + n] = named[n].grad.detach().flatten()[sample_idx[n]].clone()
+    _save("train_step.npz", **arrays)
+
+
+def gen_encoder_small():
+    from tencentpretrain.encoders import str2encoder
+    arrays = {}
+    for tag, pos in (("post", "post"), ("pre", "pre")):
+        a = _encoder_args("models/xlm-roberta/base_config.json", hidden_size=64, emb_size=64, feedforward_size=128,
+                          heads_num=4, layers_num=2, layernorm_positioning=pos, dropout=0.0)
+        enc = str2encoder["transformer"](a).eval()
+        spec = [(n, tuple(p.shape)) for n, p in enc.named_parameters()]
+        assert spec == O.encoder_param_spec(2, 64, 128, pos == "pre"), tag
+        params = O.seeded_params(spec, seed=31, std=0.3, skip_gamma_beta=False)
+        enc.load_state_dict(params, strict=True)
+        g = torch.Generator().manual_seed(41)
+        emb = torch.randn(3, 9, 64, generator=g)
+        seg = torch.ones(3, 9, dtype=torch.long)
+        seg[1, 6:] = 0
+        seg[2, 3:] = 0
+        with torch.no_grad():
+            out = enc(emb, seg)
+        arrays[f"{tag}_emb"], arrays[f"{tag}_seg"], arrays[f"{tag}_out"] = emb, seg, out
+        for k, v in params.items():
+            arrays[f"{tag}_param.{k}"] = v
+    # TP LayerNorm vs values
+    from tencentpretrain.layers.layer_norm import LayerNorm
+    ln = LayerNorm(48)
+    g = torch.Generator().manual_seed(43)
+    ln.gamma.data = torch.randn(48, generator=g)
+    ln.beta.data = torch.randn(48, generator=g)
+    x = torch.randn(5, 48, generator=g) * 3 + 1
+    arrays["ln_x"], arrays["ln_gamma"], arrays["ln_beta"] = x, ln.gamma.data, ln.beta.data
+    with torch.no_grad():
+        arrays["ln_out"] = ln(x)
+    _save("encoder_small.npz", **arrays)
+
+
+def gen_embeddings_small():
+    from tencentpretrain.embeddings import Embedding, str2embedding
+    arrays = {}
+    a = _encoder_args("models/vit/base-16-224_config.json", emb_size=32, image_height=32, image_width=48, patch_size=8,
+                      max_seq_length=25, dropout=0.0)
+    emb = Embedding(a)
+    for e in a.embedding:
+        emb.update(str2embedding[e](a, 100), e)
+    emb.eval()
+    spec = [(n, tuple(p.shape)) for n, p in emb.named_parameters()]
+    assert spec == O.vit_embedding_spec(32, 3, 8, 25)
+    params = O.seeded_params(spec, seed=51, std=0.5)
+    emb.load_state_dict(params, strict=True)
+    g = torch.Generator().manual_seed(52)
+    img = torch.randn(2, 3, 32, 48, generator=g)
+    seg = torch.ones(2, 25, dtype=torch.long)
+    with torch.no_grad():
+        arrays["vit_out"] = emb(img, seg)
+    arrays["vit_img"] = img
+    for k, v in params.items():
+        arrays["vit_param." + k] = v
+    a = _encoder_args("models/xlm-roberta/base_config.json", emb_size=32, max_seq_length=20, dropout=0.0)
+    emb = Embedding(a)
+    for e in a.embedding:
+        emb.update(str2embedding[e](a, 100), e)
+    emb.eval()
+    spec = [(n, tuple(p.shape)) for n, p in emb.named_parameters()]
+    assert spec == O.text_embedding_spec(32, 100, 20)
+    params = O.seeded_params(spec, seed=53, std=0.5, skip_gamma_beta=False)
+    emb.load_state_dict(params, strict=True)
+    src = torch.randint(0, 100, (3, 11), generator=g)
+    seg = torch.ones(3, 11, dtype=torch.long)
+    seg[1, 7:] = 0
+    seg[2, 5:] = 2
+    with torch.no_grad():
+        arrays["txt_out"] = emb(src, seg)
+    arrays["txt_src"], arrays["txt_seg"] = src, seg
+    for k, v in params.items():
+        arrays["txt_param." + k] = v
+    _save("embeddings_small.npz", **arrays)
+
+
+def gen_encoder_full():
+    """ViT-B/16 and RoBERTa-base stacks from the shipped JSON configs, seeded weights, eval."""
+    from tencentpretrain.embeddings import Embedding, str2embedding
+    from tencentpretrain.encoders import str2encoder
+    from tencentpretrain.utils.misc import pooling
+    arrays = {}
+    a = _encoder_args("models/vit/base-16-224_config.json")
+    emb = Embedding(a)
+    for e in a.embedding:
+        emb.update(str2embedding[e](a, 50265), e)
+    enc = str2encoder["transformer"](a)
+    emb.eval(), enc.eval()
+    pe = O.seeded_params(O.vit_embedding_spec(768, 3, 16, 197), seed=61)
+    pn = O.seeded_params(O.encoder_param_spec(12, 768, 3072, True), seed=62)
+    emb.load_state_dict(pe, strict=True)
+    enc.load_state_dict(pn, strict=True)
+    g = torch.Generator().manual_seed(63)
+    img = torch.randn(2, 3, 224, 224, generator=g)
+    seg = torch.ones(2, 197, dtype=torch.long)
+    with torch.no_grad():
+        e0 = emb(img, seg)
+        h = enc(e0, seg)
+    arrays["vit_emb_head"] = e0[:, :4, :]
+    arrays["vit_hidden_tok0"] = pooling(h, seg, "first")
+    arrays["vit_hidden_head"] = h[:, :6, :]
+    arrays["vit_hidden_absmean"] = h.abs().mean()
+    a = _encoder_args("models/xlm-roberta/base_config.json")
+    emb = Embedding(a)
+    for e in a.embedding:
+        emb.update(str2embedding[e](a, 50265), e)
+    enc = str2encoder["transformer"](a)
+    emb.eval(), enc.eval()
+    pe = O.seeded_params(O.text_embedding_spec(768, 50265, 514), seed=64)
+    pn = O.seeded_params(O.encoder_param_spec(12, 768, 3072, False), seed=65)
+    emb.load_state_dict(pe, strict=True)
+    enc.load_state_dict(pn, strict=True)
+    src = torch.randint(5, 50265, (2, 196), generator=g)
+    seg = torch.ones(2, 196, dtype=torch.long)
+    seg[1, 57:] = 0
+    with torch.no_grad():
+        e0 = emb(src, seg)
+        h = enc(e0, seg)
+    arrays["txt_src"], arrays["txt_seg"] = src, seg
+    arrays["txt_emb_head"] = e0[:, :4, :]
+    arrays["txt_hidden_head"] = h[:, :6, :]
+    arrays["txt_hidden_tail"] = h[:, -3:, :]
+    arrays["txt_hidden_absmean"] = h.abs().mean()
+    _save("encoder_full.npz", **arrays)
+
+
+GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
+            encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
+            head_fwd=gen_head_fwd, train_step=gen_train_step)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    ns = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    for name, fn in GENS.items():
+        if ns.only and name not in ns.only:
+            continue
+        print("==", name)
+        fn()

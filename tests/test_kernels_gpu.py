@@ -1,0 +1,381 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against the CPU oracle / fp64 torch.
+
+Tolerances: split-bf16 (passes=3) GEMMs carry ~17 mantissa bits per operand, so a K-term dot product of
+O(1) terms is off by ~6e-6*sqrt(K) rms -> atol 6e-5*sqrt(K) (10 sigma); everything else is plain fp32
+arithmetic -> 1e-5.  Index / mask work is checked bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lr2ppo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from lr2ppo_amd import ops as _ops
+    return _ops
+
+
+def _rand(gen, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=gen) * scale)
+
+
+def _close(got, ref, atol, rtol, what=""):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = err > bound
+    assert not bad.any(), f"{what}: max err {err.max().item():.3e} (ref scale {ref.abs().max().item():.3e}), {int(bad.sum())} bad"
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,bm,splits", [(200, 256, 192, 128, 1), (50, 128, 2560, 64, 5), (128, 384, 64, 128, 1),
+                                              (333, 128, 768, 128, 3), (64, 256, 1024, 64, 1)])
+def test_gemm_nt_forward(ops, dev, M, N, K, bm, splits):
+    g = torch.Generator().manual_seed(M * 7 + K)
+    a, b = _rand(g, M, K), _rand(g, N, K)
+    ref = a.double() @ b.double().t()
+    out = torch.full((M, N), float("nan"), device=dev)
+    ws = torch.empty(max(1, splits) * M * N, device=dev)
+    ops.gemm(a.to(dev), b.to(dev), out, M, N, K, splits=splits, block_m=bm, splitk_ws=ws, passes=3)
+    _close(out, ref, atol=6e-5 * math.sqrt(K), rtol=5e-5, what="x3")
+    out1 = torch.empty((M, N), device=dev)
+    ops.gemm(a.to(dev), b.to(dev), out1, M, N, K, splits=splits, block_m=bm, splitk_ws=ws, passes=1)
+    ref1 = a.bfloat16().double() @ b.bfloat16().double().t()
+    _close(out1, ref1, atol=1e-4 * math.sqrt(K), rtol=1e-4, what="x1 vs bf16-rounded inputs")
+
+
+@pytest.mark.parametrize("M,N,K,bm", [(130, 256, 192, 128), (64, 1280, 128, 64), (300, 128, 64, 128)])
+def test_gemm_nn_dgrad(ops, dev, M, N, K, bm):
+    """dx[M,N] = dy[M,K] @ W[K,N]  (W is an nn.Linear weight [out=K, in=N])."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a, w = _rand(g, M, K), _rand(g, K, N)
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(a.to(dev), w.to(dev), out, M, N, K, trans_b=True, block_m=bm, splits=1)
+    _close(out, a.double() @ w.double(), atol=6e-5 * math.sqrt(K), rtol=5e-5, what="NN")
+
+
+@pytest.mark.parametrize("M,N,K,bm", [(256, 384, 300, 128), (128, 128, 64, 128), (64, 256, 37, 64), (384, 128, 1000, 128)])
+def test_gemm_tn_wgrad_ragged_contraction(ops, dev, M, N, K, bm):
+    """dW[M,N] = dy[K,M]^T @ x[K,N]; K (token count) is ragged -> zero filled by the buffer range check."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    a, b = _rand(g, K, M), _rand(g, K, N)
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(a.to(dev), b.to(dev), out, M, N, K, trans_a=True, trans_b=True, block_m=bm, splits=1)
+    _close(out, a.double().t() @ b.double(), atol=6e-5 * math.sqrt(K), rtol=5e-5, what="TN")
+
+
+def test_gemm_tn_splitk(ops, dev):
+    g = torch.Generator().manual_seed(5)
+    K, M, N = 1500, 128, 256
+    a, b = _rand(g, K, M), _rand(g, K, N)
+    out = torch.empty((M, N), device=dev)
+    ws = torch.empty(4 * M * N, device=dev)
+    ops.gemm(a.to(dev), b.to(dev), out, M, N, K, trans_a=True, trans_b=True, splits=4, splitk_ws=ws)
+    _close(out, a.double().t() @ b.double(), atol=6e-5 * math.sqrt(K), rtol=5e-5)
+
+
+def test_gemm_epilogues(ops, dev):
+    g = torch.Generator().manual_seed(17)
+    M, N, K = 150, 256, 128
+    a, w, bias, resid = _rand(g, M, K), _rand(g, N, K, scale=0.1), _rand(g, N), _rand(g, M, N)
+    ad, wd, bd, rd = a.to(dev), w.to(dev), bias.to(dev), resid.to(dev)
+    z_ref = a.double() @ w.double().t() + bias.double()
+    # bias + GELU with saved pre-activation
+    out, z = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    ops.gemm(ad, wd, out, M, N, K, bias=bd, act=1, out_z=z)
+    _close(z, z_ref, 6e-5, 5e-5, "z")
+    _close(out, O.gelu_erf(z_ref), 6e-5, 5e-5, "gelu")
+    # bias + dropout + residual   (XiT sites 0/2: x = dropout(linear) + res)
+    drop = ops.Drop(0.1, seed=1234, site=7)
+    ops.gemm(ad, wd, out, M, N, K, bias=bd, drop=drop, resid=rd)
+    keep = torch.from_numpy(O.dropout_keep_mask(1234, 7, M * N, 0.1)).view(M, N)
+    _close(out, z_ref * keep.double() / 0.9 + resid.double(), 6e-5, 5e-5, "dropout+resid")
+    assert 0.85 < keep.float().mean() < 0.95
+    # GELU then dropout (FFN site 1)
+    ops.gemm(ad, wd, out, M, N, K, bias=bd, act=1, drop=drop)
+    _close(out, O.gelu_erf(z_ref) * keep.double() / 0.9, 6e-5, 5e-5, "gelu+dropout")
+    # backward through dropout + GELU: dz = (acc * mask/(1-p)) * gelu'(z)
+    zt = z_ref.clone().requires_grad_(True)
+    O.gelu_erf(zt).sum().backward()
+    ops.gemm(ad, wd, out, M, N, K, act=2, aux_z=z, drop=drop)
+    _close(out, (a.double() @ w.double().t()) * keep.double() / 0.9 * zt.grad, 6e-5, 5e-5, "dgelu")
+    # accumulate + alpha
+    base = _rand(g, M, N)
+    acc = base.to(dev).clone()
+    ops.gemm(ad, wd, acc, M, N, K, accumulate=True, alpha=0.5)
+    _close(acc, base.double() + 0.5 * (a.double() @ w.double().t()), 6e-5, 5e-5, "accumulate")
+
+
+def test_gemm_rejects_bad_shapes(ops, dev):
+    from lr2ppo_amd._native import NativeError
+    a = torch.zeros(8, 100, device=dev)
+    b = torch.zeros(128, 100, device=dev)
+    with pytest.raises(NativeError):
+        ops.gemm(a, b, torch.zeros(8, 128, device=dev), 8, 128, 100)       # K % 64 != 0
+    with pytest.raises(NativeError):
+        ops.gemm(torch.zeros(8, 64, device=dev), torch.zeros(100, 64, device=dev), torch.zeros(8, 100, device=dev), 8, 100, 64)
+
+
+# ------------------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,D", [(37, 768), (9, 64), (130, 1024)])
+def test_layernorm_fwd_both_semantics(ops, dev, rows, D):
+    g = torch.Generator().manual_seed(rows + D)
+    x, gam, bet = _rand(g, rows, D) * 2 + 0.5, _rand(g, D), _rand(g, D)
+    out = torch.empty(rows, D, device=dev)
+    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    ops.layernorm_fwd(x.to(dev), gam.to(dev), bet.to(dev), out, mean, rstd, rows=rows, D=D, eps=1e-5, mode=0)
+    _close(out, O.layernorm_torch(x.double(), gam.double(), bet.double()), 1e-5, 1e-5, "torch LN")
+    _close(mean, x.double().mean(-1), 1e-6, 1e-6)
+    ops.layernorm_fwd(x.to(dev), gam.to(dev), bet.to(dev), out, None, None, rows=rows, D=D, eps=1e-6, mode=1)
+    _close(out, O.layernorm_tp(x.double(), gam.double(), bet.double()), 1e-5, 1e-5, "TP LN")
+
+
+def test_layernorm_fwd_writes_into_concat_layout(ops, dev):
+    g = torch.Generator().manual_seed(3)
+    n, L, D, extra = 3, 5, 64, 2
+    x, gam, bet = _rand(g, n * L, D), _rand(g, D), _rand(g, D)
+    flat = torch.zeros(n, (L + extra) * D, device=dev)
+    ops.layernorm_fwd(x.to(dev), gam.to(dev), bet.to(dev), flat, rows=n * L, D=D, group=L, group_stride=(L + extra) * D)
+    ref = O.layernorm_torch(x, gam, bet).view(n, L * D)
+    _close(flat[:, : L * D], ref, 1e-5, 1e-5)
+    assert torch.all(flat[:, L * D:] == 0)
+
+
+@pytest.mark.parametrize("rows,D,drop_p", [(50, 768, 0.0), (1000, 768, 0.1), (7, 64, 0.0)])
+def test_layernorm_bwd(ops, dev, rows, D, drop_p):
+    g = torch.Generator().manual_seed(rows)
+    x, gam, bet, dy, rg = _rand(g, rows, D), _rand(g, D), _rand(g, D), _rand(g, rows, D), _rand(g, rows, D)
+    xt, gt, bt = x.double().requires_grad_(True), gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    O.layernorm_torch(xt, gt, bt).backward(dy.double())
+    xd = x.to(dev)
+    out = torch.empty(rows, D, device=dev)
+    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    ops.layernorm_fwd(xd, gam.to(dev), bet.to(dev), out, mean, rstd, rows=rows, D=D)
+    dx, dxm = torch.empty(rows, D, device=dev), torch.empty(rows, D, device=dev)
+    dgam, dbet = torch.empty(D, device=dev), torch.empty(D, device=dev)
+    partials = torch.empty(256 * 2 * D, device=dev)
+    drop = ops.Drop(drop_p, 99, 4) if drop_p > 0 else None
+    ops.layernorm_bwd(dy.to(dev), xd, gam.to(dev), mean, rstd, dx, partials, dgam, dbet, rows=rows, D=D,
+                      resid_grad=rg.to(dev), dx_masked=dxm, drop=drop)
+    ref_dx = xt.grad + rg.double()
+    _close(dx, ref_dx, 2e-5, 2e-5, "dx")
+    _close(dgam, gt.grad, 1e-4, 1e-4, "dgamma")
+    _close(dbet, bt.grad, 1e-4, 1e-4, "dbeta")
+    if drop_p > 0:
+        keep = torch.from_numpy(O.dropout_keep_mask(99, 4, rows * D, drop_p)).view(rows, D).double()
+        _close(dxm, ref_dx * keep / (1 - drop_p), 2e-5, 2e-5, "masked dx")
+    else:
+        _close(dxm, ref_dx, 2e-5, 2e-5, "masked dx (p=0)")
+
+
+def test_colsum(ops, dev):
+    g = torch.Generator().manual_seed(8)
+    x = _rand(g, 1234, 3072)
+    out = torch.empty(3072, device=dev)
+    ops.colsum(x.to(dev), out, torch.empty(128 * 3072, device=dev), rows=1234, cols=3072)
+    _close(out, x.double().sum(0), 2e-4, 1e-5)
+
+
+# ------------------------------------------------------------------------------------- attention
+def _xattn_ref(q, k, v, heads, scale):
+    b, n, e = q.shape
+    m = k.shape[1]
+    d = e // heads
+    qh = q.view(b, n, heads, d).permute(0, 2, 1, 3)
+    kh = k.view(b, m, heads, d).permute(0, 2, 1, 3)
+    vh = v.view(b, m, heads, d).permute(0, 2, 1, 3)
+    att = torch.softmax(qh @ kh.transpose(-1, -2), dim=-1) * scale
+    return (att @ vh).permute(0, 2, 1, 3).reshape(b, n, e)
+
+
+@pytest.mark.parametrize("batch,heads,Lq,Lk,hd", [(3, 8, 196, 16, 96), (5, 8, 4, 4, 96), (2, 8, 7, 3, 8), (4, 8, 2, 2, 96)])
+def test_xattn_fwd_bwd(ops, dev, batch, heads, Lq, Lk, hd):
+    g = torch.Generator().manual_seed(batch * Lq)
+    E = heads * hd
+    q, k, v, do = _rand(g, batch, Lq, E, scale=0.5), _rand(g, batch, Lk, E, scale=0.5), _rand(g, batch, Lk, E), _rand(g, batch, Lq, E)
+    scale = 1.0 / math.sqrt(E)
+    qt, kt, vt = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref = _xattn_ref(qt, kt, vt, heads, scale)
+    ref.backward(do.double())
+    qd, kd, vd = q.to(dev).view(-1, E), k.to(dev).view(-1, E), v.to(dev).view(-1, E)
+    o = torch.empty(batch * Lq, E, device=dev)
+    ops.xattn_fwd(qd, kd, vd, o, batch=batch, heads=heads, Lq=Lq, Lk=Lk, head_dim=hd, post_scale=scale)
+    _close(o, ref.view(-1, E), 1e-6, 1e-5, "xattn fwd")
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.xattn_bwd(qd, kd, vd, do.to(dev).view(-1, E), dq, dk, dv, batch=batch, heads=heads, Lq=Lq, Lk=Lk, head_dim=hd,
+                  post_scale=scale)
+    _close(dq, qt.grad.view(-1, E), 1e-6, 1e-4, "dq")
+    _close(dk, kt.grad.view(-1, E), 1e-5, 1e-4, "dk")
+    _close(dv, vt.grad.view(-1, E), 1e-5, 1e-4, "dv")
+
+
+@pytest.mark.parametrize("batch,heads,L", [(3, 12, 197), (2, 4, 9), (2, 12, 196)])
+def test_self_attn_fwd_with_key_mask(ops, dev, batch, heads, L):
+    g = torch.Generator().manual_seed(L)
+    E = heads * 64
+    q, k, v = _rand(g, batch, L, E, scale=0.3), _rand(g, batch, L, E, scale=0.3), _rand(g, batch, L, E)
+    seg = torch.ones(batch, L, dtype=torch.long)
+    seg[1, L // 3:] = 0
+    mask = (1.0 - (seg > 0).double()).view(batch, 1, 1, L) * -10000.0
+    qh, kh, vh = (t.double().view(batch, L, heads, 64).transpose(1, 2) for t in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(-2, -1) / 8.0 + mask, dim=-1)
+    ref = (p @ vh).transpose(1, 2).reshape(batch * L, E)
+    o = torch.empty(batch * L, E, device=dev)
+    ops.self_attn_fwd(q.to(dev).view(-1, E), k.to(dev).view(-1, E), v.to(dev).view(-1, E), seg.to(dev).view(-1), o,
+                      batch=batch, heads=heads, L=L, head_dim=64, scale=1.0 / 8.0)
+    _close(o, ref, 1e-5, 1e-5, "self-attn")
+
+
+# ------------------------------------------------------------------------------------- small ops
+def test_gather_copy_head_period(ops, dev):
+    g = torch.Generator().manual_seed(2)
+    B, T, R = 4, 3, 64
+    src = _rand(g, B, T, R)
+    idx = torch.tensor([[0, 1, 2, 1], [2, 2, 0, 1], [1, 0, 0, 2], [0, 1, 1, 0]])
+    dst = torch.empty(B, 4, R, device=dev)
+    ops.gather_rows(src.to(dev), idx.to(dev), dst, B=B, t_in=T, t_out=4, row_elems=R)
+    assert torch.equal(dst.cpu(), src[torch.arange(B).view(B, 1), idx])
+    # expanded (stride-0) image features: img[b] repeated over tags
+    img = _rand(g, B, R)
+    dst2 = torch.empty(B, 4, R, device=dev)
+    ops.gather_rows(img.to(dev), idx.to(dev), dst2, B=B, t_in=T, t_out=4, row_elems=R, src_bstride=R, src_tstride=0)
+    assert torch.equal(dst2.cpu(), img.unsqueeze(1).expand(B, 4, R))
+    dsrc = torch.empty(B, T, R, device=dev)
+    ops.gather_rows_bwd(dst, idx.to(dev), dsrc, B=B, t_in=T, t_out=4, row_elems=R)
+    ref = torch.zeros(B, T, R)
+    for b in range(B):
+        for j in range(4):
+            ref[b, idx[b, j]] += dst.cpu()[b, j]
+    _close(dsrc, ref, 1e-6, 1e-6)
+    # concat copy
+    rows, D, group = 6, 8, 2
+    x = _rand(g, rows, D)
+    flat = torch.zeros(3, 5 * D, device=dev)
+    ops.copy_rows(x.to(dev), flat, rows=rows, D=D, group=group, dst_gstride=5 * D, dst_off=3 * D)
+    assert torch.equal(flat.cpu()[:, 3 * D:], x.view(3, 2 * D)) and torch.all(flat[:, :3 * D] == 0)
+    # head fwd/bwd with last-position select
+    Bn, Tn, Dn = 5, 4, 768
+    xx, w, b_, dy = _rand(g, Bn * Tn, Dn), _rand(g, 1, Dn), _rand(g, 1), _rand(g, Bn)
+    y = torch.empty(Bn, device=dev)
+    ops.head_fwd(xx.to(dev), w.to(dev), b_.to(dev), y, rows=Bn, D=Dn, row_step=Tn, row_off=Tn - 1)
+    sel = xx.view(Bn, Tn, Dn)[:, -1]
+    _close(y, sel.double() @ w.double().view(-1) + b_.double(), 1e-5, 1e-5)
+    dx, dw, db = torch.empty(Bn * Tn, Dn, device=dev), torch.empty(1, Dn, device=dev), torch.empty(1, device=dev)
+    ops.head_bwd(xx.to(dev), w.to(dev), dy.to(dev), dx, dw, db, rows=Bn, D=Dn, row_step=Tn, row_off=Tn - 1)
+    ref_dx = torch.zeros(Bn, Tn, Dn, dtype=torch.double)
+    ref_dx[:, -1] = dy.double().view(-1, 1) * w.double()
+    _close(dx, ref_dx.view(-1, Dn), 1e-6, 1e-6)
+    _close(dw, (dy.double().view(-1, 1) * sel.double()).sum(0, keepdim=True), 1e-5, 1e-5)
+    _close(db, dy.double().sum().view(1), 1e-6, 1e-6)
+    # pos-emb add + grad
+    table = _rand(g, 4, Dn)
+    out = torch.empty(Bn * Tn, Dn, device=dev)
+    ops.add_period_rows(xx.to(dev), table.to(dev), out, rows=Bn * Tn, D=Dn, period=Tn)
+    _close(out, (xx.view(Bn, Tn, Dn) + table.unsqueeze(0)).view(-1, Dn), 1e-6, 1e-6)
+    dt = torch.zeros(4, Dn, device=dev)
+    ops.period_rows_grad(xx.to(dev), dt, rows=Bn * Tn, D=Dn, period=Tn)
+    _close(dt, xx.view(Bn, Tn, Dn).double().sum(0), 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("B,T,seed", [(32, 2, 1), (24, 2, 2), (7, 2, 3), (16, 4, 4), (1, 2, 5)])
+def test_ppo_loss_and_gradients(ops, dev, B, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    scores = _rand(g, B, T, scale=0.3)
+    old = scores + _rand(g, B, T, scale=0.05)
+    rewards, old_value = _rand(g, B, scale=0.2), _rand(g, B, scale=0.2)
+    value = old_value + _rand(g, B, scale=0.6)        # some |v - old| exceed the clip
+    state = torch.stack([torch.randperm(T, generator=g) for _ in range(B)])
+    nxt = torch.cat([torch.arange(2).unsqueeze(0).repeat(B, 1), state], dim=1)
+    kl_w, ent_w, clip = 0.001, 0.001, 0.5
+    st, vt = scores.clone().requires_grad_(True), value.clone().requires_grad_(True)
+    loss, vloss, ex = O.ppo_update_math(st, vt, old, rewards, old_value, nxt, kl_w, ent_w, clip)
+    loss.backward()
+    vloss.backward()
+    scal, per = torch.empty(4, device=dev), torch.empty(4, B, device=dev)
+    ds, dv = torch.empty(B, T, device=dev), torch.empty(B, device=dev)
+    ops.ppo_loss(scores.to(dev), old.to(dev), rewards.to(dev), old_value.to(dev), value.to(dev), nxt.to(dev), scal, per, ds,
+                 dv, B=B, T=T, kl_w=kl_w, ent_w=ent_w, value_clip=clip)
+    _close(scal[0], loss, 1e-7, 1e-5, "policy loss")
+    _close(scal[1], vloss, 1e-7, 1e-5, "value loss")
+    _close(scal[2], ex["rank_loss"], 1e-7, 1e-5, "rank loss")
+    _close(per[0], ex["kl"], 1e-7, 1e-4, "kl")
+    _close(per[1], ex["entropy"], 1e-6, 1e-5, "entropy")
+    _close(per[2], ex["rewards"], 1e-7, 1e-5, "rewards")
+    _close(per[3], ex["advantages"], 1e-7, 1e-5, "advantages")
+    _close(ds, st.grad, 1e-8, 1e-4, "dscores")
+    _close(dv, vt.grad, 1e-8, 1e-4, "dvalue")
+
+
+def test_smooth_l1(ops, dev):
+    g = torch.Generator().manual_seed(4)
+    pred, tgt = _rand(g, 77), torch.randint(0, 3, (77,), generator=g).float()
+    pt = pred.clone().requires_grad_(True)
+    ref = O.smooth_l1(pt, tgt)
+    ref.backward()
+    loss, dp = torch.empty(1, device=dev), torch.empty(77, device=dev)
+    ops.smooth_l1(pred.to(dev), tgt.to(dev), loss, dp, n=77)
+    _close(loss, ref.view(1), 1e-6, 1e-6)
+    _close(dp, pt.grad, 1e-8, 1e-5)
+
+
+def test_adamw_multi_matches_reference_order(ops, dev):
+    import ctypes as C
+    from lr2ppo_amd import _native as nat
+    g = torch.Generator().manual_seed(6)
+    sizes, wds = [1000, 7, 262147], [0.01, 0.0, 0.01]
+    ps = [_rand(g, n) for n in sizes]
+    ms, vs = [torch.zeros(n) for n in sizes], [torch.zeros(n) for n in sizes]
+    pd, md, vd = [p.to(dev) for p in ps], [m.to(dev) for m in ms], [v.to(dev) for v in vs]
+    for step in range(3):
+        gs = [_rand(g, n, scale=10.0 ** (-2 * step)) for n in sizes]
+        gd = [x.to(dev) for x in gs]
+        chunks = []
+        for p, gr, m, v, wd in zip(pd, gd, md, vd, wds):
+            n, off = p.numel(), 0
+            while off < n:
+                c = min(65536, n - off)
+                chunks.append((p.data_ptr() + 4 * off, gr.data_ptr() + 4 * off, m.data_ptr() + 4 * off, v.data_ptr() + 4 * off, c, wd))
+                off += c
+        arr = (nat.AdamChunk * len(chunks))()
+        for i, (a, b, c_, d, cnt, wd) in enumerate(chunks):
+            arr[i].p, arr[i].g, arr[i].m, arr[i].v, arr[i].count, arr[i].weight_decay = a, b, c_, d, cnt, wd
+        table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        ops.adamw_multi(table, len(chunks), 1e-2, 0.9, 0.999, 1e-6)
+        torch.cuda.synchronize()
+        for i in range(3):
+            ps[i], ms[i], vs[i] = O.adamw_step(ps[i], gs[i], ms[i], vs[i], 1e-2, wds[i])
+            _close(pd[i], ps[i], 1e-6, 1e-5, f"p step {step}")
+            _close(md[i], ms[i], 1e-8, 1e-5, "m")
+            _close(vd[i], vs[i], 1e-10, 1e-5, "v")
+
+
+def test_embedding_frontends(ops, dev, golden):
+    gd = golden("embeddings_small.npz")
+    P = {k[len("vit_param."):]: v for k, v in gd.items() if k.startswith("vit_param.")}
+    img = gd["vit_img"]
+    B, Cc, H, W, ps, D = 2, 3, 32, 48, 8, 32
+    Pn = (H // ps) * (W // ps)
+    patches = torch.empty(B * Pn, Cc * ps * ps, device=dev)
+    ops.patchify(img.to(dev), patches, B=B, Cc=Cc, H=H, W=W, ps=ps)
+    ref_p = img.view(B, Cc, H // ps, ps, W // ps, ps).permute(0, 2, 4, 1, 3, 5).reshape(B * Pn, -1)
+    assert torch.equal(patches.cpu(), ref_p)
+    proj = (ref_p @ P["patch.projection.weight"].view(D, -1).t()).to(dev)
+    out = torch.empty(B, Pn + 1, D, device=dev)
+    ops.vit_assemble(proj, P["patch.cls_emb"].to(dev).view(-1), P["pos.embedding.weight"].to(dev), out, B=B, P=Pn, D=D)
+    _close(out, gd["vit_out"], 1e-5, 1e-5, "vit embedding")
+    Pt = {k[len("txt_param."):]: v for k, v in gd.items() if k.startswith("txt_param.")}
+    src, seg = gd["txt_src"], gd["txt_seg"]
+    rows, L = src.numel(), src.shape[1]
+    e = torch.empty(rows, D, device=dev)
+    ops.text_embed(src.to(dev).view(-1), seg.to(dev).view(-1), Pt["word.embedding.weight"].to(dev),
+                   Pt["pos.embedding.weight"].to(dev), Pt["seg.embedding.weight"].to(dev), e, rows=rows, L=L, D=D)
+    o2 = torch.empty(rows, D, device=dev)
+    ops.layernorm_fwd(e, Pt["layer_norm.gamma"].to(dev), Pt["layer_norm.beta"].to(dev), o2, rows=rows, D=D, eps=1e-6, mode=1)
+    _close(o2.view(3, L, D), gd["txt_out"], 1e-5, 1e-5, "text embedding")

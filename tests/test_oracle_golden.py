@@ -1,0 +1,177 @@
+"""Pin the CPU oracle to fixtures produced by importing the reference (oracle/gen_golden.py).
+
+CPU-only; these are the `-m "not gpu"` checks that make the oracle trustworthy as the checker for
+the HIP path.  Tolerances are fp32 round-off of re-ordered but algebraically identical ops.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, load_golden
+from oracle import lr2ppo_oracle as O
+
+
+def _params(g, prefix):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+def test_key_specs_match_reference():
+    with open(os.path.join(GOLD, "keys.json")) as f:
+        keys = json.load(f)
+    for kind in ("actor", "critic", "reward"):
+        assert [(n, tuple(s)) for n, s in keys[kind]] == O.head_param_spec(kind)
+    assert [(n, tuple(s)) for n, s in keys["vit_encoder"]] == O.encoder_param_spec(12, 768, 3072, True)
+    assert [(n, tuple(s)) for n, s in keys["roberta_encoder"]] == O.encoder_param_spec(12, 768, 3072, False)
+    assert [(n, tuple(s)) for n, s in keys["vit_embedding"]] == O.vit_embedding_spec(768, 3, 16, 197)
+    assert [(n, tuple(s)) for n, s in keys["roberta_embedding"]] == O.text_embedding_spec(768, 50265, 514)
+    n_actor = sum(int(np.prod(s)) for _, s in keys["actor"])
+    n_critic = sum(int(np.prod(s)) for _, s in keys["critic"])
+    assert (n_actor, n_critic) == (519070465, 526164481)
+
+
+def test_xit_small_forward_and_grads():
+    g = load_golden("xit_small.npz")
+    P = {"xit." + k: v for k, v in _params(g, "param.").items()}
+    out = O.xit(P, "xit", g["x"], g["y"])
+    assert torch.allclose(out, g["out"], atol=2e-5, rtol=1e-5)
+    out_self = O.xit(P, "xit", g["xs"], g["xs"])
+    assert torch.allclose(out_self, g["out_self"], atol=2e-5, rtol=1e-5)
+    assert int(g["causal_equals_full"]) == 1                           # quirk 2: causal mask is a no-op
+    # gradients
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    x = g["x"].clone().requires_grad_(True)
+    y = g["y"].clone().requires_grad_(True)
+    (O.xit(Pg, "xit", x, y) * g["w"]).sum().backward()
+    assert torch.allclose(x.grad, g["dx"], atol=1e-4, rtol=1e-4)
+    assert torch.allclose(y.grad, g["dy"], atol=1e-4, rtol=1e-4)
+    for k, v in Pg.items():
+        ref = g["grad." + k[len("xit."):]]
+        assert torch.allclose(v.grad, ref, atol=2e-4, rtol=1e-4), k
+
+
+def test_losses():
+    g = load_golden("losses.npz")
+    assert abs(float(O.rank_loss(g["hand_scores"], g["hand_order"])) - 0.31) < 1e-6
+    for tag, margin in (("hand", 0.01), ("zero", 0.01), ("rand", 0.01), ("rand5", 1.0)):
+        got = O.rank_loss(g[tag + "_scores"], g[tag + "_order"], margin)
+        assert torch.allclose(got, g[tag + "_rank"], atol=1e-7), tag
+    assert float(g["zero_rank"]) == 0.0
+    for clip, key in ((0.5, "vloss_05"), (0.2, "vloss_02")):
+        assert torch.allclose(O.clipped_value_loss(g["v"], g["r"], g["ov"], clip), g[key], atol=1e-7)
+    assert torch.allclose(O.masked_normalize(g["norm_in"]), g["norm_out"], atol=1e-6)
+
+
+def test_adamw_matches_reference_update_order():
+    g = load_golden("adamw.npz")
+    wds = [0.01, 0.0, 0.01]
+    for i in range(3):
+        p = g[f"p0_{i}"]
+        m = torch.zeros_like(p)
+        v = torch.zeros_like(p)
+        for step in range(3):
+            p, m, v = O.adamw_step(p, g[f"g{step}_{i}"], m, v, lr=1e-2, wd=wds[i])
+            assert torch.allclose(p, g[f"p{step + 1}_{i}"], atol=1e-7, rtol=1e-6)
+            assert torch.allclose(m, g[f"m{step + 1}_{i}"], atol=1e-8, rtol=1e-6)
+            assert torch.allclose(v, g[f"v{step + 1}_{i}"], atol=1e-10, rtol=1e-6)
+
+
+def test_linear_schedule_table():
+    with open(os.path.join(GOLD, "sched.json")) as f:
+        s = json.load(f)
+    for step, lr in enumerate(s["lrs"]):
+        got = s["base_lr"] * O.linear_schedule_lambda(step, s["warmup_steps"], s["train_steps"])
+        assert abs(got - lr) < 1e-12, step
+    assert s["lrs"][0] == 0.0                                          # quirk 15: first cycle runs at lr 0
+
+
+def test_ndcg_cases():
+    g = load_golden("ndcg.npz")
+    for i in range(int(g["n_cases"])):
+        got = O.ndcg_vector(g[f"scores_{i}"], g[f"gold_{i}"])
+        assert torch.allclose(got, g[f"ndcg_{i}"], atol=1e-6), i
+    assert torch.all(g["ndcg_1"] == 1.0)                               # all-zero gold -> 1
+
+
+def test_encoder_small_both_ln_placements():
+    g = load_golden("encoder_small.npz")
+    for tag in ("post", "pre"):
+        P = _params(g, f"{tag}_param.")
+        out = O.transformer_encoder(P, g[f"{tag}_emb"], g[f"{tag}_seg"], layers=2, heads=4, pre_ln=(tag == "pre"))
+        assert torch.allclose(out, g[f"{tag}_out"], atol=5e-5, rtol=1e-4), tag
+    assert torch.allclose(O.layernorm_tp(g["ln_x"], g["ln_gamma"], g["ln_beta"]), g["ln_out"], atol=1e-6)
+    # the TP LayerNorm really differs from nn.LayerNorm (quirk 3)
+    diff = (O.layernorm_torch(g["ln_x"], g["ln_gamma"], g["ln_beta"]) - g["ln_out"]).abs().max()
+    assert diff > 1e-3
+
+
+def test_embeddings_small():
+    g = load_golden("embeddings_small.npz")
+    out = O.vit_embedding(_params(g, "vit_param."), g["vit_img"], patch=8)
+    assert torch.allclose(out, g["vit_out"], atol=2e-5, rtol=1e-5)
+    out = O.text_embedding(_params(g, "txt_param."), g["txt_src"], g["txt_seg"])
+    assert torch.allclose(out, g["txt_out"], atol=2e-5, rtol=1e-5)
+
+
+def test_dropout_mask_statistics_and_determinism():
+    k1 = O.dropout_keep_mask(seed=5, site=2, numel=200000, p=0.1)
+    k2 = O.dropout_keep_mask(seed=5, site=2, numel=200000, p=0.1)
+    k3 = O.dropout_keep_mask(seed=6, site=2, numel=200000, p=0.1)
+    assert np.array_equal(k1, k2) and not np.array_equal(k1, k3)
+    assert abs(k1.mean() - 0.9) < 5e-3
+
+
+@pytest.mark.slow
+def test_encoder_full_vit_and_roberta():
+    g = load_golden("encoder_full.npz")
+    with torch.no_grad():
+        pe = O.seeded_params(O.vit_embedding_spec(768, 3, 16, 197), seed=61)
+        pn = O.seeded_params(O.encoder_param_spec(12, 768, 3072, True), seed=62)
+        gen = torch.Generator().manual_seed(63)
+        img = torch.randn(2, 3, 224, 224, generator=gen)
+        seg = torch.ones(2, 197, dtype=torch.long)
+        e0 = O.vit_embedding(pe, img, 16)
+        h = O.transformer_encoder(pn, e0, seg, 12, 12, True)
+        assert torch.allclose(e0[:, :4], g["vit_emb_head"], atol=1e-4, rtol=1e-4)
+        assert torch.allclose(h[:, :6], g["vit_hidden_head"], atol=2e-4, rtol=1e-3)
+        assert torch.allclose(O.pooling_first(h, seg), g["vit_hidden_tok0"], atol=2e-4, rtol=1e-3)
+        pe = O.seeded_params(O.text_embedding_spec(768, 50265, 514), seed=64)
+        pn = O.seeded_params(O.encoder_param_spec(12, 768, 3072, False), seed=65)
+        src, seg = g["txt_src"], g["txt_seg"]
+        src2 = torch.randint(5, 50265, (2, 196), generator=gen)
+        assert torch.equal(src, src2)                                # input stream reproducible from the seed
+        e0 = O.text_embedding(pe, src, seg)
+        h = O.transformer_encoder(pn, e0, seg, 12, 12, False)
+        assert torch.allclose(e0[:, :4], g["txt_emb_head"], atol=1e-4, rtol=1e-4)
+        assert torch.allclose(h[:, :6], g["txt_hidden_head"], atol=2e-4, rtol=1e-3)
+        assert torch.allclose(h[:, -3:], g["txt_hidden_tail"], atol=2e-4, rtol=1e-3)
+
+
+@pytest.mark.slow
+def test_head_forward_full_size():
+    g = load_golden("head_fwd.npz")
+    bs, tags = int(g["bs"]), int(g["tags"])
+    text, img, tgts = O.seeded_head_inputs(1234, bs, tags)
+    state = torch.arange(tags).unsqueeze(0).repeat(bs, 1)
+    with torch.no_grad():
+        pa = O.seeded_params(O.head_param_spec("actor"), seed=7)
+        loss, logits = O.actor_forward(pa, text, img, tgts)
+        assert torch.allclose(logits, g["actor_logits"], atol=2e-5, rtol=1e-4)
+        assert torch.allclose(loss, g["actor_loss"], atol=1e-5)
+        text5, img5, tg5 = O.seeded_head_inputs(4321, 1, 5)
+        _, lg5 = O.actor_forward(pa, text5, img5, tg5)
+        assert torch.allclose(lg5, g["actor_logits_eval5"], atol=2e-5, rtol=1e-4)
+        del pa
+        pc = O.seeded_params(O.head_param_spec("critic"), seed=8)
+        v = O.critic_forward(pc, text, img, state)
+        assert torch.allclose(v, g["critic_value"], atol=2e-5, rtol=1e-4)
+        vf = O.critic_forward(pc, text, img, state.flip(dims=[-1]))
+        assert torch.allclose(vf, g["critic_value_flipped"], atol=2e-5, rtol=1e-4)
+        del pc
+        nxt = O.rollout_next_state(logits.view(bs, tags), state)
+        assert torch.equal(nxt, g["next_state"])
+        pr = O.seeded_params(O.head_param_spec("reward"), seed=9)
+        r = O.reward_forward(pr, text, img, nxt)
+        assert torch.allclose(r, g["reward"], atol=2e-5, rtol=1e-4)
