@@ -55,7 +55,8 @@ typedef struct lr2_epilogue {
  *   trans_a=0: A is [M][K] (lda>=K);  trans_a=1: A is [K][M] (lda>=M)
  *   trans_b=0: B is [N][K] (nn.Linear weight);  trans_b=1: B is [K][N]
  * Supported forms: (0,0) forward, (0,1) input gradient, (1,1) weight gradient.
- * Constraints: N%128==0; K%64==0 unless both operands are strided (1,1); lda,ldb %4==0; buffers < 4 GiB.
+ * Constraints: K%64==0 unless both operands are strided (1,1); lda,ldb %4==0 (16-byte rows); buffers < 4 GiB.
+ * M, N and (in the (1,1) form) K may be ragged.
  * a_bytes/b_bytes: bytes addressable from A/B (rows past the end read as zero: ragged M, ragged K in (1,1)).
  * splits>1 uses split-K through splitk_ws (fp32 [splits][M][N]).  block_m: 128 or 64.
  * replaces: nn.Linear / F.linear + bias + nn.GELU + nn.Dropout + residual add in

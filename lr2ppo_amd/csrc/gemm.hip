@@ -155,7 +155,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams g) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tiles_n = g.N / BN;
+  const int tiles_n = (g.N + BN - 1) / BN;
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
 
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = m0 + wm0 + 16 * i + 4 * gq + r, n = n0 + wn0 + 16 * j + c16;
-          if (m < g.M) part[(size_t)m * g.N + n] = acc[i][j][r];
+          if (m < g.M && n < g.N) part[(size_t)m * g.N + n] = acc[i][j][r];
         }
   } else {
 #pragma unroll
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = m0 + wm0 + 16 * i + 4 * gq + r, n = n0 + wn0 + 16 * j + c16;
-          if (m < g.M) epilogue_apply(g.epi, acc[i][j][r], m, n, g.N);
+          if (m < g.M && n < g.N) epilogue_apply(g.epi, acc[i][j][r], m, n, g.N);
         }
   }
 }
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 template <int BM, int BN, int WM, int WN, bool TA, bool TB, int PASSES>
 int launch(const GemmParams& p, int splits, hipStream_t stream) {
-  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   dim3 grid(tiles, 1, splits);
   const size_t lds = (size_t)(PASSES == 3 ? 2 : 1) * (BM * BK * 2 + BN * BK * 2);
   auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, PASSES>;
@@ -317,9 +317,9 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   if (!A || !B || M <= 0 || N <= 0 || K <= 0 || !epi || !epi->out) return LR2_ERR_ARG;
   if (passes != 1 && passes != 3) return LR2_ERR_ARG;
   if (block_m != 64) block_m = 128;
-  if (N % 128 != 0) return LR2_ERR_SHAPE;                // whole N tiles only
-  if ((!trans_a || !trans_b) && (K % BK != 0)) return LR2_ERR_SHAPE;   // K-contiguous operands: whole K tiles
-  if (trans_a && (M % block_m != 0)) return LR2_ERR_SHAPE;             // strided A: whole M tiles
+  // K-contiguous operands need whole K tiles (a ragged K would read into the next row, not zeros); ragged M / N
+  // are handled by the zero-filling range check on loads plus masked stores.
+  if ((!trans_a || !trans_b) && (K % BK != 0)) return LR2_ERR_SHAPE;
   if ((lda % 4) || (ldb % 4)) return LR2_ERR_SHAPE;      // 16-byte aligned rows
   if (a_bytes >= (1ull << 32) || b_bytes >= (1ull << 32)) return LR2_ERR_SHAPE;
   if (splits < 1) splits = 1;

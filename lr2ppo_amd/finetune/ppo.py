@@ -1,0 +1,782 @@
+"""LR2PPO stage 3 on MI355X -- drop-in for the reference's finetune/ppo.py.
+
+Same public surface (names, argument meaning, state_dict keys, CLI flags, returned metric order):
+`RankLoss, Mlp, ActorCritic, Actor, Critic, Reward, build_optimizer, clipped_value_loss, train_model,
+evaluate, get_dataloader, main`.  What differs is underneath: the model forwards, their backward, the PPO
+loss and the AdamW step run on the hand-written gfx950 kernels of lr2ppo_amd/csrc through
+lr2ppo_amd.engine (explicit schedule, persistent workspace, no autograd graph on the training path).
+There is no CPU fallback: without the native library every forward raises.
+
+Reference behaviours reproduced on purpose (SURVEY.md 8a "quirks"): one-step advantage A = (r - w_kl KL) - V_old
+with r' NOT detached in the policy loss; target order flipped when A < -0.1; batch-level RankLoss scalar;
+`--eps_clip` parsed and unused; schedulers stepped once per train_model call (first cycle at lr 0);
+Reward hard-codes 4 positions; Critic/Reward read the LAST position; decay exemption by substring
+bias|gamma|beta (so LayerNorm weights and pos_emb are decayed).
+Deliberate deviations: (1) gradients are averaged across ranks before each optimizer step (the reference
+trains independent replicas); (2) NaN loss raises FloatingPointError on every rank instead
+of dropping rank 0 into pdb; (3) trunk work that is provably identical is not repeated (shared image tokens,
+duplicate tags in the reward model's index) -- results are bit-identical.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import random
+import sys
+import time as _time
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch.utils.data import DataLoader, Dataset
+from torch.utils.data.distributed import DistributedSampler
+
+from .. import engine, ops, runtime
+from ..ndcg import AverageNDCGMeter
+from ..tencentpretrain.model_saver import save_model
+from ..tencentpretrain.opts import adv_opts, finetune_opts, tokenizer_opts
+from ..tencentpretrain.utils.config import load_hyperparam
+from ..tencentpretrain.utils.logging import init_logger
+from ..tencentpretrain.utils.optimizers import str2optimizer, str2scheduler
+from . import misc
+from .xit import XiT
+
+FEAT = 768        # reference hard-codes 768 / 196 (finetune/ppo.py:202-208,219-220)
+SEQ_LEN = engine.SEQ_LEN
+
+
+# ---------------------------------------------------------------------------------------------
+# small host-side helpers of the reference's API (finetune/ppo.py:38-55, 422-498)
+# ---------------------------------------------------------------------------------------------
+class RankLoss(nn.Module):
+    """Pairwise hinge over a target order; mean over the POSITIVE entries of the whole batch.
+    Stand-alone module for API parity; train_model uses the fused lr2_ppo_loss kernel instead."""
+
+    def __init__(self, margin=1):
+        super().__init__()
+        self.margin = margin
+
+    def forward(self, scores, indices):
+        s = torch.gather(scores, 1, indices)
+        hinge = torch.relu(torch.triu(self.margin - (s.unsqueeze(2) - s.unsqueeze(1)), diagonal=1))
+        total, cnt = hinge.sum(), torch.sign(hinge).sum()
+        return total if cnt == 0 else total / cnt
+
+
+def log(t, eps=1e-20):
+    return torch.log(t.clamp(min=eps))
+
+
+def log_prob(prob):
+    return log(prob.max(dim=-1).values)
+
+
+def masked_entropy(prob, dim=-1, mask=None):
+    return (prob * log(prob)).sum(dim=-1)
+
+
+def exists(val):
+    return val is not None
+
+
+def default(val, d):
+    return val if exists(val) else (d() if callable(d) else d)
+
+
+def masked_mean(seq, mask=None, dim=1, keepdim=False):
+    if mask is None:
+        return seq.mean(dim=dim)
+    if seq.ndim == 3:
+        mask = mask.unsqueeze(-1)
+    numer = seq.masked_fill(~mask, 0.0).sum(dim=dim, keepdim=keepdim)
+    denom = mask.sum(dim=dim, keepdim=keepdim)
+    return (numer / denom.clamp(min=1e-3)).masked_fill(denom == 0, 0.0)
+
+
+def masked_kl_div(prob1, prob2, mask=None, reduce_batch=False):
+    kl = (prob1 * (log(prob1) - log(prob2))).sum(dim=-1)
+    return kl.mean() if reduce_batch else kl
+
+
+def masked_normalize(t, eps=1e-5, mask=None, dim=None):
+    centred = t - t.mean()
+    return centred * (centred ** 2).mean().clamp(min=eps).rsqrt()
+
+
+def clipped_value_loss(values, rewards, old_values, clip):
+    clipped = old_values + (values - old_values).clamp(-clip, clip)
+    return torch.mean(torch.max((clipped.flatten() - rewards) ** 2, (values.flatten() - rewards) ** 2))
+
+
+def get_inds(indices, tgts, cls):
+    return [i for i, t in zip(indices, tgts) if t == cls]
+
+
+def freeze_layer(layer):
+    for p in layer.parameters():
+        p.requires_grad = False
+
+
+# ---------------------------------------------------------------------------------------------
+# models
+# ---------------------------------------------------------------------------------------------
+class Mlp(nn.Module):
+    """fc1 -> GELU(erf) -> fc2 parameter holder (finetune/ppo.py:154-170; drop is 0 everywhere upstream).
+    Stand-alone calls run two fused GEMMs; inside the heads the engine schedules them."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        if drop:
+            raise NotImplementedError("Mlp dropout is 0 in every reference configuration")
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    @torch.no_grad()
+    def forward(self, x):
+        K, F, Nout = self.fc1.in_features, self.fc1.out_features, self.fc2.out_features
+        x2 = x.contiguous().view(-1, K)
+        M = x2.shape[0]
+        ws = engine.Workspace(x.device)
+        h = torch.empty(M, F, device=x.device)
+        out = torch.empty(M, Nout, device=x.device)
+        engine.linear_fwd(ws, x2, self.fc1.weight.data, self.fc1.bias.data, h, M, F, K, act=1)
+        engine.linear_fwd(ws, h, self.fc2.weight.data, self.fc2.bias.data, out, M, Nout, F)
+        return out.view(*x.shape[:-1], Nout)
+
+
+class _Head(nn.Module):
+    """Shared machinery of Actor / Critic / Reward: parameters, flat gradient buffer, workspace, engine calls."""
+    has_tail = False
+    fixed_positions: Optional[int] = None
+
+    def __init__(self, args, vit_args=None):
+        super().__init__()
+        self.mode = args.mode
+        self.labels_num = args.labels_num
+        if self.mode != "reg":
+            raise NotImplementedError("the HIP path implements mode='reg' (the mode of every LR2PPO launcher, ppo.sh:25)")
+        if args.visual_feat_dim != FEAT:
+            raise ValueError("visual_feat_dim must be 768 (hard-coded in the reference, finetune/ppo.py:202-208)")
+        self.seq_length, self.max_imgs = args.seq_length, args.max_imgs
+        if self.seq_length != SEQ_LEN:
+            raise ValueError("seq_length must be 196 (hard-coded in the reference, finetune/ppo.py:219-220)")
+        self.text_proj = Mlp(FEAT, FEAT * 4, FEAT, nn.GELU, 0)
+        self.img_proj = Mlp(FEAT, FEAT * 4, FEAT, nn.GELU, 0)
+        if self.has_tail:
+            self.pos_emb = nn.Embedding(4, FEAT)
+        self.xit = XiT(feat_size=FEAT)
+        if self.has_tail:
+            self.xitt = XiT(feat_size=FEAT, attention_mask="causal")
+        self.out_layer = Mlp((args.seq_length + args.max_imgs) * args.visual_feat_dim, FEAT * 4, FEAT, nn.GELU, 0)
+        self.head = nn.Linear(FEAT, 1)
+        self._ws: Optional[engine.Workspace] = None
+        self._G: Optional[Dict[str, torch.Tensor]] = None
+        self._flat_grad: Optional[torch.Tensor] = None
+        self._saved = None
+
+    # ---- plumbing ----
+    def _workspace(self, device) -> engine.Workspace:
+        if self._ws is None or self._ws.device != device:
+            self._ws = engine.Workspace(device)
+        return self._ws
+
+    def _P(self) -> Dict[str, torch.Tensor]:
+        return {n: p.data for n, p in self.named_parameters()}
+
+    GRAD_ORDER_FIRST = ("out_layer.fc2.weight", "out_layer.fc2.bias", "out_layer.fc1.weight", "out_layer.fc1.bias")
+
+    def grad_buffers(self) -> Dict[str, torch.Tensor]:
+        """Persistent gradient storage: one flat fp32 buffer, out_layer (96 % of the bytes, produced first in
+        backward) at the front so its all-reduce can start while the rest of backward runs."""
+        dev = next(self.parameters()).device
+        if self._G is not None and self._flat_grad.device == dev:
+            return self._G
+        named = dict(self.named_parameters())
+        order = [n for n in self.GRAD_ORDER_FIRST if n in named] + [n for n in named if n not in self.GRAD_ORDER_FIRST]
+        total = sum((named[n].numel() + 3) // 4 * 4 for n in order)
+        self._flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._G, off = {}, 0
+        self._bucket_split = 0
+        for n in order:
+            k = named[n].numel()
+            self._G[n] = self._flat_grad[off:off + k].view_as(named[n])
+            off += (k + 3) // 4 * 4
+            if n == self.GRAD_ORDER_FIRST[-1]:
+                self._bucket_split = off
+        return self._G
+
+    def bind_grads(self):
+        """Point every parameter's .grad at its slice of the flat buffer (no copies, no per-step allocation)."""
+        G = self.grad_buffers()
+        for n, p in self.named_parameters():
+            if p.grad is None or p.grad.data_ptr() != G[n].data_ptr():
+                p.grad = G[n]
+
+    def _prep_inputs(self, text_emb, img_emb):
+        if text_emb.dtype != torch.float32 or not text_emb.is_cuda:
+            raise TypeError("lr2ppo_amd: text_emb must be a float32 tensor on the HIP device (no CPU path)")
+        bs, tags = text_emb.shape[:2]
+        if text_emb.shape[2] != SEQ_LEN or text_emb.shape[3] != FEAT:
+            raise ValueError(f"text_emb must be [bs, tags, {SEQ_LEN}, {FEAT}]")
+        shared = engine._img_shared(img_emb)
+        n_img = img_emb.shape[-2]
+        if n_img != self.max_imgs:
+            raise ValueError(f"img_emb carries {n_img} image tokens, model was built for max_imgs={self.max_imgs}")
+        if shared:
+            img2 = (img_emb if img_emb.dim() == 3 else img_emb[:, 0]).contiguous().view(bs * n_img, FEAT)
+        else:
+            img2 = img_emb.contiguous().view(bs * tags * n_img, FEAT)
+        return text_emb.contiguous().view(bs * tags * SEQ_LEN, FEAT), img2, bs, tags, n_img, shared
+
+    def _drop_cfg(self, site_base=0):
+        return runtime.next_drop(engine.DROP_P, site_base) if self.training else None
+
+
+class Actor(_Head):
+    """finetune/ppo.py:196-244 (mode 'reg'): forward(text_emb, img_emb, tgts) -> (SmoothL1 loss, logits[bs*tags])
+    or logits when tgts is None."""
+
+    def forward(self, text_emb, img_emb, tgts=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            logits = _ActorFn.apply(self, text_emb, img_emb, *list(self.parameters()))
+        else:
+            logits = self.engine_forward(text_emb, img_emb, save=False)
+        if tgts is None:
+            return logits
+        return _SmoothL1Fn.apply(logits, tgts.reshape(-1).to(torch.float32).contiguous()), logits
+
+    def engine_forward(self, text_emb, img_emb, *, save: bool) -> torch.Tensor:
+        text2, img2, bs, tags, n_img, shared = self._prep_inputs(text_emb, img_emb)
+        ws, P = self._workspace(text_emb.device), self._P()
+        drop = self._drop_cfg(0)
+        g2 = engine.trunk_forward(ws, P, text2, img2, bs, tags, n_img, FEAT, save=save, drop=drop, img_shared=shared)
+        logits = torch.empty(bs * tags, device=text_emb.device)
+        ops.head_fwd(g2, P["head.weight"], P["head.bias"], logits, rows=bs * tags, D=FEAT)
+        if save:
+            self._saved = (text2, img2, bs, tags, n_img, shared, drop)
+        return logits
+
+    def engine_backward(self, dlogits: torch.Tensor):
+        """Gradients of sum(dlogits * logits) into the flat gradient buffer (call after engine_forward(save=True))."""
+        text2, img2, bs, tags, n_img, shared, drop = self._saved
+        ws, P, G = self._workspace(text2.device), self._P(), self.grad_buffers()
+        N = bs * tags
+        g2 = ws.mat("g2", N, FEAT)
+        dg2 = ws.mat("dg2", N, FEAT)
+        ops.head_bwd(g2, P["head.weight"], dlogits.contiguous().view(-1), dg2, G["head.weight"], G["head.bias"], rows=N, D=FEAT)
+        engine.trunk_backward(ws, P, G, text2, img2, dg2, bs, tags, n_img, FEAT, drop=drop, img_shared=shared)
+        self._saved = None
+
+
+class _TailHead(_Head):
+    has_tail = True
+
+    def forward(self, text_emb, img_emb, tgts, index):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _CriticFn.apply(self, text_emb, img_emb, index, *list(self.parameters()))
+        return self.engine_forward(text_emb, img_emb, index, save=False)
+
+    def _n_pos(self, t_out: int) -> int:
+        if self.fixed_positions is not None:
+            if t_out != self.fixed_positions:
+                raise ValueError(f"Reward adds pos_emb(arange(4)) (finetune/ppo.py:339): index must have 4 columns, got {t_out}")
+            return self.fixed_positions
+        if t_out > 4:
+            raise IndexError("pos_emb has 4 rows (finetune/ppo.py:256): at most 4 positions")
+        return t_out
+
+    def engine_forward(self, text_emb, img_emb, index, *, save: bool) -> torch.Tensor:
+        dev = text_emb.device
+        bs, tags_in = text_emb.shape[:2]
+        index = index.to(device=dev, dtype=torch.int64).contiguous()
+        t_out = index.shape[1]
+        self._n_pos(t_out)
+        ws, P = self._workspace(dev), self._P()
+        n_img = img_emb.shape[-2]
+        if save:
+            # train mode: gather the inputs by index exactly like the reference (ppo.py:267-271), then run the trunk
+            shared_in = engine._img_shared(img_emb)
+            text_g = ws.mat("text_g", bs * t_out * SEQ_LEN, FEAT)
+            ops.gather_rows(text_emb.contiguous(), index, text_g, B=bs, t_in=tags_in, t_out=t_out, row_elems=SEQ_LEN * FEAT)
+            img_src = (img_emb if img_emb.dim() == 3 else img_emb[:, 0]).contiguous() if shared_in else img_emb.contiguous()
+            img_g = ws.mat("img_g", bs * t_out * n_img, FEAT)
+            ops.gather_rows(img_src, index, img_g, B=bs, t_in=tags_in, t_out=t_out, row_elems=n_img * FEAT,
+                            src_bstride=(n_img * FEAT) if shared_in else tags_in * n_img * FEAT,
+                            src_tstride=0 if shared_in else n_img * FEAT)
+            drop = self._drop_cfg(0)
+            g2 = engine.trunk_forward(ws, P, text_g, img_g, bs, t_out, n_img, FEAT, save=True, drop=drop, img_shared=False)
+            drop_t = engine.DropCfg(drop.p, drop.seed, 3) if drop else None
+        else:
+            # no-grad: every (item, tag) pair goes through the trunk once; duplicates in `index` are gathered
+            # from the [bs, tags, 768] trunk output (the trunk is per-pair, so this is bit-identical)
+            text2, img2, _, _, _, shared = self._prep_inputs(text_emb, img_emb)
+            drop = self._drop_cfg(0)
+            g2_all = engine.trunk_forward(ws, P, text2, img2, bs, tags_in, n_img, FEAT, save=False, drop=drop, img_shared=shared)
+            g2 = ws.mat("g2_g", bs * t_out, FEAT)
+            ops.gather_rows(g2_all, index, g2, B=bs, t_in=tags_in, t_out=t_out, row_elems=FEAT)
+            drop_t = engine.DropCfg(drop.p, drop.seed, 3) if drop else None
+        M = bs * t_out
+        xin = ws.mat("xin", M, FEAT)
+        ops.add_period_rows(g2, P["pos_emb.weight"], xin, rows=M, D=FEAT, period=t_out)
+        xo = ws.mat("xo", M, FEAT)
+        engine.xit_forward(ws, "xitt.", P, engine.XITT, xin, xin, bs, t_out, t_out, FEAT, xo, save=save, drop=drop_t)
+        value = torch.empty(bs, device=dev)
+        ops.head_fwd(xo, P["head.weight"], P["head.bias"], value, rows=bs, D=FEAT, row_step=t_out, row_off=t_out - 1)
+        if save:
+            self._saved = (text_g, img_g, bs, t_out, n_img, drop, drop_t)
+        return value
+
+    def engine_backward(self, dvalue: torch.Tensor):
+        text_g, img_g, bs, t_out, n_img, drop, drop_t = self._saved
+        ws, P, G = self._workspace(text_g.device), self._P(), self.grad_buffers()
+        M = bs * t_out
+        xo, xin = ws.mat("xo", M, FEAT), ws.mat("xin", M, FEAT)
+        dxo = ws.mat("dxo", M, FEAT)
+        ops.head_bwd(xo, P["head.weight"], dvalue.contiguous().view(-1), dxo, G["head.weight"], G["head.bias"], rows=bs,
+                     D=FEAT, row_step=t_out, row_off=t_out - 1, total_rows=M)
+        dxin = ws.mat("dxin", M, FEAT)
+        engine.xit_backward(ws, "xitt.", P, G, engine.XITT, xin, xin, dxo, bs, t_out, t_out, FEAT, dxin, None,
+                            drop=drop_t, same_xy=True)
+        G["pos_emb.weight"].zero_()
+        ops.period_rows_grad(dxin, G["pos_emb.weight"], rows=M, D=FEAT, period=t_out)
+        engine.trunk_backward(ws, P, G, text_g, img_g, dxin, bs, t_out, n_img, FEAT, drop=drop, img_shared=False)
+        self._saved = None
+
+
+class Critic(_TailHead):
+    """finetune/ppo.py:247-297: value of the ordering `index` -> [bs] (head output at the last position)."""
+
+
+class Reward(_TailHead):
+    """finetune/ppo.py:300-350: as Critic, with pos_emb(arange(4)) hard-coded (index must be [bs, 4])."""
+    fixed_positions = 4
+
+
+class ActorCritic(nn.Module):
+    """finetune/ppo.py:173-193."""
+
+    def __init__(self, args, vit_args=None):
+        super().__init__()
+        self.actor = Actor(args, vit_args)
+        self.critic = Critic(args, vit_args)
+
+    def enable_actor(self):
+        for p in self.actor.parameters():
+            p.requires_grad = True
+
+    def disable_actor(self):
+        for p in self.actor.parameters():
+            p.requires_grad = False
+
+    def enable_critic(self):
+        for p in self.critic.parameters():
+            p.requires_grad = True
+
+    def disable_critic(self):
+        for p in self.critic.parameters():
+            p.requires_grad = False
+
+
+class _SmoothL1Fn(torch.autograd.Function):
+    """nn.SmoothL1Loss(beta=0.3) of finetune/ppo.py:236 (mean reduction), differentiable w.r.t. the logits."""
+
+    @staticmethod
+    def forward(ctx, logits, targets):
+        loss = torch.empty(1, device=logits.device)
+        dpred = torch.empty_like(logits) if logits.requires_grad else None
+        ops.smooth_l1(logits.detach().contiguous(), targets, loss, dpred, n=logits.numel(), beta=0.3)
+        ctx.dpred = dpred
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        return (ctx.dpred * dloss if ctx.dpred is not None else None), None
+
+
+class _ActorFn(torch.autograd.Function):
+    """Autograd entry of the drop-in nn.Module path: `loss.backward()` works as with the reference."""
+
+    @staticmethod
+    def forward(ctx, mod, text_emb, img_emb, *params):
+        ctx.mod = mod
+        with torch.no_grad():
+            return mod.engine_forward(text_emb, img_emb, save=True)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        mod = ctx.mod
+        mod.engine_backward(dlogits)
+        G = mod.grad_buffers()
+        return (None, None, None, *[G[n].clone() for n, _ in mod.named_parameters()])
+
+
+class _CriticFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, text_emb, img_emb, index, *params):
+        ctx.mod = mod
+        with torch.no_grad():
+            return mod.engine_forward(text_emb, img_emb, index, save=True)
+
+    @staticmethod
+    def backward(ctx, dvalue):
+        mod = ctx.mod
+        mod.engine_backward(dvalue)
+        G = mod.grad_buffers()
+        return (None, None, None, None, *[G[n].clone() for n, _ in mod.named_parameters()])
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter init / optimizer (finetune/ppo.py:358-419)
+# ---------------------------------------------------------------------------------------------
+def _init_normal(model, generator=None):
+    for n, p in list(model.named_parameters()):
+        if "gamma" not in n and "beta" not in n:
+            p.data.normal_(0, 0.02, generator=generator)
+
+
+def load_or_initialize_parameters(args, model):
+    if getattr(args, "pretrained_model_path", None) is not None:
+        model.load_state_dict(torch.load(args.pretrained_model_path, map_location="cpu"), strict=True)
+    else:
+        _init_normal(model)
+
+
+def load_or_initialize_parameters_reward(args, model):
+    if getattr(args, "reward_model_path", None) is not None:
+        model.load_state_dict(torch.load(args.reward_model_path, map_location="cpu"), strict=True)
+    else:
+        _init_normal(model)
+
+
+def _grouped(named):
+    no_decay = ["bias", "gamma", "beta"]
+    return [{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
+            {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
+
+
+def build_optimizer(args, model):
+    if args.optimizer not in str2optimizer:
+        raise NotImplementedError(f"optimizer {args.optimizer!r}: only adamw is on the HIP path (every LR2PPO launcher uses it)")
+    optimizer = str2optimizer[args.optimizer](_grouped(list(model.actor.named_parameters())), lr=args.learning_rate,
+                                              correct_bias=False)
+    critic_optimizer = str2optimizer[args.optimizer](_grouped(list(model.critic.named_parameters())),
+                                                     lr=args.critic_learning_rate, correct_bias=False)
+    if args.scheduler in ["constant"]:
+        scheduler = str2scheduler[args.scheduler](optimizer)
+        critic_scheduler = str2scheduler[args.scheduler](critic_optimizer)
+    elif args.scheduler in ["constant_with_warmup"]:
+        scheduler = str2scheduler[args.scheduler](optimizer, args.train_steps * args.warmup)
+        critic_scheduler = str2scheduler[args.scheduler](critic_optimizer, args.train_steps * args.warmup)
+    else:
+        scheduler = str2scheduler[args.scheduler](optimizer, args.train_steps * args.warmup, args.train_steps)
+        critic_scheduler = str2scheduler[args.scheduler](critic_optimizer, args.train_steps * args.warmup, args.train_steps)
+    return optimizer, critic_optimizer, scheduler, critic_scheduler
+
+
+# ---------------------------------------------------------------------------------------------
+# rollout + update  (finetune/ppo.py:501-617, 844-883)
+# ---------------------------------------------------------------------------------------------
+@torch.no_grad()
+def rollout_step(model, reward_model, text_emb, img_emb, tgts, state=None):
+    """One timestep of the rollout loop (finetune/ppo.py:844-883) -> the 8-entry memory record."""
+    bs, tags = text_emb.shape[:2]
+    dev = text_emb.device
+    if state is None:
+        state = torch.arange(tags, device=dev).unsqueeze(0).repeat(bs, 1)
+    logits = model.actor.engine_forward(text_emb, img_emb, save=False)
+    value = model.critic.engine_forward(text_emb, img_emb, state, save=False)
+    scores = logits.view(bs, tags)
+    _, order = torch.sort(scores, dim=-1, descending=True)
+    next_state = torch.cat([torch.arange(2, device=dev).unsqueeze(0).repeat(bs, 1), torch.gather(state, 1, order)], dim=1)
+    rewards = reward_model.engine_forward(text_emb, img_emb, next_state, save=False)
+    return [state, next_state, scores.clone(), rewards, value, text_emb, img_emb, tgts]
+
+
+class _DataParallel:
+    """Gradient exchange for the north-star DP mode: all-reduce(avg) of the flat gradient buffers over RCCL,
+    the 2 GB out_layer bucket first and on a side stream so it overlaps the rest of backward."""
+
+    def __init__(self):
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
+
+    def reduce(self, head: _Head):
+        if self.world == 1:
+            return
+        flat = head._flat_grad
+        flat.div_(self.world)
+        dist.all_reduce(flat)
+
+
+def train_model(args, model, optimizer, critic_optim, scheduler, critic_scheduler, memories, epoch):
+    """One PPO update cycle over the stored rollouts; returns the reference's 10 averaged metrics
+    [policy, value, kl, old_value, value, rewards_ori, rewards, advantages, rank_loss, entropy] (ppo.py:615-617)."""
+    dev = next(model.parameters()).device
+    dp = _DataParallel()
+    actor, critic = model.actor, model.critic
+    actor.bind_grads()
+    critic.bind_grads()
+    total = torch.zeros(10, device=dev)
+    metrics = torch.empty(10, device=dev)
+    n_done = 0
+    for (state, next_state, old_scores, rewards, old_value, text, img, tgts) in memories:
+        bs, tags = old_scores.shape[:2]
+        scal, per = torch.empty(4, device=dev), torch.empty(4, bs, device=dev)
+        dscores, dvalue = torch.empty(bs, tags, device=dev), torch.empty(bs, device=dev)
+        logits = actor.engine_forward(text, img, save=True)
+        value = critic.engine_forward(text, img, state, save=True)
+        ops.ppo_loss(logits.view(bs, tags), old_scores.contiguous(), rewards.contiguous(), old_value.contiguous(), value,
+                     next_state.contiguous(), scal, per, dscores, dvalue, B=bs, T=tags, kl_w=args.kl_div_loss_weight,
+                     ent_w=args.entropy_weight, value_clip=args.value_clip, margin=0.01, adv_eps=-0.1)
+        actor.engine_backward(dscores)
+        dp.reduce(actor)
+        optimizer.step()
+        critic.engine_backward(dvalue)
+        dp.reduce(critic)
+        critic_optim.step()
+        pm = per.mean(dim=1)
+        metrics[0], metrics[1], metrics[2], metrics[3] = scal[0], scal[1], pm[0], old_value.mean()
+        metrics[4], metrics[5], metrics[6], metrics[7] = value.mean(), rewards.mean(), pm[2], pm[3]
+        metrics[8], metrics[9] = scal[2], pm[1]
+        if dp.world > 1:           # the reference's 10 logging all-reduces (ppo.py:589-598), packed into one
+            metrics.div_(dp.world)
+            dist.all_reduce(metrics)
+        total += metrics
+        n_done += 1
+    scheduler.step()
+    critic_scheduler.step()
+    out = (total / max(n_done, 1)).tolist()
+    if any(v != v for v in out):
+        raise FloatingPointError("NaN in PPO metrics (the reference drops into pdb here, finetune/ppo.py:576-578)")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# evaluation (finetune/ppo.py:620-681)
+# ---------------------------------------------------------------------------------------------
+@torch.no_grad()
+def evaluate(args, val_loader, step, split="test", num_tasks=None):
+    ndcg_obj = AverageNDCGMeter()
+    args.model.eval()
+    local = []
+    for text_emb, img_emb, tgts in val_loader:
+        text_emb = text_emb.to(args.device)
+        img_emb = img_emb.to(args.device)            # [1, n_img, 768]: shared by all tags of the item
+        logits = args.model.actor.engine_forward(text_emb, img_emb, save=False)
+        local.append((logits.view(-1).cpu(), tgts.view(-1).cpu()))
+    vecs = [ndcg_obj.return_ndcg_at_k_from_scores(s, g) for s, g in local]
+    mine = torch.stack(vecs) if vecs else torch.zeros(0, len(ndcg_obj.ndcg_at_k))
+    world = num_tasks or 1
+    if world > 1 and dist.is_initialized():
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        # interleave like the reference's per-item all_gather (rank-major within each step)
+        rows = [g[i] for i in range(max(len(g) for g in gathered)) for g in gathered if i < len(g)]
+        mine = torch.stack(rows) if rows else mine
+    if getattr(args, "is_master", True):
+        for row in mine:
+            for i, k in enumerate(ndcg_obj.ndcg_at_k):
+                ndcg_obj.ndcg[k].append(row[i])
+        vals = ndcg_obj.value()
+        if hasattr(args, "logger"):
+            args.logger.info("NDCG:")
+            args.logger.info("".join("\nNDCG@{}={:.4f}".format(k, vals[k]) for k in sorted(vals.keys())))
+        args.last_ndcg = {int(k): float(v) for k, v in vals.items()}
+        return vals[100000000]
+    return None
+
+
+# ---------------------------------------------------------------------------------------------
+# data (finetune/ppo.py:58-151, 684-699)
+# ---------------------------------------------------------------------------------------------
+class MovieNet(Dataset):
+    """LRMovieNet reader with the reference's sampling (80 random ordered tag pairs per item in training,
+    shuffled image features cyclically padded to max_imgs).  Needs h5py + LRMovieNet/clean_feat.h5."""
+
+    def __init__(self, args, path, is_train=False):
+        try:
+            import h5py
+        except ImportError as e:
+            raise RuntimeError("MovieNet needs h5py (absent in this image); use --synthetic_items for synthetic data") from e
+        with open(path) as f:
+            self.data = json.load(f)
+        self.embed_data = h5py.File(os.path.join("LRMovieNet", "clean_feat.h5"), "r")
+        self.max_imgs, self.is_train, self.max_tags = args.max_imgs, is_train, args.max_tags
+        self.items = []
+        for item in self.data:
+            tags = item["tags"]
+            if is_train:
+                for _ in range(self.max_tags):
+                    idx = list(range(len(tags)))
+                    random.shuffle(idx)
+                    self.items.append((item["id"], idx[:2], [tags[i] for i in idx[:2]]))
+            else:
+                self.items.append((item["id"], list(range(len(tags))), tags))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        item_id, tag_index, tag_list = self.items[i]
+        grp = self.embed_data[f"{item_id}"]
+        text = torch.tensor(grp["text_emb"][:])[torch.tensor(tag_index)]
+        loaded = torch.tensor(grp["img_emb"][:][0])
+        loaded = loaded[torch.randperm(loaded.shape[0])]
+        n = loaded.shape[0]
+        img = loaded[: self.max_imgs] if n > self.max_imgs else loaded[torch.arange(self.max_imgs) % n]
+        return text, img, torch.tensor([int(t["target"]) for t in tag_list])
+
+
+class SyntheticMovieNet(Dataset):
+    """Seeded stand-in with LRMovieNet's shapes: text_emb ~ N(0,1) [tags,196,768], img_emb ~ N(0,1)
+    [16,768], targets in {0,1,2}.  Train items are ordered tag pairs, val items carry all `val_tags` tags."""
+
+    def __init__(self, n_items, tags, max_imgs=16, seed=7):
+        self.n, self.tags, self.max_imgs, self.seed = n_items, tags, max_imgs, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        text = torch.randn(self.tags, SEQ_LEN, FEAT, generator=g)
+        img = torch.randn(self.max_imgs, FEAT, generator=g)
+        return text, img, torch.randint(0, 3, (self.tags,), generator=g)
+
+
+def get_dataloader(args, dataset, num_tasks, global_rank, is_train=False):
+    sampler = DistributedSampler(dataset, num_replicas=num_tasks, rank=global_rank, shuffle=is_train)
+    workers = getattr(args, "num_workers", 32 if not isinstance(dataset, SyntheticMovieNet) else 2)
+    return DataLoader(dataset=dataset, batch_size=args.batch_size if is_train else 1, sampler=sampler,
+                      num_workers=workers, drop_last=False)
+
+
+# ---------------------------------------------------------------------------------------------
+# entry point (finetune/ppo.py:702-915)
+# ---------------------------------------------------------------------------------------------
+def build_parser():
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    finetune_opts(parser)
+    tokenizer_opts(parser)
+    parser.add_argument("--mode", type=str, default="reg")
+    adv_opts(parser)
+    parser.add_argument("--vit_pretrained_model_path", default=None, type=str)
+    parser.add_argument("--vit_config_path", default="models/bert/base_config.json", type=str)
+    parser.add_argument("--vit_tokenizer", choices=["bert", "bpe", "char", "space", "xlmroberta", "image", "text_image", "virtual"])
+    parser.add_argument("--vit_encoder", choices=["transformer", "rnn", "lstm", "gru", "birnn", "bilstm", "bigru", "gatedcnn", "dual"])
+    parser.add_argument("--dist_url", type=str, default="env://")
+    parser.add_argument("--max_tags", type=int, default=32)
+    parser.add_argument("--exp_name", type=str)
+    parser.add_argument("--use_pairwise", action="store_true")
+    parser.add_argument("--reward_model_path", type=str)
+    parser.add_argument("--max_timesteps", type=int, default=5)
+    parser.add_argument("--update_timesteps", type=int, default=300)
+    parser.add_argument("--eps_clip", type=float, default=0.2)        # parsed, never read -- as upstream
+    parser.add_argument("--kl_div_loss_weight", type=float, default=0.1)
+    parser.add_argument("--entropy_weight", type=float, default=0.1)
+    parser.add_argument("--value_clip", type=float, default=0.4)
+    parser.add_argument("--critic_learning_rate", type=float, default=2e-6, help="Learning rate.")
+    # additions of this build (not in the reference): synthetic data + bounded runs for boxes without LRMovieNet
+    parser.add_argument("--synthetic_items", type=int, default=0, help="use SyntheticMovieNet with this many train items")
+    parser.add_argument("--synthetic_val_items", type=int, default=16)
+    parser.add_argument("--max_cycles", type=int, default=0, help="stop after this many update cycles (0 = run all epochs)")
+    return parser
+
+
+def main(argv=None):
+    parser = build_parser()
+    args = parser.parse_args(argv)
+    vit_args_dict = dict(vars(args))
+    for k, v in vars(args).items():
+        if "vit_" in k:
+            vit_args_dict[k[4:]] = v
+    vit_args = argparse.Namespace(**vit_args_dict)
+    args = load_hyperparam(args)
+    if os.path.exists(vit_args.config_path):
+        vit_args = load_hyperparam(vit_args)
+    args.labels_num = 3
+
+    misc.init_distributed_mode(args)
+    misc.setup_seed(args.seed + misc.get_rank())
+    args.is_master = misc.is_main_process()
+    num_tasks, global_rank = misc.get_world_size(), misc.get_rank()
+
+    model = ActorCritic(args, vit_args)
+    reward_model = Reward(args, vit_args)
+    load_or_initialize_parameters(args, model.actor)
+    load_or_initialize_parameters_reward(args, model.critic)
+    load_or_initialize_parameters_reward(args, reward_model)
+    if args.is_master:
+        args.logger = init_logger(args)
+    args.device = torch.device("cuda", torch.cuda.current_device())
+    model = model.to(args.device)
+    reward_model = reward_model.to(args.device).eval()
+    if num_tasks > 1:   # the reference initialises each rank from its own seed (quirk 17); replicas must start equal
+        for p in list(model.parameters()) + list(reward_model.parameters()):
+            dist.broadcast(p.data, src=0)
+
+    def make_sets():
+        if args.synthetic_items > 0:
+            return (SyntheticMovieNet(args.synthetic_items, 2, args.max_imgs, args.seed),
+                    SyntheticMovieNet(args.synthetic_val_items, 20, args.max_imgs, args.seed + 1))
+        return MovieNet(args, args.train_path, is_train=True), MovieNet(args, args.dev_path, is_train=False)
+
+    trainset, valset = make_sets()
+    val_loader = get_dataloader(args, valset, num_tasks, global_rank, is_train=False)
+    args.train_steps = int(len(trainset) * args.epochs_num / args.batch_size) + 1
+    if args.is_master:
+        args.logger.info("Batch size: {}".format(args.batch_size))
+        args.logger.info("The number of training instances: {}".format(len(trainset)))
+    optimizer, critic_optimizer, scheduler, critic_scheduler = build_optimizer(args, model)
+    args.model = model
+    best_result, step, time, cycles = 0.0, 0, 0, 0
+    if args.is_master:
+        args.logger.info("Start training.")
+    for epoch in range(1, args.epochs_num):            # range(1, N): as upstream (quirk 18)
+        trainset, _ = make_sets()
+        train_loader = get_dataloader(args, trainset, num_tasks, global_rank, is_train=True)
+        train_loader.sampler.set_epoch(epoch)
+        memories = []
+        for text_emb, img_emb, tgts in train_loader:
+            text_emb, img_emb, tgts = text_emb.to(args.device), img_emb.to(args.device), tgts.to(args.device)
+            model.eval()
+            state = None
+            for timestep in range(args.max_timesteps):
+                time += 1
+                rec = rollout_step(model, reward_model, text_emb, img_emb, tgts, state)
+                state = rec[1]
+                memories.append(rec)
+                if time % args.update_timesteps == 0:
+                    model.train()
+                    t0 = _time.time()
+                    vals = train_model(args, model, optimizer, critic_optimizer, scheduler, critic_scheduler, memories, epoch)
+                    memories = []
+                    model.eval()
+                    cycles += 1
+                    names = ["Policy loss", "Critic Loss", "KL Penalty", "Old Values", "Values", "Rewards Ori", "Reward",
+                             "Rank Loss", "Advantages", "Entropy"]
+                    order = [0, 1, 2, 3, 4, 5, 6, 8, 7, 9]
+                    if args.is_master:
+                        args.logger.info(f"Training step: {step}")
+                        for n, i in zip(names, order):
+                            args.logger.info(f"{n}: {vals[i]}")
+                        args.logger.info(f"update cycle wall time {_time.time() - t0:.2f}s")
+                        args.logger.info("\nVal set evaluation.")
+                    result = evaluate(args, val_loader, step, split="val", num_tasks=num_tasks)
+                    if args.is_master and result > best_result:
+                        best_result = result
+                        save_model(model, args.output_model_path)
+                        args.logger.info("Best val indicator until now!")
+                    if args.max_cycles and cycles >= args.max_cycles:
+                        return best_result
+    return best_result
+
+
+if __name__ == "__main__":
+    main()

@@ -54,7 +54,7 @@ class Drop:
 def choose_tiling(M: int, N: int, K: int, trans_a: bool):
     """(block_m, splits): fill the 256 CUs (>= ~2 workgroups each) using split-K for skinny GEMMs."""
     bm = 64 if (M <= 64 and not trans_a) else 128
-    tiles = ((M + bm - 1) // bm) * (N // 128)
+    tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
     k_tiles = (K + 63) // 64
     splits = 1
     if tiles < 256 and k_tiles >= 8:

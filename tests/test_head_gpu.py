@@ -1,0 +1,230 @@
+"""Model-level parity on a real MI355X: the drop-in Actor / Critic / Reward / train_model against
+(a) golden outputs captured from the imported reference (tests/golden/*.npz, oracle/gen_golden.py) and
+(b) the CPU oracle on the same seeded inputs (train-mode dropout, gradients).
+
+Tolerance: north_star asks for 1e-3 on logits / returns; the split-bf16 path is expected at ~1e-5, so the
+tests assert 1e-4 to keep an order of magnitude of margin visible.
+"""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import lr2ppo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ARGS = dict(mode="reg", labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768)
+TOL = 1e-4
+
+
+def _ns(**kw):
+    return argparse.Namespace(**kw)
+
+
+def _load(mod, kind, seed, dev):
+    mod.load_state_dict(O.seeded_params(O.head_param_spec(kind), seed=seed), strict=True)
+    return mod.to(dev)
+
+
+def _maxerr(a, b):
+    return (a.detach().double().cpu() - b.detach().double().cpu()).abs().max().item()
+
+
+def test_forward_matches_reference_golden(dev):
+    from lr2ppo_amd.finetune import ppo
+    g = load_golden("head_fwd.npz")
+    bs, tags = int(g["bs"]), int(g["tags"])
+    text, img, tgts = O.seeded_head_inputs(1234, bs, tags)
+    td, imd, tg = text.to(dev), img.to(dev), tgts.to(dev)
+    state = torch.arange(tags).unsqueeze(0).repeat(bs, 1).to(dev)
+    with torch.no_grad():
+        actor = _load(ppo.Actor(_ns(**ARGS), None).eval(), "actor", 7, dev)
+        loss, logits = actor(td, imd, tg)
+        assert _maxerr(logits, g["actor_logits"]) < TOL
+        assert abs(float(loss) - float(g["actor_loss"])) < TOL
+        # shared image tokens (stride-0 expand / [bs,16,768]) must give the same logits as the materialised repeat
+        logits_shared = actor(td, imd[:, 0].contiguous(), None)
+        assert torch.equal(logits_shared, logits)
+        text5, img5, tg5 = O.seeded_head_inputs(4321, 1, 5)
+        lg5 = actor(text5.to(dev), img5.to(dev), None)
+        assert _maxerr(lg5, g["actor_logits_eval5"]) < TOL
+        del actor
+        critic = _load(ppo.Critic(_ns(**ARGS), None).eval(), "critic", 8, dev)
+        assert _maxerr(critic(td, imd, tg, state), g["critic_value"]) < TOL
+        assert _maxerr(critic(td, imd, tg, state.flip(dims=[-1])), g["critic_value_flipped"]) < TOL
+        del critic
+        nxt = O.rollout_next_state(logits.view(bs, tags).cpu(), state.cpu())
+        assert torch.equal(nxt, g["next_state"])
+        reward = _load(ppo.Reward(_ns(**ARGS), None).eval(), "reward", 9, dev)
+        assert _maxerr(reward(td, imd, tg, nxt.to(dev)), g["reward"]) < TOL
+        with pytest.raises(ValueError):
+            reward(td, imd, tg, state)          # Reward hard-codes 4 positions (finetune/ppo.py:339)
+
+
+def test_train_model_two_cycles_match_reference_golden(dev):
+    """Two consecutive train_model cycles (lr 0, then lr/warm): the 10 returned metrics, the rollout tensors,
+    sampled gradients and sampled post-step weights against the imported reference."""
+    from lr2ppo_amd.finetune import ppo
+    g = load_golden("train_step.npz")
+    bs, tags = int(g["bs"]), int(g["tags"])
+    args = _ns(**ARGS, is_master=False, kl_div_loss_weight=0.001, entropy_weight=0.001, value_clip=0.5, optimizer="adamw",
+               scheduler="linear", learning_rate=1e-3, critic_learning_rate=1e-3, train_steps=41, warmup=0.1, device=dev)
+    model = ppo.ActorCritic(args, None)
+    _load(model.actor, "actor", 7, dev)
+    _load(model.critic, "critic", 8, dev)
+    model = model.to(dev)
+    reward = _load(ppo.Reward(args, None).eval(), "reward", 9, dev)
+    opt, copt, sch, csch = ppo.build_optimizer(args, model)
+    model.eval()          # dropout off, as in the golden run
+    named = dict(model.named_parameters())
+    for cycle in range(2):
+        lrs = g[f"lr_{cycle}"]
+        assert abs(opt.param_groups[0]["lr"] - float(lrs[0])) < 1e-12 and abs(copt.param_groups[0]["lr"] - float(lrs[1])) < 1e-12
+        memories = []
+        for mb in range(2):
+            text, img, tgts = O.seeded_head_inputs(1000 + 10 * cycle + mb, bs, tags)
+            rec = ppo.rollout_step(model, reward, text.to(dev), img.to(dev), tgts.to(dev))
+            assert _maxerr(rec[2], g[f"c{cycle}_mb{mb}_scores"]) < TOL
+            assert _maxerr(rec[4], g[f"c{cycle}_mb{mb}_value"]) < TOL
+            assert _maxerr(rec[3], g[f"c{cycle}_mb{mb}_reward"]) < TOL
+            assert torch.equal(rec[1].cpu(), g[f"c{cycle}_mb{mb}_next_state"])
+            memories.append(rec)
+        out = ppo.train_model(args, model, opt, copt, sch, csch, memories, 1)
+        ref = g[f"metrics_{cycle}"]
+        for i, (a, b) in enumerate(zip(out, ref.tolist())):
+            assert abs(a - b) < TOL, f"cycle {cycle} metric {i}: {a} vs {b}"
+        for key in [k for k in g if k.startswith(f"w{cycle}.")]:
+            n = key[len(f"w{cycle}."):]
+            idx = g["idx." + n].to(dev)
+            w = named[n].detach().flatten()[idx]
+            assert _maxerr(w, g[key]) < 2e-6, f"weights {n} after cycle {cycle}"
+            gk = f"g{cycle}." + n
+            if gk in g:
+                gr = named[n].grad.detach().flatten()[idx]
+                ref_g = g[gk]
+                assert _maxerr(gr, ref_g) < 1e-6 + 2e-3 * float(ref_g.abs().max()), f"grad {n} cycle {cycle}"
+    assert out[2] > 0.0          # KL becomes non-zero only after the first real update (cycle 2)
+
+
+def test_train_mode_dropout_and_gradients_match_oracle(dev):
+    """Train mode (dropout 0.1 at the three XiT sites) with a pinned mask stream: logits and parameter
+    gradients of a weighted logit sum against the oracle's autograd on CPU, Actor and Critic."""
+    from lr2ppo_amd import runtime
+    from lr2ppo_amd.finetune import ppo
+    bs, tags = 2, 2
+    text, img, tgts = O.seeded_head_inputs(55, bs, tags)
+    gen = torch.Generator().manual_seed(56)
+    wlog = torch.randn(bs * tags, generator=gen)
+    wval = torch.randn(bs, generator=gen)
+    check = ["text_proj.fc1.weight", "text_proj.fc2.bias", "img_proj.fc2.weight", "xit.0.0.0.fn.0.ln_x.weight",
+             "xit.0.0.0.fn.0.ln_y.bias", "xit.0.0.0.fn.1.keys.weight", "xit.0.0.0.fn.1.queries.bias",
+             "xit.0.0.0.fn.1.values.weight", "xit.0.0.0.fn.1.projection.weight", "xit.0.0.1.fn.0.weight",
+             "xit.0.0.1.fn.1.0.weight", "xit.0.0.1.fn.1.3.bias", "xit.1.0.weight", "xit.1.0.bias", "out_layer.fc1.bias",
+             "out_layer.fc2.weight", "head.weight", "head.bias"]
+    # ---- actor ----
+    P = O.seeded_params(O.head_param_spec("actor"), seed=7)
+    actor = ppo.Actor(_ns(**ARGS), None)
+    actor.load_state_dict(P, strict=True)
+    actor = actor.to(dev).train()
+    runtime.set_dropout_seed(2024, calls=5)
+    seed = runtime.peek_drop_seed()
+    logits = actor.engine_forward(text.to(dev), img.to(dev), save=True)
+    actor.engine_backward(wlog.to(dev))
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref_logits = O.actor_forward(Pg, text, img, None, drop={"p": 0.1, "seed": seed, "site_base": 0})
+    (ref_logits * wlog).sum().backward()
+    assert _maxerr(logits, ref_logits) < TOL
+    G = actor.grad_buffers()
+    for n in check + ["out_layer.fc1.weight"]:
+        ref_g = Pg[n].grad
+        err = _maxerr(G[n], ref_g)
+        assert err < 1e-7 + 2e-3 * float(ref_g.abs().max()), f"actor grad {n}: err {err} scale {float(ref_g.abs().max())}"
+    # eval mode must ignore dropout entirely
+    actor.eval()
+    ev = actor.engine_forward(text.to(dev), img.to(dev), save=False)
+    assert _maxerr(ev, O.actor_forward(P, text, img, None)) < TOL
+    del actor, Pg, G
+    # ---- critic (trunk + pos_emb + xitt + last-position head), non-identity index ----
+    P = O.seeded_params(O.head_param_spec("critic"), seed=8)
+    critic = ppo.Critic(_ns(**ARGS), None)
+    critic.load_state_dict(P, strict=True)
+    critic = critic.to(dev).train()
+    index = torch.tensor([[1, 0], [0, 1]])
+    runtime.set_dropout_seed(2025, calls=1)
+    seed = runtime.peek_drop_seed()
+    value = critic.engine_forward(text.to(dev), img.to(dev), index.to(dev), save=True)
+    critic.engine_backward(wval.to(dev))
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref_v = O.critic_forward(Pg, text, img, index, drop={"p": 0.1, "seed": seed, "site_base": 0})
+    (ref_v * wval).sum().backward()
+    assert _maxerr(value, ref_v) < TOL
+    G = critic.grad_buffers()
+    tail = [n.replace("xit.", "xitt.") for n in check if n.startswith("xit.")] + ["pos_emb.weight"]
+    for n in check + tail:
+        ref_g = Pg[n].grad
+        err = _maxerr(G[n], ref_g)
+        assert err < 1e-7 + 2e-3 * float(ref_g.abs().max()), f"critic grad {n}: err {err} scale {float(ref_g.abs().max())}"
+
+
+def test_autograd_dropin_path_matches_engine(dev):
+    """`loss.backward()` on the nn.Module outputs (the reference's calling convention) fills p.grad with the
+    same values as the explicit engine schedule."""
+    from lr2ppo_amd.finetune import ppo
+    bs, tags = 2, 2
+    text, img, tgts = O.seeded_head_inputs(77, bs, tags)
+    actor = ppo.Actor(_ns(**ARGS), None)
+    actor.load_state_dict(O.seeded_params(O.head_param_spec("actor"), seed=7), strict=True)
+    actor = actor.to(dev).eval()
+    loss, logits = actor(text.to(dev), img.to(dev), tgts.to(dev))
+    assert logits.requires_grad
+    (logits * 2.0).sum().backward()
+    got = {n: p.grad.clone() for n, p in actor.named_parameters()}
+    lg = actor.engine_forward(text.to(dev), img.to(dev), save=True)
+    actor.engine_backward(torch.full((bs * tags,), 2.0, device=dev))
+    G = actor.grad_buffers()
+    assert torch.equal(lg, logits.detach())
+    for n in got:
+        assert torch.equal(got[n], G[n]), n
+
+
+def test_xit_small_golden_standalone_module(dev):
+    """XiT(feat_size=64) forward + input/parameter gradients against full tensors captured from the reference."""
+    from lr2ppo_amd.finetune.xit import XiT
+    g = load_golden("xit_small.npz")
+    m = XiT(feat_size=64)
+    m.load_state_dict({k[len("param."):]: v for k, v in g.items() if k.startswith("param.")}, strict=True)
+    m = m.to(dev).eval()
+    x = g["x"].to(dev).requires_grad_(True)
+    y = g["y"].to(dev).requires_grad_(True)
+    out = m((x, y))
+    assert _maxerr(out, g["out"]) < 2e-5
+    (out * g["w"].to(dev)).sum().backward()
+    assert _maxerr(x.grad, g["dx"]) < 1e-4 and _maxerr(y.grad, g["dy"]) < 1e-4
+    for n, p in m.named_parameters():
+        ref = g["grad." + n]
+        assert _maxerr(p.grad, ref) < 1e-5 + 1e-3 * float(ref.abs().max()), n
+    xs = g["xs"].to(dev)
+    with torch.no_grad():
+        out_self = m((xs, xs))
+    assert _maxerr(out_self, g["out_self"]) < 2e-5
+
+
+def test_single_bf16_pass_is_not_good_enough(dev):
+    """Documents why the default is the split-bf16 GEMM: one bf16 pass breaks the 1e-3 logit bar."""
+    from lr2ppo_amd import ops
+    from lr2ppo_amd.finetune import ppo
+    g = load_golden("head_fwd.npz")
+    bs, tags = int(g["bs"]), int(g["tags"])
+    text, img, _ = O.seeded_head_inputs(1234, bs, tags)
+    actor = _load(ppo.Actor(_ns(**ARGS), None).eval(), "actor", 7, dev)
+    try:
+        ops.set_gemm_passes(1)
+        with torch.no_grad():
+            lg = actor(text.to(dev), img.to(dev), None)
+    finally:
+        ops.set_gemm_passes(3)
+    err = _maxerr(lg, g["actor_logits"])
+    assert 2e-4 < err < 2e-2, err

@@ -120,7 +120,19 @@ def test_gemm_rejects_bad_shapes(ops, dev):
     with pytest.raises(NativeError):
         ops.gemm(a, b, torch.zeros(8, 128, device=dev), 8, 128, 100)       # K % 64 != 0
     with pytest.raises(NativeError):
-        ops.gemm(torch.zeros(8, 64, device=dev), torch.zeros(100, 64, device=dev), torch.zeros(8, 100, device=dev), 8, 100, 64)
+        ops.gemm(torch.zeros(8, 66, device=dev), torch.zeros(128, 66, device=dev), torch.zeros(8, 128, device=dev), 8, 128, 64, lda=66, ldb=66)
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm_ragged_n_and_m(ops, dev, ta, tb):
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 72, 200, 64
+    a = _rand(g, K, M) if ta else _rand(g, M, K)
+    b = _rand(g, K, N) if tb else _rand(g, N, K)
+    ref = (a.double().t() if ta else a.double()) @ (b.double() if tb else b.double().t())
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(a.to(dev), b.to(dev), out, M, N, K, trans_a=ta, trans_b=tb, splits=1)
+    _close(out, ref, atol=6e-5 * math.sqrt(K), rtol=5e-5, what=f"ragged ta={ta} tb={tb}")
 
 
 # ------------------------------------------------------------------------------------- LayerNorm
