@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""PPO steps/s of the LR2PPO stage-3 hot path on MI355X (BASELINE.json metric).
+
+One "PPO step"  = one rollout timestep (actor + critic + reward no-grad forwards on a batch,
+finetune/ppo.py:844-883) + one update minibatch (actor fwd/bwd/AdamW + critic fwd/bwd/AdamW with the fused PPO
+loss, finetune/ppo.py:518-587, dropout active as under model.train()) on a batch of the same shape.
+Synthetic LRMovieNet-shaped inputs resident in HBM, random N(0, 0.02) weights of the reference architecture
+(519 M-parameter actor, 526 M critic and reward), batch 32 items x 2 tags per GPU.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0.  `roofline` describes the kernel signature that took the most device time in the
+timed region (HIP events on the launch stream); `cpu_baseline` is the CPU oracle ("port") timed on the host cores
+of this box on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.3 TB/s achievable)
+MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="items per GPU per step (BASELINE: 32)")
+    ap.add_argument("--tags", type=int, default=2)
+    ap.add_argument("--passes", type=int, default=3, choices=[1, 3], help="GEMM precision: 3 = split-bf16 (parity mode)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4, help="batch of the CPU-baseline sample")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if a.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+
+    from lr2ppo_amd import _native
+    if rank == 0:
+        _native.build()
+    if world > 1:
+        dist.barrier()
+    from lr2ppo_amd import ops, runtime
+    from lr2ppo_amd.finetune import ppo
+
+    ops.set_gemm_passes(a.passes)
+    margs = argparse.Namespace(mode="reg", labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768, is_master=rank == 0,
+                               kl_div_loss_weight=0.001, entropy_weight=0.001, value_clip=0.5, optimizer="adamw",
+                               scheduler="linear", learning_rate=1e-3, critic_learning_rate=1e-3, train_steps=1000, warmup=0.1,
+                               device=dev)
+    # identical replicas on every rank: same seed for the weights, rank-specific seed for the data
+    torch.manual_seed(7)
+    torch.cuda.manual_seed(7)
+    model = ppo.ActorCritic(margs, None).to(dev)
+    reward = ppo.Reward(margs, None).to(dev).eval()
+    with torch.no_grad():
+        for p in list(model.parameters()) + list(reward.parameters()):
+            p.normal_(0, 0.02)                     # the reference's initialiser (finetune/ppo.py:362-365), on device
+    opt, copt, sch, csch = ppo.build_optimizer(margs, model)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(20):                        # leave the lr-0 first cycle (quirk 15): lr = 20/100 of 1e-3
+            sch.step(), csch.step()
+    model.actor.bind_grads(), model.critic.bind_grads()
+    runtime.set_dropout_seed(1234 + rank)
+    dp = ppo._DataParallel()
+
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    n_batches = 4
+    data = [(torch.randn(a.batch, a.tags, 196, 768, device=dev, generator=g),
+             torch.randn(a.batch, 16, 768, device=dev, generator=g),          # shared by the tags of an item
+             torch.randint(0, 3, (a.batch, a.tags), device=dev, generator=g)) for _ in range(n_batches)]
+
+    def step(i):
+        text, img, tgts = data[i % n_batches]
+        model.eval()
+        rec = ppo.rollout_step(model, reward, text, img, tgts)
+        model.train()
+        return ppo.update_minibatch(margs, model, opt, copt, rec, dp)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        m = step(i)
+    fence()
+    if not a.no_profile:
+        ops.profile_start()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        m = step(a.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_stop() if not a.no_profile else {}
+    if not torch.isfinite(m).all():
+        raise SystemExit("bench: non-finite PPO metrics")
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms_per_step = dt / a.steps * 1e3
+    value = world * a.steps / dt
+    out = {
+        "metric": "ppo_steps_per_sec", "value": round(value, 3), "unit": "PPO steps/s (1 step = 1 rollout batch + 1 update minibatch, 32 items x 2 tags per GPU)",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (GEMMs: split-bf16 x3 on MFMA, fp32 accumulate)" if a.passes == 3 else "bf16 inputs, fp32 accumulate (1 pass)",
+        "data": "synthetic",
+        "config": {"workload": "LR2PPO stage-3 head-only PPO step (actor 519M + critic 526M + reward 526M params), "
+                               "LRMovieNet-shaped synthetic features: text_emb [32,2,196,768], img_emb [32,16,768]",
+                   "batch_per_gpu": a.batch, "tags": a.tags, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                   "items_per_sec": round(value * a.batch, 1),
+                   "algorithmic_tflop_per_step": 3.44 if (a.batch, a.tags) == (32, 2) else None},
+    }
+    # ---- roofline of the dominant kernel signature in the timed region ----
+    if prof:
+        key, rec = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        avg_ms = rec["ms"] / rec["n"]
+        top = sorted(((k, round(v["ms"] / a.steps, 3)) for k, v in prof.items()), key=lambda kv: -kv[1])[:8]
+        # ridge point: a GEMM is matrix-core bound when its flops/byte exceeds (MFMA peak / passes) / HBM peak
+        ridge = (MFMA_BF16_PEAK_TF * 1e12 / a.passes) / (HBM_PEAK_GBS * 1e9)
+        if key.startswith("gemm") and rec["flops"] / max(rec["bytes"], 1) > ridge:
+            ach = rec["flops"] / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": key, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TF,
+                               "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TF, 4), "traffic": None,
+                               "avg_launch_ms": round(avg_ms, 4), "launches": rec["n"],
+                               "note": "achieved counts algorithmic 2MNK flops; passes=%d bf16 MFMA products per flop" % a.passes}
+        else:
+            ach = rec["bytes"] / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"kernel": key, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                               "launches": rec["n"]}
+        out["roofline"]["top_ms_per_step"] = top
+        out["roofline"]["timed_kernels_ms_per_step"] = round(sum(v["ms"] for v in prof.values()) / a.steps, 3)
+    # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
+    if world == 1 and not a.no_cpu_baseline:
+        del model, reward, opt, copt, data
+        torch.cuda.empty_cache()
+        from oracle import cpu_baseline
+        r = cpu_baseline.time_ppo_step(a.cpu_batch, a.tags)
+        scale = a.batch / a.cpu_batch
+        est = scale * (r["rollout_s"] + r["fwd_bwd_s"]) + r["adamw_s"]
+        out["cpu_baseline"] = {"value": round(1.0 / est, 5), "unit": "PPO steps/s (batch 32 equivalent)", "cores": r["threads"],
+                               "kind": "port",
+                               "sample": f"oracle (torch CPU fp32) on 1 PPO step at batch {a.cpu_batch}: rollout {r['rollout_s']:.1f}s, "
+                                         f"update fwd+bwd {r['fwd_bwd_s']:.1f}s, AdamW(1.045B) {r['adamw_s']:.1f}s; "
+                                         f"batch-32 time = {scale:.0f} x (rollout + fwd/bwd) + AdamW"}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -110,6 +110,10 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"lr2ppo_amd: native library {LIB_PATH} is missing. Build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback.")
+        # PyTorch-ROCm ships its own libamdhip64 (SONAME libamdhip64.so.7).  Import torch FIRST so that the loader
+        # resolves this library's libamdhip64.so.7 to that already-loaded runtime; loaded in the other order the
+        # process would hold two HIP/HSA runtimes and the second one finds "no ROCm-capable device".
+        import torch  # noqa: F401
         try:
             handle = C.CDLL(LIB_PATH)
         except OSError as e:  # e.g. libamdhip64 not loadable

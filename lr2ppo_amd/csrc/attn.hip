@@ -258,9 +258,9 @@ extern "C" int lr2_xattn_fwd(const void* Q, const void* K, const void* V, void* 
                              int head_dim, float post_scale, void* stream) {
   if (!Q || !K || !V || !O || batch <= 0 || heads <= 0) return LR2_ERR_ARG;
   if (Lq < 1 || Lq > 256 || Lk < 1 || Lk > MAX_LK || head_dim > MAX_HD || head_dim % 4 != 0) return LR2_ERR_SHAPE;
-  hipLaunchKernelGGL(xattn_fwd_kernel, dim3(batch * heads), dim3(256), 0, (hipStream_t)stream, (const float*)Q,
+  LR2_LAUNCH(xattn_fwd_kernel, dim3(batch * heads), dim3(256), 0, (hipStream_t)stream, (const float*)Q,
                      (const float*)K, (const float*)V, (float*)O, heads, Lq, Lk, head_dim, post_scale);
-  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+  return lr2_launch_status(__func__);
 }
 
 extern "C" int lr2_xattn_bwd(const void* Q, const void* K, const void* V, const void* dO, void* dQ, void* dK, void* dV,
@@ -270,13 +270,13 @@ extern "C" int lr2_xattn_bwd(const void* Q, const void* K, const void* V, const 
   const size_t lds = sizeof(float) * ((size_t)2 * MAX_LK * MAX_HD + 2 * 256 * MAX_LK + 2 * 2 * MAX_LK * (MAX_HD + 1));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)xattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lr2_allow_dynamic_lds(xattn_bwd_kernel, lds, "xattn_bwd")) return LR2_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(xattn_bwd_kernel, dim3(batch * heads), dim3(256), lds, (hipStream_t)stream, (const float*)Q,
+  LR2_LAUNCH(xattn_bwd_kernel, dim3(batch * heads), dim3(256), lds, (hipStream_t)stream, (const float*)Q,
                      (const float*)K, (const float*)V, (const float*)dO, (float*)dQ, (float*)dK, (float*)dV, heads, Lq,
                      Lk, head_dim, post_scale);
-  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+  return lr2_launch_status(__func__);
 }
 
 extern "C" int lr2_self_attn_fwd(const void* Q, const void* K, const void* V, const int64_t* seg, void* O, int batch,
@@ -286,10 +286,10 @@ extern "C" int lr2_self_attn_fwd(const void* Q, const void* K, const void* V, co
   const size_t lds = ((size_t)2 * L * SA_HD + L) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)self_attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lr2_allow_dynamic_lds(self_attn_fwd_kernel, 160 * 1024, "self_attn_fwd")) return LR2_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(self_attn_fwd_kernel, dim3(batch * heads), dim3(256), lds, (hipStream_t)stream, (const float*)Q,
+  LR2_LAUNCH(self_attn_fwd_kernel, dim3(batch * heads), dim3(256), lds, (hipStream_t)stream, (const float*)Q,
                      (const float*)K, (const float*)V, seg, (float*)O, heads, L, scale);
-  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+  return lr2_launch_status(__func__);
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits in HBM / LDS
 
@@ -102,4 +103,35 @@ __device__ __forceinline__ void epilogue_apply(const Epilogue& e, float acc, int
   float* p = e.out + (size_t)m * e.ld_out + n;
   if (e.accumulate) v += *p;
   *p = v;
+}
+
+// hipGetLastError() reports the calling thread's most recent error from ANY runtime call, including benign ones
+// made by the host framework (hipErrorNotReady from event queries).  Clear the slot before a launch so that the
+// check after it reports this launch only.
+#define LR2_LAUNCH(...)        \
+  do {                         \
+    (void)hipGetLastError();   \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
+// 0 when the preceding launch was accepted, LR2_ERR_LAUNCH (-3) otherwise (the HIP error string goes to stderr).
+static inline int lr2_launch_status(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  fprintf(stderr, "lr2ppo_hip: %s: %s\n", what, hipGetErrorString(e));
+  return -3;
+}
+// Raise a kernel's dynamic-LDS limit.  hipFuncGetAttributes first: it forces the lazily loaded code object in,
+// without which hipFuncSetAttribute can fail when this is the first kernel the process touches.
+template <typename K>
+static inline int lr2_allow_dynamic_lds(K kern, size_t bytes, const char* what) {
+  hipFuncAttributes fa;
+  (void)hipFuncGetAttributes(&fa, (const void*)kern);
+  const hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  (void)hipGetLastError();
+  if (e != hipSuccess) {
+    fprintf(stderr, "lr2ppo_hip: %s: hipFuncSetAttribute(%zu B LDS): %s\n", what, bytes, hipGetErrorString(e));
+    return -3;
+  }
+  return 0;
 }

@@ -270,11 +270,11 @@ int launch(const GemmParams& p, int splits, hipStream_t stream) {
   auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, PASSES>;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lr2_allow_dynamic_lds(kern, lds, "gemm")) return LR2_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(NTHREADS), lds, stream, p);
-  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+  LR2_LAUNCH(kern, grid, dim3(NTHREADS), lds, stream, p);
+  return lr2_launch_status(__func__);
 }
 
 template <bool TA, bool TB>
@@ -351,8 +351,8 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
     const size_t total = (size_t)M * N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)splitk_ws, splits, M, N, p.epi);
-    if (hipGetLastError() != hipSuccess) return LR2_ERR_LAUNCH;
+    LR2_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)splitk_ws, splits, M, N, p.epi);
+    if (lr2_launch_status(__func__)) return LR2_ERR_LAUNCH;
   }
   return 0;
 }

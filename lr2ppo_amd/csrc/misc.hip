@@ -368,7 +368,7 @@ inline int grid_for(size_t work_items, int cap = 4096) {
   if (b > (size_t)cap) b = cap;
   return (int)b;
 }
-#define CHECK_LAUNCH() return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH
+#define CHECK_LAUNCH() return lr2_launch_status(__func__)
 
 }  // namespace
 
@@ -392,7 +392,7 @@ extern "C" int lr2_gather_rows(const void* src, const int64_t* index, void* dst,
   if (!src || !dst || B <= 0 || t_in <= 0 || t_out <= 0) return LR2_ERR_ARG;
   if (row_elems % 4 || src_bstride % 4 || src_tstride % 4) return LR2_ERR_SHAPE;
   dim3 grid(grid_for(row_elems / 4, 64), B * t_out);
-  hipLaunchKernelGGL(gather_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, index, (float*)dst,
+  LR2_LAUNCH(gather_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)src, index, (float*)dst,
                      t_in, t_out, row_elems, src_bstride, src_tstride);
   CHECK_LAUNCH();
 }
@@ -402,7 +402,7 @@ extern "C" int lr2_gather_rows_bwd(const void* ddst, const int64_t* index, void*
   if (!ddst || !dsrc || B <= 0 || t_in <= 0 || t_out <= 0) return LR2_ERR_ARG;
   if (row_elems % 4) return LR2_ERR_SHAPE;
   dim3 grid(grid_for(row_elems / 4, 64), B * t_in);
-  hipLaunchKernelGGL(gather_rows_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)ddst, index,
+  LR2_LAUNCH(gather_rows_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)ddst, index,
                      (float*)dsrc, t_in, t_out, row_elems);
   CHECK_LAUNCH();
 }
@@ -411,7 +411,7 @@ extern "C" int lr2_copy_rows(const void* src, void* dst, int rows, int D, int gr
                              uint64_t dst_off, void* stream) {
   if (!src || !dst || rows <= 0 || D <= 0 || group <= 0) return LR2_ERR_ARG;
   if (D % 4 || dst_gstride % 4 || dst_off % 4) return LR2_ERR_SHAPE;
-  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((size_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream,
+  LR2_LAUNCH(copy_rows_kernel, dim3(grid_for((size_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)src, (float*)dst, rows, D, group, dst_gstride, dst_off);
   CHECK_LAUNCH();
 }
@@ -420,7 +420,7 @@ extern "C" int lr2_head_fwd(const void* x, const void* w, const void* b, void* y
                             int row_off, void* stream) {
   if (!x || !w || !b || !y || rows <= 0 || row_step <= 0) return LR2_ERR_ARG;
   if (D % 4) return LR2_ERR_SHAPE;
-  hipLaunchKernelGGL(head_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+  LR2_LAUNCH(head_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x,
                      (const float*)w, (const float*)b, (float*)y, rows, D, row_step, row_off);
   CHECK_LAUNCH();
 }
@@ -431,12 +431,12 @@ extern "C" int lr2_head_bwd(const void* x, const void* w, const void* dy, void* 
   if (D % 4) return LR2_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
   if (dx) {
-    hipLaunchKernelGGL(head_bwd_dx_kernel, dim3(grid_for((size_t)total_rows * D / 4)), dim3(256), 0, s, (const float*)w,
+    LR2_LAUNCH(head_bwd_dx_kernel, dim3(grid_for((size_t)total_rows * D / 4)), dim3(256), 0, s, (const float*)w,
                        (const float*)dy, (float*)dx, D, row_step, row_off, total_rows);
-    if (hipGetLastError() != hipSuccess) return LR2_ERR_LAUNCH;
+    if (lr2_launch_status(__func__)) return LR2_ERR_LAUNCH;
   }
   if (dw && db) {
-    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((D + 255) / 256), dim3(256), 0, s, (const float*)x, (const float*)dy,
+    LR2_LAUNCH(head_bwd_dw_kernel, dim3((D + 255) / 256), dim3(256), 0, s, (const float*)x, (const float*)dy,
                        (float*)dw, (float*)db, rows, D, row_step, row_off);
   }
   CHECK_LAUNCH();
@@ -446,14 +446,14 @@ extern "C" int lr2_add_period_rows(const void* x, const void* table, void* out, 
                                    void* stream) {
   if (!x || !table || !out || rows <= 0 || period <= 0) return LR2_ERR_ARG;
   if (D % 4) return LR2_ERR_SHAPE;
-  hipLaunchKernelGGL(add_period_rows_kernel, dim3(grid_for((size_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream,
+  LR2_LAUNCH(add_period_rows_kernel, dim3(grid_for((size_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)x, (const float*)table, (float*)out, rows, D, period);
   CHECK_LAUNCH();
 }
 
 extern "C" int lr2_period_rows_grad(const void* dy, void* dtable, int rows, int D, int period, void* stream) {
   if (!dy || !dtable || rows <= 0 || period <= 0) return LR2_ERR_ARG;
-  hipLaunchKernelGGL(period_rows_grad_kernel, dim3((period * D + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  LR2_LAUNCH(period_rows_grad_kernel, dim3((period * D + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      (const float*)dy, (float*)dtable, rows, D, period);
   CHECK_LAUNCH();
 }
@@ -467,7 +467,7 @@ extern "C" int lr2_ppo_loss(const void* scores, const void* old_scores, const vo
     return LR2_ERR_ARG;
   if (B < 1 || B > 1024 || T < 1 || T > PPO_MAX_T || rank_len < 1 || rank_len > T || ns_len < rank_len) return LR2_ERR_SHAPE;
   const int threads = ((B + 63) / 64) * 64;
-  hipLaunchKernelGGL(ppo_loss_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, (const float*)scores,
+  LR2_LAUNCH(ppo_loss_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, (const float*)scores,
                      (const float*)old_scores, (const float*)rewards, (const float*)old_value, (const float*)value,
                      next_state, ns_len, rank_len, B, T, kl_w, ent_w, value_clip, margin, adv_eps, (float*)scalars,
                      (float*)per_item, (float*)dscores, (float*)dvalue);
@@ -477,7 +477,7 @@ extern "C" int lr2_ppo_loss(const void* scores, const void* old_scores, const vo
 extern "C" int lr2_smooth_l1(const void* pred, const void* target, int n, float beta, void* loss, void* dpred,
                              void* stream) {
   if (!pred || !target || !loss || n <= 0 || beta <= 0.f) return LR2_ERR_ARG;
-  hipLaunchKernelGGL(smooth_l1_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)pred,
+  LR2_LAUNCH(smooth_l1_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)pred,
                      (const float*)target, n, beta, (float*)loss, (float*)dpred);
   CHECK_LAUNCH();
 }
@@ -487,7 +487,7 @@ extern "C" int lr2_adamw_multi(const lr2_adamw_chunk* table_dev, int n_chunks, d
   static_assert(sizeof(lr2_adamw_chunk) == sizeof(AdamChunk), "chunk layout");
   if (!table_dev || n_chunks <= 0) return LR2_ERR_ARG;
   // (1 - beta) is formed in double like the reference's Python scalars, then rounded once to fp32
-  hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)table_dev,
+  LR2_LAUNCH(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)table_dev,
                      (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
   CHECK_LAUNCH();
 }
@@ -496,7 +496,7 @@ extern "C" int lr2_text_embed(const int64_t* src, const int64_t* seg, const void
                               const void* seg_table, void* out, int rows, int L, int D, void* stream) {
   if (!src || !seg || !word || !pos || !seg_table || !out || rows <= 0 || L <= 0) return LR2_ERR_ARG;
   if (D % 4) return LR2_ERR_SHAPE;
-  hipLaunchKernelGGL(text_embed_kernel, dim3(grid_for((size_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream, src,
+  LR2_LAUNCH(text_embed_kernel, dim3(grid_for((size_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream, src,
                      seg, (const float*)word, (const float*)pos, (const float*)seg_table, (float*)out, rows, L, D);
   CHECK_LAUNCH();
 }
@@ -504,7 +504,7 @@ extern "C" int lr2_text_embed(const int64_t* src, const int64_t* seg, const void
 extern "C" int lr2_patchify(const void* img, void* out, int B, int C, int H, int W, int ps, void* stream) {
   if (!img || !out || B <= 0 || C <= 0 || ps <= 0) return LR2_ERR_ARG;
   if (H % ps || W % ps) return LR2_ERR_SHAPE;
-  hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream,
+  LR2_LAUNCH(patchify_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)img, (float*)out, B, C, H, W, ps);
   CHECK_LAUNCH();
 }
@@ -513,7 +513,7 @@ extern "C" int lr2_vit_assemble(const void* patch_proj, const void* cls, const v
                                 void* stream) {
   if (!patch_proj || !cls || !pos || !out || B <= 0 || P <= 0) return LR2_ERR_ARG;
   if (D % 4) return LR2_ERR_SHAPE;
-  hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for((size_t)B * (P + 1) * D / 4)), dim3(256), 0, (hipStream_t)stream,
+  LR2_LAUNCH(vit_assemble_kernel, dim3(grid_for((size_t)B * (P + 1) * D / 4)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)patch_proj, (const float*)cls, (const float*)pos, (float*)out, B, P, D);
   CHECK_LAUNCH();
 }

@@ -185,10 +185,10 @@ extern "C" int lr2_layernorm_fwd(const void* x, const void* gamma, const void* b
   if (!x || !gamma || !beta || !out || rows <= 0) return LR2_ERR_ARG;
   if (D % 4 != 0 || D > MAXV * 256 || D < 4) return LR2_ERR_SHAPE;
   if (group <= 0) { group = rows; group_stride = 0; }
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+  LR2_LAUNCH(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x,
                      (const float*)gamma, (const float*)beta, (float*)out, (float*)mean, (float*)rstd, rows, D, eps,
                      mode, group, group_stride);
-  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+  return lr2_launch_status(__func__);
 }
 
 extern "C" int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_stride, const void* x, const void* gamma,
@@ -207,18 +207,18 @@ extern "C" int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_strid
     thr = dropout_threshold(drop_p);
     key = (((uint64_t)drop_site) << 40) ^ (drop_seed * 0x9E3779B97F4A7C15ull);
   }
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, group,
+  LR2_LAUNCH(layernorm_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, group,
                      group_stride, (const float*)x, (const float*)gamma, (const float*)mean, (const float*)rstd,
                      (const float*)resid_grad, (float*)dx, (float*)dx_masked, scale, thr, key, (float*)partials, rows, D);
-  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+  return lr2_launch_status(__func__);
 }
 
 extern "C" int lr2_colsum_partials_finish(const void* partials, int nblocks, int cols, int ld, void* out, int accumulate,
                                           void* stream) {
   if (!partials || !out || nblocks <= 0 || cols <= 0) return LR2_ERR_ARG;
-  hipLaunchKernelGGL(partials_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  LR2_LAUNCH(partials_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                      (const float*)partials, nblocks, cols, ld, (float*)out, accumulate);
-  return hipGetLastError() == hipSuccess ? 0 : LR2_ERR_LAUNCH;
+  return lr2_launch_status(__func__);
 }
 
 extern "C" int lr2_colsum(const void* x, int rows, int cols, int ld, void* partials, int nblocks, void* out,
@@ -227,8 +227,8 @@ extern "C" int lr2_colsum(const void* x, int rows, int cols, int ld, void* parti
   if (cols % 4 != 0 || ld % 4 != 0) return LR2_ERR_SHAPE;
   if (nblocks > rows) nblocks = rows;
   dim3 grid((cols + 1023) / 1024, nblocks);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, cols, ld,
+  LR2_LAUNCH(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, cols, ld,
                      (float*)partials);
-  if (hipGetLastError() != hipSuccess) return LR2_ERR_LAUNCH;
+  if (lr2_launch_status(__func__)) return LR2_ERR_LAUNCH;
   return lr2_colsum_partials_finish(partials, nblocks, cols, cols, out, 0, stream);
 }

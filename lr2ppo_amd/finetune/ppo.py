@@ -514,44 +514,50 @@ class _DataParallel:
         dist.all_reduce(flat)
 
 
+def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
+    """The body of one train_model iteration (finetune/ppo.py:518-598) on one stored rollout record:
+    actor + critic train forwards, fused PPO loss, actor backward + AdamW, critic backward + AdamW.
+    Returns the 10 logged metrics of this minibatch as a device tensor (no host sync)."""
+    state, next_state, old_scores, rewards, old_value, text, img, tgts = record
+    dev = text.device
+    dp = dp or _DataParallel()
+    actor, critic = model.actor, model.critic
+    bs, tags = old_scores.shape[:2]
+    scal, per = torch.empty(4, device=dev), torch.empty(4, bs, device=dev)
+    dscores, dvalue = torch.empty(bs, tags, device=dev), torch.empty(bs, device=dev)
+    logits = actor.engine_forward(text, img, save=True)
+    value = critic.engine_forward(text, img, state, save=True)
+    ops.ppo_loss(logits.view(bs, tags), old_scores.contiguous(), rewards.contiguous(), old_value.contiguous(), value,
+                 next_state.contiguous(), scal, per, dscores, dvalue, B=bs, T=tags, kl_w=args.kl_div_loss_weight,
+                 ent_w=args.entropy_weight, value_clip=args.value_clip, margin=0.01, adv_eps=-0.1)
+    actor.engine_backward(dscores)
+    dp.reduce(actor)
+    optimizer.step()
+    critic.engine_backward(dvalue)
+    dp.reduce(critic)
+    critic_optim.step()
+    pm = per.mean(dim=1)
+    metrics = torch.stack([scal[0], scal[1], pm[0], old_value.mean(), value.mean(), rewards.mean(), pm[2], pm[3], scal[2],
+                           pm[1]])
+    if dp.world > 1:           # the reference's 10 logging all-reduces (ppo.py:589-598), packed into one
+        metrics.div_(dp.world)
+        dist.all_reduce(metrics)
+    return metrics
+
+
 def train_model(args, model, optimizer, critic_optim, scheduler, critic_scheduler, memories, epoch):
     """One PPO update cycle over the stored rollouts; returns the reference's 10 averaged metrics
     [policy, value, kl, old_value, value, rewards_ori, rewards, advantages, rank_loss, entropy] (ppo.py:615-617)."""
     dev = next(model.parameters()).device
     dp = _DataParallel()
-    actor, critic = model.actor, model.critic
-    actor.bind_grads()
-    critic.bind_grads()
+    model.actor.bind_grads()
+    model.critic.bind_grads()
     total = torch.zeros(10, device=dev)
-    metrics = torch.empty(10, device=dev)
-    n_done = 0
-    for (state, next_state, old_scores, rewards, old_value, text, img, tgts) in memories:
-        bs, tags = old_scores.shape[:2]
-        scal, per = torch.empty(4, device=dev), torch.empty(4, bs, device=dev)
-        dscores, dvalue = torch.empty(bs, tags, device=dev), torch.empty(bs, device=dev)
-        logits = actor.engine_forward(text, img, save=True)
-        value = critic.engine_forward(text, img, state, save=True)
-        ops.ppo_loss(logits.view(bs, tags), old_scores.contiguous(), rewards.contiguous(), old_value.contiguous(), value,
-                     next_state.contiguous(), scal, per, dscores, dvalue, B=bs, T=tags, kl_w=args.kl_div_loss_weight,
-                     ent_w=args.entropy_weight, value_clip=args.value_clip, margin=0.01, adv_eps=-0.1)
-        actor.engine_backward(dscores)
-        dp.reduce(actor)
-        optimizer.step()
-        critic.engine_backward(dvalue)
-        dp.reduce(critic)
-        critic_optim.step()
-        pm = per.mean(dim=1)
-        metrics[0], metrics[1], metrics[2], metrics[3] = scal[0], scal[1], pm[0], old_value.mean()
-        metrics[4], metrics[5], metrics[6], metrics[7] = value.mean(), rewards.mean(), pm[2], pm[3]
-        metrics[8], metrics[9] = scal[2], pm[1]
-        if dp.world > 1:           # the reference's 10 logging all-reduces (ppo.py:589-598), packed into one
-            metrics.div_(dp.world)
-            dist.all_reduce(metrics)
-        total += metrics
-        n_done += 1
+    for record in memories:
+        total += update_minibatch(args, model, optimizer, critic_optim, record, dp)
     scheduler.step()
     critic_scheduler.step()
-    out = (total / max(n_done, 1)).tolist()
+    out = (total / max(len(memories), 1)).tolist()
     if any(v != v for v in out):
         raise FloatingPointError("NaN in PPO metrics (the reference drops into pdb here, finetune/ppo.py:576-578)")
     return out

@@ -27,6 +27,49 @@ def get_gemm_passes() -> int:
     return _PASSES
 
 
+# ---- optional per-launch timing (bench.py): HIP events on the launch stream around selected entry points ----
+_PROF = None
+
+
+def profile_start():
+    """Start collecting (start, end) HIP events per kernel signature; see profile_stop()."""
+    global _PROF
+    _PROF = {}
+
+
+def profile_stop():
+    """-> {key: {"ms": total, "n": launches, "flops": per-launch, "bytes": per-launch}} (synchronises)."""
+    global _PROF
+    prof, _PROF = _PROF, None
+    torch.cuda.synchronize()
+    out = {}
+    for key, rec in (prof or {}).items():
+        ms = sum(s.elapsed_time(e) for s, e in rec["ev"])
+        out[key] = {"ms": ms, "n": len(rec["ev"]), "flops": rec["flops"], "bytes": rec["bytes"]}
+    return out
+
+
+class _Timed:
+    __slots__ = ("key", "flops", "bytes", "s")
+
+    def __init__(self, key, flops=0, nbytes=0):
+        self.key, self.flops, self.bytes = key, flops, nbytes
+
+    def __enter__(self):
+        if _PROF is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _PROF is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            rec = _PROF.setdefault(self.key, {"ev": [], "flops": self.flops, "bytes": self.bytes})
+            rec["ev"].append((self.s, e))
+        return False
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -92,8 +135,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
     if drop is not None and drop.p > 0.0:
         e.drop_p, e.drop_seed, e.drop_site = drop.p, drop.seed, drop.site
     a_bytes, b_bytes = a.numel() * 4, b.numel() * 4
-    rc = _nat.lib().lr2_gemm(a.data_ptr(), b.data_ptr(), M, N, K, lda, ldb, 1 if trans_a else 0, 1 if trans_b else 0,
-                          a_bytes, b_bytes, C.byref(e), _ptr(splitk_ws), sp, bm, passes or _PASSES, _stream())
+    form = "TN" if trans_a else ("NN" if trans_b else "NT")
+    with _Timed(f"gemm_{form}_M{M}_N{N}_K{K}", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)):
+        rc = _nat.lib().lr2_gemm(a.data_ptr(), b.data_ptr(), M, N, K, lda, ldb, 1 if trans_a else 0, 1 if trans_b else 0,
+                                 a_bytes, b_bytes, C.byref(e), _ptr(splitk_ws), sp, bm, passes or _PASSES, _stream())
     _nat.check(rc, f"lr2_gemm(M={M},N={N},K={K},ta={trans_a},tb={trans_b})")
     return out
 
@@ -229,8 +274,11 @@ def smooth_l1(pred, target, loss, dpred=None, *, n, beta=0.3):
     return loss
 
 
-def adamw_multi(table_dev: torch.Tensor, n_chunks: int, lr: float, beta1: float, beta2: float, eps: float):
-    _nat.check(_nat.lib().lr2_adamw_multi(table_dev.data_ptr(), n_chunks, lr, beta1, beta2, eps, _stream()), "lr2_adamw_multi")
+def adamw_multi(table_dev: torch.Tensor, n_chunks: int, lr: float, beta1: float, beta2: float, eps: float,
+                n_params: int = 0):
+    with _Timed(f"adamw_{n_params}", 0.0, 28.0 * n_params):
+        _nat.check(_nat.lib().lr2_adamw_multi(table_dev.data_ptr(), n_chunks, lr, beta1, beta2, eps, _stream()),
+                   "lr2_adamw_multi")
 
 
 def text_embed(src, seg, word, pos, seg_table, out, *, rows, L, D):

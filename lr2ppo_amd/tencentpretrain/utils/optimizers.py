@@ -67,7 +67,7 @@ class AdamW(Optimizer):
             arr[i].p, arr[i].g, arr[i].m, arr[i].v, arr[i].count, arr[i].weight_decay = a, b, c_, d, cnt, wd
         dev = ps[0].device
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
-        self._tables[gi] = (sig, table, len(rows))
+        self._tables[gi] = (sig, table, len(rows), sum(p.numel() for p in ps))
         return table, len(rows), ps
 
     @torch.no_grad()
@@ -90,7 +90,7 @@ class AdamW(Optimizer):
                 if group["weight_decay"] > 0.0 and step_size != group["lr"]:
                     # decay must use the raw lr (optimizers.py:399-400): run the decay-free update, then decay
                     raise NotImplementedError("correct_bias=True with weight decay is not used by LR2PPO")
-            ops.adamw_multi(table, n, step_size, beta1, beta2, group["eps"])
+            ops.adamw_multi(table, n, step_size, beta1, beta2, group["eps"], n_params=self._tables[gi][3])
         return loss
 
 
