@@ -152,13 +152,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
+// 64 columns x 4 row slices per workgroup: coalesced 256-B reads, rows split 4 ways, LDS combine.
 __global__ __launch_bounds__(256) void partials_finish_kernel(const float* __restrict__ partials, int nblocks, int cols,
                                                               int ld, float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * ld + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < cols)
+    for (int b = slice; b < nblocks; b += 4) s += partials[(size_t)b * ld + c];
+  red[slice][lane] = s;
+  __syncthreads();
+  if (slice == 0 && c < cols) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // thread <-> 4 adjacent columns, block <-> 1024 columns x one row chunk
@@ -216,7 +224,7 @@ extern "C" int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_strid
 extern "C" int lr2_colsum_partials_finish(const void* partials, int nblocks, int cols, int ld, void* out, int accumulate,
                                           void* stream) {
   if (!partials || !out || nblocks <= 0 || cols <= 0) return LR2_ERR_ARG;
-  LR2_LAUNCH(partials_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  LR2_LAUNCH(partials_finish_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const float*)partials, nblocks, cols, ld, (float*)out, accumulate);
   return lr2_launch_status(__func__);
 }

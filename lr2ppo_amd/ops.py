@@ -95,14 +95,25 @@ class Drop:
 
 
 def choose_tiling(M: int, N: int, K: int, trans_a: bool):
-    """(block_m, splits): fill the 256 CUs (>= ~2 workgroups each) using split-K for skinny GEMMs."""
+    """(block_m, splits).  256 CUs hold 2 (BM=128) or 3 (BM=64) workgroups each; pick the split-K factor that minimises
+    rounds x (K-tiles per workgroup + fixed prologue/epilogue cost) + the cost of writing/reading the partial slabs, so
+    that skinny GEMMs fill the chip without wave-quantisation tails (576 workgroups on 512 slots = 2 rounds)."""
     bm = 64 if (M <= 64 and not trans_a) else 128
     tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
     k_tiles = (K + 63) // 64
-    splits = 1
-    if tiles < 256 and k_tiles >= 8:
-        splits = min(max(1, k_tiles // 4), (512 + tiles - 1) // tiles)
-    return bm, splits
+    slots = 768 if bm == 64 else 512
+    if tiles >= slots or k_tiles < 8:
+        return bm, 1
+    slab_cost = M * N * 6.4e-7            # one fp32 slab written + read, in units of one K-tile step (~2.5 us)
+    best, best_cost = 1, None
+    for s in range(1, min(k_tiles // 2, 64) + 1):
+        per = -(-k_tiles // s)
+        s_eff = -(-k_tiles // per)
+        rounds = -(-(tiles * s_eff) // slots)
+        cost = rounds * (per + 3.0) + (s_eff * slab_cost if s_eff > 1 else 0.0)
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = s_eff, cost
+    return bm, best
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, trans_a=False, trans_b=False,

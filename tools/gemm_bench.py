@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of lr2_gemm on the shapes of the LR2PPO head (run on the GPU box).
+usage: python tools/gemm_bench.py [--passes 3] [--iters 20]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from lr2ppo_amd import ops  # noqa: E402
+
+SHAPES = [  # (form, M, N, K) as ops.gemm sees them
+    ("NT", 12544, 3072, 768), ("NT", 12544, 768, 3072), ("NT", 12544, 768, 768), ("NN", 12544, 768, 3072),
+    ("NN", 12544, 3072, 768), ("TN", 3072, 768, 12544), ("TN", 768, 3072, 12544), ("TN", 768, 768, 12544),
+    ("NT", 64, 3072, 162816), ("NN", 64, 162816, 3072), ("TN", 3072, 162816, 64), ("NT", 1024, 3072, 768),
+    ("NT", 4096, 4096, 4096),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--passes", type=int, default=3)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    for form, M, N, K in SHAPES:
+        ta, tb = form == "TN", form in ("NN", "TN")
+        A = torch.randn((K, M) if ta else (M, K), device=dev, generator=g)
+        B = torch.randn((K, N) if tb else (N, K), device=dev, generator=g)
+        out = torch.empty(M, N, device=dev)
+        bm, sp = ops.choose_tiling(M, N, K, ta)
+        ws = torch.empty(max(1, sp) * M * N, device=dev) if sp > 1 else None
+        for _ in range(3):
+            ops.gemm(A, B, out, M, N, K, trans_a=ta, trans_b=tb, splitk_ws=ws, passes=a.passes)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(a.iters):
+            ops.gemm(A, B, out, M, N, K, trans_a=ta, trans_b=tb, splitk_ws=ws, passes=a.passes)
+        e.record()
+        torch.cuda.synchronize()
+        ms = s.elapsed_time(e) / a.iters
+        tf = 2.0 * M * N * K / ms / 1e9
+        gbs = 4.0 * (M * K + N * K + M * N) / ms / 1e6
+        print(f"{form} M={M:6d} N={N:6d} K={K:6d} bm={bm} splits={sp:2d}: {ms:8.4f} ms  {tf:7.1f} TFLOP/s  {gbs:7.0f} GB/s(alg)", flush=True)
+        del A, B, out, ws
+
+
+if __name__ == "__main__":
+    main()
