@@ -23,6 +23,8 @@
 // multiplied.  K-contiguous operands are read with ds_read_b128; contraction-strided operands keep their
 // HBM orientation in LDS and are read with ds_read_b64_tr_b16 (hardware transpose), so no operand is
 // ever transposed in HBM.
+#include <stdlib.h>
+
 #include "common.h"
 #include "lr2ppo_hip.h"
 
@@ -40,6 +42,7 @@ struct GemmParams {
   int k_tiles_per_split;      // in units of BK
   int tiles_m, tiles_n;       // output tile grid
   float* partial;             // split-K workspace [splits][M][N] or nullptr
+  int ablate;                 // diagnostics only (LR2_GEMM_ABLATE): 1 no MFMA, 2 no global loads, 4 no convert/store, 8 no frag reads
   Epilogue epi;
 };
 
@@ -105,17 +108,21 @@ struct Stager {
       return (k * UPR + ((rg >> 1) ^ swz_tr<UPR>(k))) * 16 + (rg & 1) * 8;
     }
   }
+  // hi pair = v_cvt_pk_bf16_f32(x0, x1) is already in LDS element order; its two halves, widened back to fp32 by a
+  // shift / mask, give the residuals whose packed conversion is the lo pair: 6 VALU per pair, no repacking.
   __device__ __forceinline__ void store(char* tile_hi) {
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
       const float x0 = __uint_as_float(regs[q][0]), x1 = __uint_as_float(regs[q][1]);
       const float x2 = __uint_as_float(regs[q][2]), x3 = __uint_as_float(regs[q][3]);
-      const bf16_t h0 = f2bf(x0), h1 = f2bf(x1), h2 = f2bf(x2), h3 = f2bf(x3);
+      const uint32_t h01 = cvt_pk_bf16(x0, x1), h23 = cvt_pk_bf16(x2, x3);
       const int off = lds_offset(q);
-      u32x2_t hv = {(uint32_t)h0 | ((uint32_t)h1 << 16), (uint32_t)h2 | ((uint32_t)h3 << 16)};
+      u32x2_t hv = {h01, h23};
       *reinterpret_cast<u32x2_t*>(tile_hi + off) = hv;
       if (PASSES == 3) {
-        u32x2_t lv = {pack_bf2(x0 - bf2f(h0), x1 - bf2f(h1)), pack_bf2(x2 - bf2f(h2), x3 - bf2f(h3))};
+        const uint32_t l01 = cvt_pk_bf16(x0 - __uint_as_float(h01 << 16), x1 - __uint_as_float(h01 & 0xffff0000u));
+        const uint32_t l23 = cvt_pk_bf16(x2 - __uint_as_float(h23 << 16), x3 - __uint_as_float(h23 & 0xffff0000u));
+        u32x2_t lv = {l01, l23};
         *reinterpret_cast<u32x2_t*>(tile_hi + TILE_BYTES + off) = lv;
       }
     }
@@ -142,6 +149,18 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int rbase, int k
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+
+// per (ks, j) group: R reads that prefetch the next group (+ R0 for the A fragments of the second k-step in group 0),
+// then MF MFMAs
+template <int GRP, int NGRP, int R0, int R, int MF>
+__device__ __forceinline__ void pin_pipeline() {
+  if constexpr (GRP < NGRP) {
+    constexpr int reads = (GRP == 0 ? R0 : 0) + (GRP + 1 < NGRP ? R : 0);
+    if constexpr (reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, reads, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+    pin_pipeline<GRP + 1, NGRP, R0, R, MF>();
   }
 }
 
@@ -184,6 +203,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams g) {
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
+  if (g.ablate & 0xff00) {   // experiment: stagger co-resident workgroups
+    const int bit = (g.ablate >> 16) & 31;
+    if (((blockIdx.x >> 3) >> bit) & 1) {
+      const int n = (g.ablate >> 8) & 0xff;
+      for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   const int total_k_tiles = (g.K + BK - 1) / BK;
   const int kt_begin = blockIdx.z * g.k_tiles_per_split;
   int kt_end = kt_begin + g.k_tiles_per_split;
@@ -216,35 +242,71 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams g) {
 
   for (int t = 0; t < nt; ++t) {
     const bool more = (t + 1 < nt);
-    if (more) {  // tile t+1 travels HBM -> VGPR while tile t is multiplied
+    if (more && !(g.ablate & 2)) {  // tile t+1 travels HBM -> VGPR while tile t is multiplied
       sa.load(rsrc_a);
       sb.load(rsrc_b);
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t ah[MI], al[MI];
+    if (!(g.ablate & 8))
+    // Fragment reads run one MFMA group ahead of their use (register double buffering): the A fragments of k-step
+    // ks+1 and the next B fragment are requested before the 3*MI MFMAs of the current (ks, j) group are issued, so
+    // the ~100-cycle LDS latency hides under >= 12 MFMAs instead of stalling the wave at every group.
+    {
+      bf16x8_t ah[2][MI], al[2][MI], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        ah[i] = read_frag<BM, TA>(lds_a, wm0 + 16 * i, ks, lane);
-        if (PASSES == 3) al[i] = read_frag<BM, TA>(lds_a + A_TILE, wm0 + 16 * i, ks, lane);
+        ah[0][i] = read_frag<BM, TA>(lds_a, wm0 + 16 * i, 0, lane);
+        if (PASSES == 3) al[0][i] = read_frag<BM, TA>(lds_a + A_TILE, wm0 + 16 * i, 0, lane);
       }
+      bh[0] = read_frag<BN, TB>(lds_b, wn0, 0, lane);
+      if (PASSES == 3) bl[0] = read_frag<BN, TB>(lds_b + B_TILE, wn0, 0, lane);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const bf16x8_t bh = read_frag<BN, TB>(lds_b, wn0 + 16 * j, ks, lane);
-        if (PASSES == 3) {
-          const bf16x8_t bl = read_frag<BN, TB>(lds_b + B_TILE, wn0 + 16 * j, ks, lane);
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-          for (int i = 0; i < MI; ++i) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) {
+          const int cur = (ks * NI + j) & 1, nxt = cur ^ 1;
+          const int nj = (j + 1 < NI) ? j + 1 : 0, nks = (j + 1 < NI) ? ks : ks + 1;
+          if (nks < 2) {
+            bh[nxt] = read_frag<BN, TB>(lds_b, wn0 + 16 * nj, nks, lane);
+            if (PASSES == 3) bl[nxt] = read_frag<BN, TB>(lds_b + B_TILE, wn0 + 16 * nj, nks, lane);
           }
-        }
+          if (j == 0 && ks == 0) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+            for (int i = 0; i < MI; ++i) {
+              ah[1][i] = read_frag<BM, TA>(lds_a, wm0 + 16 * i, 1, lane);
+              if (PASSES == 3) al[1][i] = read_frag<BM, TA>(lds_a + A_TILE, wm0 + 16 * i, 1, lane);
+            }
+          }
+          if (g.ablate & 1) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+              asm volatile("" ::"v"(ah[ks][i]), "v"(bh[cur]));
+              if (PASSES == 3) asm volatile("" ::"v"(al[ks][i]), "v"(bl[cur]));
+            }
+            continue;
+          }
+          if (PASSES == 3) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks][i], bh[cur], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks][i], bl[cur], acc[i][j], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks][i], bh[cur], acc[i][j], 0, 0, 0);
+        }
       }
+      // pin the software pipeline in the emitted stream: [prologue reads] then, per (ks, j) group, the reads that
+      // prefetch the NEXT group followed by this group's MFMAs (hipcc otherwise sinks every read to its first use)
+      constexpr int NIMGS = PASSES == 3 ? 2 : 1;
+      constexpr int DS_READ = 0x100, MFMA = 0x008;
+      constexpr int RPF = TB ? 2 : 1, RPA = TA ? 2 : 1;      // LDS read instructions per fragment
+      __builtin_amdgcn_sched_group_barrier(DS_READ, (MI * RPA + RPF) * NIMGS, 0);
+      pin_pipeline<0, 2 * NI, MI * RPA * NIMGS, RPF * NIMGS, MI * PASSES>();
+      (void)MFMA;
     }
     __syncthreads();  // every wave is done reading tile t
-    if (more) {
+    if (more && !(g.ablate & 4)) {
       sa.store(lds_a);
       sb.store(lds_b);
     }
@@ -367,6 +429,14 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   splits = (total_k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
   p.partial = splits > 1 ? (float*)splitk_ws : nullptr;
   p.epi = to_device_epilogue(epi);
+  {
+    static int ablate = -1;
+    if (ablate < 0) {
+      const char* e = getenv("LR2_GEMM_ABLATE");
+      ablate = e ? atoi(e) : 0;
+    }
+    p.ablate = ablate;
+  }
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (!trans_a && !trans_b) rc = dispatch<false, false>(p, splits, block_m, passes, s);

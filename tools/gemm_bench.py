@@ -22,10 +22,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", type=int, nargs="*", default=None, help="indices into SHAPES")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
-    for form, M, N, K in SHAPES:
+    for si, (form, M, N, K) in enumerate(SHAPES):
+        if a.only is not None and si not in a.only:
+            continue
         ta, tb = form == "TN", form in ("NN", "TN")
         A = torch.randn((K, M) if ta else (M, K), device=dev, generator=g)
         B = torch.randn((K, N) if tb else (N, K), device=dev, generator=g)
