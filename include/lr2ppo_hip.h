@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 1
+#define LR2_ABI_VERSION 2
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -32,13 +32,16 @@ int lr2_device_info(char* name, int len);
 /* Fused GEMM epilogue, applied per element (m, n) in this order:
  *   v = acc*alpha (+bias[n]); act==1: z=v (stored to out_z if set), v=gelu_erf(v);
  *   drop_p>0: v = keep(seed,site,m*N+n) ? v/(1-p) : 0;  act==2: v *= gelu_erf'(aux_z[m,n]);
- *   resid: v += resid[m,n];  accumulate: v += out[m,n];  out[m,n] = v.   All pointers fp32. */
+ *   resid: v += resid[m,n];  accumulate: v += out[m,n];  out[m,n] = v (fp32) and/or (out_hi, out_lo)[m,n] = split(v). */
 typedef struct lr2_epilogue {
   const void* bias;   /* [N] or NULL */
   const void* resid;  /* [M, ld_resid] or NULL */
   const void* aux_z;  /* [M, ld_aux], required when act == 2 */
-  void* out;          /* [M, ld_out] */
+  void* out;          /* [M, ld_out] fp32 or NULL (then out_hi must be set) */
   void* out_z;        /* [M, ld_z] pre-activation (act == 1) or NULL */
+  void* out_hi;       /* bf16 hi plane [M, ld_planes] or NULL: result ALSO/INSTEAD written as split planes */
+  uint64_t out_lo_off; /* elements from the hi plane to the lo plane */
+  int32_t ld_planes;
   int32_t ld_resid, ld_aux, ld_out, ld_z;
   int32_t act;        /* 0 none, 1 GELU(erf), 2 multiply by GELU'(aux_z) */
   int32_t accumulate; /* 1: out += result */
@@ -57,14 +60,19 @@ typedef struct lr2_epilogue {
  * Supported forms: (0,0) forward, (0,1) input gradient, (1,1) weight gradient.
  * Constraints: K%64==0 unless both operands are strided (1,1); lda,ldb %4==0 (16-byte rows); buffers < 4 GiB.
  * M, N and (in the (1,1) form) K may be ragged.
- * a_bytes/b_bytes: bytes addressable from A/B (rows past the end read as zero: ragged M, ragged K in (1,1)).
+ * Operand formats: a_planes / b_planes = 0: fp32 matrix (split into bf16 hi+lo inside the kernel);
+ *   = 1: pre-split "planes" tensor: bf16 hi plane at the pointer, bf16 lo plane a_lo_off / b_lo_off BYTES later, both
+ *   with the matrix's row-major shape and leading dimension (elements); streamed by LDS-DMA, no conversion work.
+ *   Supported: (fp32, fp32), (planes, planes), (planes A, fp32 B).  Planes are produced by the epilogue's out_hi,
+ *   by lr2_split_planes(_multi) and by the LayerNorm / attention kernels' planes outputs.
+ * a_bytes/b_bytes: bytes addressable from A/B, per plane (rows past the end read as zero: ragged M, ragged K in (1,1)).
  * splits>1 uses split-K through splitk_ws (fp32 [splits][M][N]).  block_m: 128 or 64.
  * replaces: nn.Linear / F.linear + bias + nn.GELU + nn.Dropout + residual add in
  *   finetune/ppo.py:164-170 (Mlp), finetune/xit.py:103-110,118-122,147,
  *   tencentpretrain/layers/{multi_headed_attn.py:55-58,75, position_ffn.py:12-15} and their autograd backward. */
 int lr2_gemm(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int trans_a, int trans_b,
-             uint64_t a_bytes, uint64_t b_bytes, const lr2_epilogue* epi, void* splitk_ws, int splits, int block_m,
-             int passes, void* stream);
+             uint64_t a_bytes, uint64_t b_bytes, int a_planes, uint64_t a_lo_off, int b_planes, uint64_t b_lo_off,
+             const lr2_epilogue* epi, void* splitk_ws, int splits, int block_m, int passes, void* stream);
 
 /* Row gather: dst[b, j, :] = src[b, index[b, j], :]  (rows of row_elems fp32; strides in elements).
  * replaces: text_emb[batch_index, index] / img_emb[batch_index, index] (finetune/ppo.py:268-271,321-324). */
@@ -74,43 +82,61 @@ int lr2_gather_rows(const void* src, const int64_t* index, void* dst, int B, int
 int lr2_gather_rows_bwd(const void* ddst, const int64_t* index, void* dsrc, int B, int t_in, int t_out,
                         uint64_t row_elems, void* stream);
 /* Strided row copy: dst[(r / group)*dst_gstride + (r % group)*D + dst_off + c] = src[r*D + c].
+ * dst_planes=1: dst is a bf16 planes tensor (same element offsets, lo plane dst_lo_off elements later).
  * replaces: torch.cat([x, img_feature], dim=1) (finetune/ppo.py:224). */
-int lr2_copy_rows(const void* src, void* dst, int rows, int D, int group, uint64_t dst_gstride, uint64_t dst_off,
-                  void* stream);
+int lr2_copy_rows(const void* src, void* dst, int dst_planes, uint64_t dst_lo_off, int rows, int D, int group,
+                  uint64_t dst_gstride, uint64_t dst_off, void* stream);
+/* fp32 -> bf16 planes: dst_hi[i] = bf16(src[i]), dst_hi[lo_off + i] = bf16(src[i] - hi) for i < n (n % 4 == 0). */
+int lr2_split_planes(const void* src, void* dst_hi, uint64_t lo_off, uint64_t n, void* stream);
+/* The same for many tensors in one launch (weights after an optimizer step). table: DEVICE array of chunks. */
+typedef struct lr2_split_chunk {
+  const void* src;
+  void* dst_hi;
+  uint64_t lo_off; /* elements */
+  uint64_t count;  /* elements, multiple of 4 */
+} lr2_split_chunk;
+int lr2_split_planes_multi(const lr2_split_chunk* table_dev, int n_chunks, void* stream);
 
 /* LayerNorm forward over rows of length D (D%4==0, D<=1024).
  *   mode 0: nn.LayerNorm (biased variance, eps inside sqrt)      -- finetune/xit.py:37,74,93-94
  *   mode 1: TencentPretrain LayerNorm gamma*(x-mu)/(std_unbiased+eps)+beta -- tencentpretrain/layers/layer_norm.py:16-21
  * Output row r is written at out + (r / group)*group_stride + (r % group)*D (group<=0: dense), which lets the
  * final XiT LayerNorm write straight into the concat buffer of finetune/ppo.py:224.
+ * out (fp32) and/or out_hi (bf16 planes, lo plane out_lo_off elements later, same row mapping) receive the result.
  * mean/rstd (fp32 [rows]) may be NULL when no backward is needed. */
-int lr2_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* out, void* mean, void* rstd, int rows,
-                      int D, float eps, int mode, int group, uint64_t group_stride, void* stream);
+int lr2_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* out, void* out_hi, uint64_t out_lo_off,
+                      void* mean, void* rstd, int rows, int D, float eps, int mode, int group, uint64_t group_stride,
+                      void* stream);
 
 /* LayerNorm backward (mode 0).  dy uses the same (group, stride) row mapping as the forward output.
- * dx = LN'(dy) (+ resid_grad) -> dx (fp32); optional dx_masked = dropout_mask(dx)/(1-p) (the gradient of
- * y = dropout(a) + res with respect to a, finetune/xit.py:34,40).  dgamma/dbeta are accumulated per block
+ * dx = LN'(dy) (+ resid_grad) -> dx (fp32); optional dxm_hi = bf16 planes of dropout_mask(dx)/(1-p) (the gradient of
+ * y = dropout(a) + res with respect to a, finetune/xit.py:34,40; p = 0: planes of dx), the next GEMMs' operand.  dgamma/dbeta are accumulated per block
  * into partials [nblocks][2][D]; finish with lr2_colsum_partials_finish.
  * replaces: autograd of nn.LayerNorm + the in-place residual adds of finetune/xit.py:45-55,77-86. */
 int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_stride, const void* x, const void* gamma,
-                      const void* mean, const void* rstd, const void* resid_grad, void* dx, void* dx_masked,
-                      float drop_p, uint64_t drop_seed, uint32_t drop_site, void* partials, int nblocks, int rows,
-                      int D, void* stream);
+                      const void* mean, const void* rstd, const void* resid_grad, void* dx, void* dxm_hi,
+                      uint64_t dxm_lo_off, float drop_p, uint64_t drop_seed, uint32_t drop_site, void* partials,
+                      int nblocks, int rows, int D, void* stream);
 /* out[c] = sum_b partials[b*ld + c] for c < cols (deterministic second stage of column reductions). */
 int lr2_colsum_partials_finish(const void* partials, int nblocks, int cols, int ld, void* out, int accumulate,
                                void* stream);
-/* Column sums of a fp32 [rows, cols] matrix -> [cols] (bias gradients); partials: workspace [nblocks][cols].
+/* Column sums of a [rows, cols] matrix (fp32, or bf16 planes with the lo plane lo_off elements after the hi plane)
+ * -> fp32 [cols] (bias gradients); partials: workspace [nblocks][cols].
  * replaces: autograd of the nn.Linear bias add. */
-int lr2_colsum(const void* x, int rows, int cols, int ld, void* partials, int nblocks, void* out, void* stream);
+int lr2_colsum(const void* x, int is_planes, uint64_t lo_off, int rows, int cols, int ld, void* partials, int nblocks,
+               void* out, void* stream);
 
 /* XiT multi-head attention core, per (sequence b, head h): S = Q K^T (no pre-scale), P = softmax(S) * post_scale,
  * O = P V.  Q/O: [batch*Lq, heads*hd]; K/V: [batch*Lk, heads*hd].  Lq<=256, Lk<=16, hd<=96, hd%4==0.
+ * o_planes=1: O is written as bf16 planes (hi at O, lo o_lo_off elements later) for the projection GEMM.
  * replaces: finetune/xit.py:133-146 (einsum, softmax, "/ scaling", einsum). */
-int lr2_xattn_fwd(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int Lq, int Lk,
-                  int head_dim, float post_scale, void* stream);
-/* Backward of lr2_xattn_fwd: recomputes P; writes dQ [batch*Lq, E], dK, dV [batch*Lk, E]. */
+int lr2_xattn_fwd(const void* Q, const void* K, const void* V, void* O, int o_planes, uint64_t o_lo_off, int batch,
+                  int heads, int Lq, int Lk, int head_dim, float post_scale, void* stream);
+/* Backward of lr2_xattn_fwd: recomputes P; writes dQ [batch*Lq, E], dK, dV [batch*Lk, E] (fp32, or bf16 planes when
+ * planes=1: lo planes q_lo_off / kv_lo_off elements after the hi planes). */
 int lr2_xattn_bwd(const void* Q, const void* K, const void* V, const void* dO, void* dQ, void* dK, void* dV,
-                  int batch, int heads, int Lq, int Lk, int head_dim, float post_scale, void* stream);
+                  int planes, uint64_t q_lo_off, uint64_t kv_lo_off, int batch, int heads, int Lq, int Lk, int head_dim,
+                  float post_scale, void* stream);
 
 /* TencentPretrain self-attention core, per (sequence, head): S = Q K^T * scale + (seg[key]>0 ? 0 : -10000),
  * P = softmax(S), O = P V.  Q,K,V,O [batch*L, heads*hd]; seg int64 [batch*L]; L <= 256, hd == 64.

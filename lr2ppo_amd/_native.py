@@ -58,9 +58,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 class Epilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("resid", C.c_void_p), ("aux_z", C.c_void_p), ("out", C.c_void_p),
-                ("out_z", C.c_void_p), ("ld_resid", C.c_int32), ("ld_aux", C.c_int32), ("ld_out", C.c_int32),
+                ("out_z", C.c_void_p), ("out_hi", C.c_void_p), ("out_lo_off", C.c_uint64), ("ld_planes", C.c_int32),
+                ("ld_resid", C.c_int32), ("ld_aux", C.c_int32), ("ld_out", C.c_int32),
                 ("ld_z", C.c_int32), ("act", C.c_int32), ("accumulate", C.c_int32), ("alpha", C.c_float),
                 ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("_pad", C.c_uint32), ("drop_seed", C.c_uint64)]
+
+
+class SplitChunk(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst_hi", C.c_void_p), ("lo_off", C.c_uint64), ("count", C.c_uint64)]
 
 
 class AdamChunk(C.Structure):
@@ -74,16 +79,18 @@ _P, _I, _F, _U64, _U32 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_uint32
 SIGNATURES = {
     "lr2_abi_version": [],
     "lr2_device_info": [C.c_char_p, _I],
-    "lr2_gemm": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _U64, _U64, C.POINTER(Epilogue), _P, _I, _I, _I, _P],
+    "lr2_gemm": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _U64, _U64, _I, _U64, _I, _U64, C.POINTER(Epilogue), _P, _I, _I, _I, _P],
     "lr2_gather_rows": [_P, _P, _P, _I, _I, _I, _U64, _U64, _U64, _P],
     "lr2_gather_rows_bwd": [_P, _P, _P, _I, _I, _I, _U64, _P],
-    "lr2_copy_rows": [_P, _P, _I, _I, _I, _U64, _U64, _P],
-    "lr2_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _I, _U64, _P],
-    "lr2_layernorm_bwd": [_P, _I, _U64, _P, _P, _P, _P, _P, _P, _P, _F, _U64, _U32, _P, _I, _I, _I, _P],
+    "lr2_copy_rows": [_P, _P, _I, _U64, _I, _I, _I, _U64, _U64, _P],
+    "lr2_split_planes": [_P, _P, _U64, _U64, _P],
+    "lr2_split_planes_multi": [_P, _I, _P],
+    "lr2_layernorm_fwd": [_P, _P, _P, _P, _P, _U64, _P, _P, _I, _I, _F, _I, _I, _U64, _P],
+    "lr2_layernorm_bwd": [_P, _I, _U64, _P, _P, _P, _P, _P, _P, _P, _U64, _F, _U64, _U32, _P, _I, _I, _I, _P],
     "lr2_colsum_partials_finish": [_P, _I, _I, _I, _P, _I, _P],
-    "lr2_colsum": [_P, _I, _I, _I, _P, _I, _P, _P],
-    "lr2_xattn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
-    "lr2_xattn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "lr2_colsum": [_P, _I, _U64, _I, _I, _I, _P, _I, _P, _P],
+    "lr2_xattn_fwd": [_P, _P, _P, _P, _I, _U64, _I, _I, _I, _I, _I, _F, _P],
+    "lr2_xattn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _U64, _U64, _I, _I, _I, _I, _I, _F, _P],
     "lr2_self_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "lr2_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lr2_head_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -125,7 +132,7 @@ def lib() -> C.CDLL:
                 raise RuntimeError(f"lr2ppo_amd: {LIB_PATH} does not export {name}") from e
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        if handle.lr2_abi_version() != 1:
+        if handle.lr2_abi_version() != 2:
             raise RuntimeError("lr2ppo_amd: ABI version mismatch between python package and native library")
         _lib = handle
         return _lib

@@ -16,8 +16,9 @@ constexpr int MAX_HD = 96;
 
 // ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                        const float* __restrict__ V, float* __restrict__ O, int heads,
-                                                        int Lq, int Lk, int hd, float post_scale) {
+                                                        const float* __restrict__ V, float* __restrict__ O, int o_planes,
+                                                        size_t o_lo_off, int heads, int Lq, int Lk, int hd,
+                                                        float post_scale) {
   __shared__ __attribute__((aligned(16))) float sK[MAX_LK][MAX_HD];
   __shared__ __attribute__((aligned(16))) float sV[MAX_LK][MAX_HD];
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
   const float inv = post_scale / sum;
 #pragma unroll
   for (int j = 0; j < MAX_LK; ++j) s[j] *= inv;
-  float* o = O + ((size_t)b * Lq + t) * E + (size_t)h * hd;
+  const size_t oo = ((size_t)b * Lq + t) * E + (size_t)h * hd;
   for (int d = 0; d < hd; d += 4) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
       const float4 v4 = *reinterpret_cast<const float4*>(&sV[j][d]);
       a.x += s[j] * v4.x; a.y += s[j] * v4.y; a.z += s[j] * v4.z; a.w += s[j] * v4.w;
     }
-    *reinterpret_cast<float4*>(o + d) = a;
+    if (o_planes) store_planes4(reinterpret_cast<bf16_t*>(O) + oo + d, o_lo_off, a);
+    else *reinterpret_cast<float4*>(O + oo + d) = a;
   }
 }
 
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                         const float* __restrict__ V, const float* __restrict__ dO,
                                                         float* __restrict__ dQ, float* __restrict__ dK,
-                                                        float* __restrict__ dV, int heads, int Lq, int Lk, int hd,
+                                                        float* __restrict__ dV, int planes, size_t q_lo_off,
+                                                        size_t kv_lo_off, int heads, int Lq, int Lk, int hd,
                                                         float post_scale) {
   extern __shared__ __attribute__((aligned(16))) float bwd_smem[];
   typedef float RowK[MAX_HD];
@@ -151,7 +154,8 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
         const float4 k4 = *reinterpret_cast<const float4*>(&sK[j][d]);
         a.x += dp[j] * k4.x; a.y += dp[j] * k4.y; a.z += dp[j] * k4.z; a.w += dp[j] * k4.w;
       }
-      *reinterpret_cast<float4*>(dQ + ro + d) = a;
+      if (planes) store_planes4(reinterpret_cast<bf16_t*>(dQ) + ro + d, q_lo_off, a);
+      else *reinterpret_cast<float4*>(dQ + ro + d) = a;
     }
   }
   __syncthreads();
@@ -184,11 +188,21 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
     }
   }
   __syncthreads();
-  for (int idx = t; idx < Lk * hd; idx += 256) {
-    const int j = idx / hd, d = idx % hd;
+  for (int idx = t; idx < Lk * (hd / 4); idx += 256) {
+    const int j = idx / (hd / 4), d = (idx % (hd / 4)) * 4;
     const size_t o = ((size_t)b * Lk + j) * E + (size_t)h * hd + d;
-    dK[o] = sAcc[0][j][d] + sAcc[1][j][d];
-    dV[o] = sAcc[0][MAX_LK + j][d] + sAcc[1][MAX_LK + j][d];
+    float4 gk, gv;
+    gk.x = sAcc[0][j][d + 0] + sAcc[1][j][d + 0]; gk.y = sAcc[0][j][d + 1] + sAcc[1][j][d + 1];
+    gk.z = sAcc[0][j][d + 2] + sAcc[1][j][d + 2]; gk.w = sAcc[0][j][d + 3] + sAcc[1][j][d + 3];
+    gv.x = sAcc[0][MAX_LK + j][d + 0] + sAcc[1][MAX_LK + j][d + 0]; gv.y = sAcc[0][MAX_LK + j][d + 1] + sAcc[1][MAX_LK + j][d + 1];
+    gv.z = sAcc[0][MAX_LK + j][d + 2] + sAcc[1][MAX_LK + j][d + 2]; gv.w = sAcc[0][MAX_LK + j][d + 3] + sAcc[1][MAX_LK + j][d + 3];
+    if (planes) {
+      store_planes4(reinterpret_cast<bf16_t*>(dK) + o, kv_lo_off, gk);
+      store_planes4(reinterpret_cast<bf16_t*>(dV) + o, kv_lo_off, gv);
+    } else {
+      *reinterpret_cast<float4*>(dK + o) = gk;
+      *reinterpret_cast<float4*>(dV + o) = gv;
+    }
   }
 }
 
@@ -254,17 +268,18 @@ __global__ __launch_bounds__(256) void self_attn_fwd_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int lr2_xattn_fwd(const void* Q, const void* K, const void* V, void* O, int batch, int heads, int Lq, int Lk,
-                             int head_dim, float post_scale, void* stream) {
+extern "C" int lr2_xattn_fwd(const void* Q, const void* K, const void* V, void* O, int o_planes, uint64_t o_lo_off, int batch,
+                             int heads, int Lq, int Lk, int head_dim, float post_scale, void* stream) {
   if (!Q || !K || !V || !O || batch <= 0 || heads <= 0) return LR2_ERR_ARG;
   if (Lq < 1 || Lq > 256 || Lk < 1 || Lk > MAX_LK || head_dim > MAX_HD || head_dim % 4 != 0) return LR2_ERR_SHAPE;
   LR2_LAUNCH(xattn_fwd_kernel, dim3(batch * heads), dim3(256), 0, (hipStream_t)stream, (const float*)Q,
-                     (const float*)K, (const float*)V, (float*)O, heads, Lq, Lk, head_dim, post_scale);
+                     (const float*)K, (const float*)V, (float*)O, o_planes, (size_t)o_lo_off, heads, Lq, Lk, head_dim, post_scale);
   return lr2_launch_status(__func__);
 }
 
 extern "C" int lr2_xattn_bwd(const void* Q, const void* K, const void* V, const void* dO, void* dQ, void* dK, void* dV,
-                             int batch, int heads, int Lq, int Lk, int head_dim, float post_scale, void* stream) {
+                             int planes, uint64_t q_lo_off, uint64_t kv_lo_off, int batch, int heads, int Lq, int Lk,
+                             int head_dim, float post_scale, void* stream) {
   if (!Q || !K || !V || !dO || !dQ || !dK || !dV || batch <= 0 || heads <= 0) return LR2_ERR_ARG;
   if (Lq < 1 || Lq > 256 || Lk < 1 || Lk > MAX_LK || head_dim > MAX_HD || head_dim % 4 != 0) return LR2_ERR_SHAPE;
   const size_t lds = sizeof(float) * ((size_t)2 * MAX_LK * MAX_HD + 2 * 256 * MAX_LK + 2 * 2 * MAX_LK * (MAX_HD + 1));
@@ -274,8 +289,8 @@ extern "C" int lr2_xattn_bwd(const void* Q, const void* K, const void* V, const 
     attr_set = true;
   }
   LR2_LAUNCH(xattn_bwd_kernel, dim3(batch * heads), dim3(256), lds, (hipStream_t)stream, (const float*)Q,
-                     (const float*)K, (const float*)V, (const float*)dO, (float*)dQ, (float*)dK, (float*)dV, heads, Lq,
-                     Lk, head_dim, post_scale);
+                     (const float*)K, (const float*)V, (const float*)dO, (float*)dQ, (float*)dK, (float*)dV, planes,
+                     (size_t)q_lo_off, (size_t)kv_lo_off, heads, Lq, Lk, head_dim, post_scale);
   return lr2_launch_status(__func__);
 }
 

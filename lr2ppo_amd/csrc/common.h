@@ -70,16 +70,25 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// fp32 x 4 -> packed bf16 hi and lo pairs (x = hi + lo, hi = bf16(x), lo = bf16(x - hi)): the operand format of the
+// split-bf16 GEMM.  Element order in memory = argument order.
+__device__ __forceinline__ void split4(float4 v, u32x2_t& hv, u32x2_t& lv) {
+  const uint32_t h01 = cvt_pk_bf16(v.x, v.y), h23 = cvt_pk_bf16(v.z, v.w);
+  const uint32_t l01 = cvt_pk_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
+  const uint32_t l23 = cvt_pk_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));
+  hv = u32x2_t{h01, h23};
+  lv = u32x2_t{l01, l23};
+}
+// store 4 consecutive elements of a planes tensor (hi plane at p, lo plane lo_off elements later)
+__device__ __forceinline__ void store_planes4(bf16_t* p, size_t lo_off, float4 v) {
+  u32x2_t hv, lv;
+  split4(v, hv, lv);
+  *reinterpret_cast<u32x2_t*>(p) = hv;
+  *reinterpret_cast<u32x2_t*>(p + lo_off) = lv;
+}
+
 // ---------------------------------------------------------------------------------------------
-// Fused GEMM epilogue description (shared by the MFMA kernel and the split-K reducer).
-// Applied per output element (m, n), in this order:
-//   v = acc * alpha (+ bias[n])
-//   act == 1 : z = v (optionally stored in out_z) ; v = gelu_erf(v)
-//   drop_p>0 : v = keep(m*N+n) ? v/(1-p) : 0
-//   act == 2 : v *= gelu_erf'(aux_z[m,n])            (backward through GELU; aux is the saved z)
-//   resid    : v += resid[m,n]                         (residual stream)
-//   accumulate: v += out[m,n]
-//   store out[m,n]
+// Fused GEMM epilogue description (shared by the MFMA kernel and the split-K reducer); see gemm.hip::epilogue_vec4.
 // ---------------------------------------------------------------------------------------------
 struct Epilogue {
   const float* bias;
@@ -87,6 +96,9 @@ struct Epilogue {
   const float* aux_z;
   float* out;
   float* out_z;
+  bf16_t* out_hi;        // planes output (hi plane); lo plane at out_hi + lo_off
+  size_t lo_off;
+  int ld_planes;
   int ld_resid, ld_aux, ld_out, ld_z;
   int act;
   int accumulate;
@@ -95,23 +107,6 @@ struct Epilogue {
   uint32_t drop_thr;
   uint64_t drop_key;
 };
-
-__device__ __forceinline__ void epilogue_apply(const Epilogue& e, float acc, int m, int n, int N) {
-  float v = acc * e.alpha;
-  if (e.bias) v += e.bias[n];
-  if (e.act == 1) {
-    if (e.out_z) e.out_z[(size_t)m * e.ld_z + n] = v;
-    v = gelu_erf(v);
-  }
-  if (e.drop_scale != 0.0f) {
-    v = dropout_keep(e.drop_key, (uint64_t)m * (uint64_t)N + (uint64_t)n, e.drop_thr) ? v * e.drop_scale : 0.0f;
-  }
-  if (e.act == 2) v *= gelu_erf_grad(e.aux_z[(size_t)m * e.ld_aux + n]);
-  if (e.resid) v += e.resid[(size_t)m * e.ld_resid + n];
-  float* p = e.out + (size_t)m * e.ld_out + n;
-  if (e.accumulate) v += *p;
-  *p = v;
-}
 
 // hipGetLastError() reports the calling thread's most recent error from ANY runtime call, including benign ones
 // made by the host framework (hipErrorNotReady from event queries).  Clear the slot before a launch so that the

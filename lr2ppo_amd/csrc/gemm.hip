@@ -1,4 +1,4 @@
-// fp32-in / fp32-out GEMM on the bf16 matrix cores of gfx950 with fused epilogues:  C[M,N] = op(A) . op(B)
+// fp32-grade GEMM on the bf16 matrix cores of gfx950 with fused epilogues:  C[M,N] = op(A) . op(B)
 //
 //   TA == 0 : A is [M][K] row-major (K contiguous)          TA == 1 : A is [K][M] (M contiguous)
 //   TB == 0 : B is [N][K] row-major (nn.Linear weight)      TB == 1 : B is [K][N] (N contiguous)
@@ -10,39 +10,54 @@
 // Replaces the cuBLAS sgemm calls reached through nn.Linear in the reference
 // (finetune/ppo.py:164-170, finetune/xit.py:103-148, tencentpretrain/layers/*.py).
 //
-// Precision: the reference is fp32 end to end and the parity bar is 1e-3 on logits; a single bf16
-// pass misses it (2.5e-3 measured by CPU emulation).  So tensors stay fp32 in HBM and every
-// operand is split while it is staged into LDS:  x = hi + lo, hi = bf16(x), lo = bf16(x - hi).
-// PASSES == 3 accumulates lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_bf16 (fp32 accumulators; error
-// ~2^-17 relative, 4e-6 on logits) -- fp32-grade results at up to 1/3 of the bf16 MFMA peak, i.e. 5x
-// the fp32-MFMA peak of the chip.  PASSES == 1 keeps only hi*hi (plain bf16 inputs).
+// Precision.  The reference is fp32 end to end and the parity bar is 1e-3 on logits; a single bf16 pass misses it
+// (2.5e-3).  Every operand is therefore used as a split pair x = hi + lo (hi = bf16(x), lo = bf16(x - hi)).
+// PASSES == 3 accumulates lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulators: fp32-grade
+// results (~17 mantissa bits per operand) at up to 1/3 of the bf16 MFMA peak = 5x the chip's fp32-MFMA peak.
+// PASSES == 1 keeps hi*hi only.
 //
-// Structure (CDNA4): 256 threads = 4 waves, tile BM x 128 x 64.  Global -> VGPR (16-B buffer loads whose
-// descriptor range check zero-fills rows past the end: ragged M, ragged contraction in the TN form) -> split
-// -> ds_write_b64 into XOR-swizzled LDS images; the loads for tile t+1 are in flight while tile t is
-// multiplied.  K-contiguous operands are read with ds_read_b128; contraction-strided operands keep their
-// HBM orientation in LDS and are read with ds_read_b64_tr_b16 (hardware transpose), so no operand is
-// ever transposed in HBM.
+// Operand sources (per operand, template flags APL / BPL):
+//   fp32  : fp32 matrix in HBM -> VGPR (16-B buffer loads) -> split in registers -> ds_write_b64 into LDS, single
+//           buffered, tile t+1 in flight in registers while tile t is multiplied.  Used for the 2 GB out_layer.fc1
+//           weight, which is streamed once per pass and must not be duplicated.
+//   planes: the producer already wrote the operand as two bf16 planes [hi | lo] (same bytes as fp32).  Tiles go
+//           HBM -> LDS by LDS-DMA (buffer_load ... lds, 16 B/lane, no VGPRs, no VALU).  Default: ONE LDS image per
+//           workgroup and two workgroups per CU (measured 285-339 TFLOP/s fp32-equivalent on the head's shapes vs
+//           239-275 with a double-buffered image and one workgroup per CU; LR2_GEMM_DMA_STAGES=2 selects the latter).  The measured profile of the all-fp32 form showed its phases (loads, split, LDS
+//           write, fragment reads, MFMA) adding up serially with the matrix pipe ~30 % busy; with planes the split is
+//           paid once by the producer's epilogue instead of once per consuming tile (24-98x), and the loop is
+//           DMA + ds_read + MFMA only.
+// Both sources zero-fill rows past the end of the matrix through the buffer descriptor's range check, so ragged M, N
+// and (TN form) ragged contraction length need no host padding.  K-contiguous operands are read from LDS with
+// ds_read_b128, contraction-strided operands keep their HBM orientation and are read with ds_read_b64_tr_b16
+// (hardware transpose): nothing is ever transposed in HBM.  LDS images are XOR-swizzled (on the DMA *source* address
+// for planes, on the ds_write address for fp32) -- 0 bank conflicts measured (profiles/).
+//
+// Epilogue: the accumulators of a wave are staged through LDS so that every global access is a full 16-B vector on
+// 256-B contiguous row segments; bias, GELU (+ saved pre-activation), dropout, GELU', residual, accumulate, and the
+// output either as fp32 or as bf16 hi/lo planes for the next GEMM.
 #include <stdlib.h>
 
 #include "common.h"
 #include "lr2ppo_hip.h"
 
-namespace {
+namespace lr2gemm {
 
 constexpr int BK = 64;
 constexpr int NTHREADS = 256;
 
 struct GemmParams {
-  const float* A;
-  const float* B;
+  const void* A;
+  const void* B;
   int M, N, K;
-  int lda, ldb;               // elements
-  uint32_t a_bytes, b_bytes;  // buffer sizes for the range check
-  int k_tiles_per_split;      // in units of BK
-  int tiles_m, tiles_n;       // output tile grid
-  float* partial;             // split-K workspace [splits][M][N] or nullptr
-  int ablate;                 // diagnostics only (LR2_GEMM_ABLATE): 1 no MFMA, 2 no global loads, 4 no convert/store, 8 no frag reads
+  int lda, ldb;                 // elements
+  uint32_t a_bytes, b_bytes;    // bytes addressable from A / B (one plane for planes operands)
+  uint32_t a_lo_off, b_lo_off;  // byte offset from the hi plane to the lo plane (planes operands)
+  int k_tiles_per_split;        // in units of BK
+  int tiles_m, tiles_n;         // output tile grid
+  float* partial;               // split-K workspace [splits][M][N] or nullptr
+  int dma_stages;               // LDS images per planes operand: 2 = double buffered (1 workgroup/CU at BM=128), 1 = single
+  int ablate;                   // diagnostics only (LR2_GEMM_ABLATE): 2 no global loads, 4 no LDS fill
   Epilogue epi;
 };
 
@@ -55,8 +70,7 @@ __device__ __forceinline__ int swz_tr(int k) {
   return ((((k & 3) | (((k >> 3) & 1) << 2))) << 1) & (UPR - 1);
 }
 
-// Buffer descriptor built from provably wave-uniform words.  Without the readfirstlane hipcc cannot prove the
-// descriptor uniform and wraps EVERY buffer load in a serialising waterfall loop (s_and_saveexec ... s_cbranch_execnz).
+// Buffer descriptor built from provably wave-uniform words (else hipcc wraps every buffer op in a waterfall loop).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, uint32_t bytes) {
   const uint64_t a = (uint64_t)p;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
@@ -65,16 +79,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, ui
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-// Global fp32 tile -> registers -> (hi, lo) bf16 LDS images.
+// ---- operand source 1: fp32 in HBM, split in registers ---------------------------------------
 template <int BR, bool TR, int PASSES>
-struct Stager {
+struct RegStager {
   static constexpr int NV = BR * BK / 4 / NTHREADS;  // float4 per thread per tile
   static constexpr int UPR = TR ? BR / 8 : 8;
   static constexpr int TILE_BYTES = BR * BK * 2;
   u32x4_t regs[NV];
-  uint32_t voff;   // byte offset of this thread's q = 0 vector for the current k tile
-  uint32_t qstep;  // byte distance between consecutive q
-  uint32_t kstep;  // byte distance between consecutive k tiles
+  uint32_t voff, qstep, kstep;
   int tid;
 
   __device__ __forceinline__ void init(int tid_, int r0, int ld, int ktile0) {
@@ -108,8 +120,8 @@ struct Stager {
       return (k * UPR + ((rg >> 1) ^ swz_tr<UPR>(k))) * 16 + (rg & 1) * 8;
     }
   }
-  // hi pair = v_cvt_pk_bf16_f32(x0, x1) is already in LDS element order; its two halves, widened back to fp32 by a
-  // shift / mask, give the residuals whose packed conversion is the lo pair: 6 VALU per pair, no repacking.
+  // hi pair = v_cvt_pk_bf16_f32(x0, x1) is already in LDS element order; its halves widened back to fp32 by a
+  // shift / mask give the residuals whose packed conversion is the lo pair: 6 VALU per pair, no repacking.
   __device__ __forceinline__ void store(char* tile_hi) {
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
@@ -125,6 +137,44 @@ struct Stager {
         u32x2_t lv = {l01, l23};
         *reinterpret_cast<u32x2_t*>(tile_hi + TILE_BYTES + off) = lv;
       }
+    }
+  }
+};
+
+// ---- operand source 2: bf16 hi/lo planes in HBM, LDS-DMA ---------------------------------------
+// LDS-DMA writes lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
+// address; the LDS image is then identical to the one RegStager writes and read_frag() serves both.
+template <int BR, bool TR, int PASSES>
+struct DmaStager {
+  static constexpr int UNITS = BR * 8;             // 16-byte units per plane tile (BR x 64 bf16)
+  static constexpr int PER_WAVE = UNITS / 64 / 4;  // DMA instructions per wave per plane
+  static constexpr int UPR = TR ? BR / 8 : 8;
+  static constexpr int TILE_BYTES = BR * BK * 2;
+  uint32_t voff[PER_WAVE];
+  uint32_t kstep;
+  __device__ __forceinline__ void init(int wave, int lane, int r0, int ld, int ktile0) {
+    kstep = TR ? (uint32_t)ld * 2u * BK : 2u * BK;
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) {
+      const int p = (wave * PER_WAVE + q) * 64 + lane;
+      if (!TR) {
+        const int row = p >> 3, u = (p & 7) ^ swz_kc(row);
+        voff[q] = (uint32_t)(((uint64_t)(r0 + row) * (uint64_t)ld) * 2u + (uint32_t)u * 16u);
+      } else {
+        const int k = p / UPR, u = (p % UPR) ^ swz_tr<UPR>(k);
+        voff[q] = (uint32_t)(((uint64_t)k * (uint64_t)ld + (uint64_t)r0) * 2u + (uint32_t)u * 16u);
+      }
+      voff[q] += (uint32_t)ktile0 * kstep;
+    }
+  }
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc_hi, __amdgpu_buffer_rsrc_t rsrc_lo, char* tile_hi,
+                                        int wave) {
+#pragma unroll
+    for (int q = 0; q < PER_WAVE; ++q) {
+      char* dst = tile_hi + (wave * PER_WAVE + q) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_hi, LDS_PTR(dst), 16, voff[q], 0, 0, 0);
+      if (PASSES == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lo, LDS_PTR(dst + TILE_BYTES), 16, voff[q], 0, 0, 0);
+      voff[q] += kstep;
     }
   }
 };
@@ -152,6 +202,84 @@ __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int rbase, int k
   }
 }
 
+// Transposed fragment read issued through inline asm.  While an LDS-DMA is in flight hipcc puts s_waitcnt vmcnt(0) in
+// front of every ds_read_b64_tr_b16 *builtin* (it cannot disambiguate the read from the DMA's LDS destination), which
+// would serialise the copy of tile t+1 with the multiply of tile t.  An asm read is invisible to that pass; the caller
+// owns the wait (s_waitcnt lgkmcnt + sched_barrier) before the first use.
+template <int BR>
+__device__ __forceinline__ bf16x8_t read_frag_tr_asm(const char* tile, int rbase, int ks, int lane) {
+  constexpr int UPR = BR / 8;
+  const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+  const int g = lane >> 4;
+  const int ka = 32 * ks + 8 * g + q, kb = ka + 4;
+  const int u = (rbase >> 3) + (p >> 1);
+  const char* pa = tile + (ka * UPR + (u ^ swz_tr<UPR>(ka))) * 16 + 8 * (p & 1);
+  const char* pb = tile + (kb * UPR + (u ^ swz_tr<UPR>(kb))) * 16 + 8 * (p & 1);
+  const uint32_t aa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)pa;
+  const uint32_t ab = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)pb;
+  u32x2_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(aa));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(ab));
+  u32x4_t v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// K-tile multiply for planes (LDS-DMA) operands with at least one contraction-strided operand: all fragments of the
+// tile are requested up front (strided ones by asm, see above), the k-step-0 MFMAs start once the first half of the
+// LDS queue has drained (LDS returns in order, so a counted lgkmcnt is exact), k-step 1 after the rest.
+template <int BM, int BN, int MI, int NI, bool TA, bool TB, int PASSES>
+__device__ __forceinline__ void compute_tile_preload(const char* a_hi, const char* b_hi, int wm0, int wn0, int lane,
+                                                     f32x4_t (&acc)[MI][NI]) {
+  constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;
+  bf16x8_t ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      if (TA) {
+        ah[ks][i] = read_frag_tr_asm<BM>(a_hi, wm0 + 16 * i, ks, lane);
+        if (PASSES == 3) al[ks][i] = read_frag_tr_asm<BM>(a_hi + A_TILE, wm0 + 16 * i, ks, lane);
+      } else {
+        ah[ks][i] = read_frag<BM, false>(a_hi, wm0 + 16 * i, ks, lane);
+        if (PASSES == 3) al[ks][i] = read_frag<BM, false>(a_hi + A_TILE, wm0 + 16 * i, ks, lane);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (TB) {
+        bh[ks][j] = read_frag_tr_asm<BN>(b_hi, wn0 + 16 * j, ks, lane);
+        if (PASSES == 3) bl[ks][j] = read_frag_tr_asm<BN>(b_hi + B_TILE, wn0 + 16 * j, ks, lane);
+      } else {
+        bh[ks][j] = read_frag<BN, false>(b_hi, wn0 + 16 * j, ks, lane);
+        if (PASSES == 3) bl[ks][j] = read_frag<BN, false>(b_hi + B_TILE, wn0 + 16 * j, ks, lane);
+      }
+    }
+    if (ks == 0) __builtin_amdgcn_sched_barrier(0);   // keep the k-step-0 requests ahead of the k-step-1 ones
+  }
+  constexpr int NIMGS = PASSES == 3 ? 2 : 1;
+  constexpr int PER_KS = (MI * (TA ? 2 : 1) + NI * (TB ? 2 : 1)) * NIMGS;   // LDS instructions per k-step
+  // s_waitcnt immediate (gfx9 encoding): vmcnt = 63 and expcnt = 7 (no wait), lgkmcnt in bits [11:8]
+  constexpr int WAIT_HALF = 0xC07F | ((PER_KS <= 15 ? PER_KS : 0) << 8);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    if (ks == 0) __builtin_amdgcn_s_waitcnt(WAIT_HALF);   // the k-step-0 fragments have landed (LDS returns in order)
+    else __builtin_amdgcn_s_waitcnt(0xC07F);              // everything has
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      if (PASSES == 3) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+    }
+  }
+}
+
 // per (ks, j) group: R reads that prefetch the next group (+ R0 for the A fragments of the second k-step in group 0),
 // then MF MFMAs
 template <int GRP, int NGRP, int R0, int R, int MF>
@@ -164,52 +292,174 @@ __device__ __forceinline__ void pin_pipeline() {
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, int PASSES>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams g) {
+// One K-tile of MFMA work for a wave.  Fragment reads run one MFMA group ahead of their use (register double
+// buffering, pinned with sched_group_barrier: hipcc otherwise sinks every read to its first use and drains
+// lgkmcnt(0) ten times per tile).
+template <int BM, int BN, int MI, int NI, bool TA, bool TB, int PASSES>
+__device__ __forceinline__ void compute_tile(const char* a_hi, const char* b_hi, int wm0, int wn0, int lane,
+                                             f32x4_t (&acc)[MI][NI]) {
+  constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;
+  bf16x8_t ah[2][MI], al[2][MI], bh[2], bl[2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    ah[0][i] = read_frag<BM, TA>(a_hi, wm0 + 16 * i, 0, lane);
+    if (PASSES == 3) al[0][i] = read_frag<BM, TA>(a_hi + A_TILE, wm0 + 16 * i, 0, lane);
+  }
+  bh[0] = read_frag<BN, TB>(b_hi, wn0, 0, lane);
+  if (PASSES == 3) bl[0] = read_frag<BN, TB>(b_hi + B_TILE, wn0, 0, lane);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int cur = (ks * NI + j) & 1, nxt = cur ^ 1;
+      const int nj = (j + 1 < NI) ? j + 1 : 0, nks = (j + 1 < NI) ? ks : ks + 1;
+      if (nks < 2) {
+        bh[nxt] = read_frag<BN, TB>(b_hi, wn0 + 16 * nj, nks, lane);
+        if (PASSES == 3) bl[nxt] = read_frag<BN, TB>(b_hi + B_TILE, wn0 + 16 * nj, nks, lane);
+      }
+      if (j == 0 && ks == 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          ah[1][i] = read_frag<BM, TA>(a_hi, wm0 + 16 * i, 1, lane);
+          if (PASSES == 3) al[1][i] = read_frag<BM, TA>(a_hi + A_TILE, wm0 + 16 * i, 1, lane);
+        }
+      }
+      if (PASSES == 3) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks][i], bh[cur], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks][i], bl[cur], acc[i][j], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks][i], bh[cur], acc[i][j], 0, 0, 0);
+    }
+  }
+  constexpr int NIMGS = PASSES == 3 ? 2 : 1;
+  constexpr int RPF = TB ? 2 : 1, RPA = TA ? 2 : 1;  // LDS read instructions per fragment
+  __builtin_amdgcn_sched_group_barrier(0x100, (MI * RPA + RPF) * NIMGS, 0);
+  pin_pipeline<0, 2 * NI, MI * RPA * NIMGS, RPF * NIMGS, MI * PASSES>();
+}
+
+// ---- epilogue ------------------------------------------------------------------------------------
+// Wave tile WM x WN, staged through a private LDS slab of 32 x (WN + 4) floats, 32 rows at a time.  After the
+// transpose each lane owns 4 consecutive columns of one row, so every global access below is a 16-B vector and a
+// row segment of WN*4 bytes is contiguous across 16 (WN = 64) or 8 (WN = 32) lanes.
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ void epilogue_vec4(const Epilogue& e, float4 v, int m, int n, int N) {
+  v.x *= e.alpha; v.y *= e.alpha; v.z *= e.alpha; v.w *= e.alpha;
+  if (e.bias) {
+    const float4 b = ld4(e.bias + n);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  }
+  if (e.act == 1) {
+    if (e.out_z) st4(e.out_z + (size_t)m * e.ld_z + n, v);
+    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+  }
+  if (e.drop_scale != 0.0f) {
+    const uint64_t idx = (uint64_t)m * (uint64_t)N + (uint64_t)n;
+    v.x = dropout_keep(e.drop_key, idx + 0, e.drop_thr) ? v.x * e.drop_scale : 0.0f;
+    v.y = dropout_keep(e.drop_key, idx + 1, e.drop_thr) ? v.y * e.drop_scale : 0.0f;
+    v.z = dropout_keep(e.drop_key, idx + 2, e.drop_thr) ? v.z * e.drop_scale : 0.0f;
+    v.w = dropout_keep(e.drop_key, idx + 3, e.drop_thr) ? v.w * e.drop_scale : 0.0f;
+  }
+  if (e.act == 2) {
+    const float4 z = ld4(e.aux_z + (size_t)m * e.ld_aux + n);
+    v.x *= gelu_erf_grad(z.x); v.y *= gelu_erf_grad(z.y); v.z *= gelu_erf_grad(z.z); v.w *= gelu_erf_grad(z.w);
+  }
+  if (e.resid) {
+    const float4 r = ld4(e.resid + (size_t)m * e.ld_resid + n);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  if (e.out) {
+    float* p = e.out + (size_t)m * e.ld_out + n;
+    if (e.accumulate) {
+      const float4 o = ld4(p);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    st4(p, v);
+  }
+  if (e.out_hi) {  // bf16 hi/lo planes for the next GEMM (same bytes as the fp32 tensor they replace)
+    u32x2_t hv, lv;
+    split4(v, hv, lv);
+    bf16_t* ph = e.out_hi + (size_t)m * e.ld_planes + n;
+    *reinterpret_cast<u32x2_t*>(ph) = hv;
+    *reinterpret_cast<u32x2_t*>(ph + e.lo_off) = lv;
+  }
+}
+
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void epilogue_wave(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
+                                              int lane, float* partial) {
+  constexpr int LDW = WN + 4;
+  constexpr int LPR = WN / 4;    // lanes per row
+  constexpr int RPP = 64 / LPR;  // rows per pass
+  const int gq = lane >> 4, c16 = lane & 15;
+#pragma unroll
+  for (int half = 0; half < WM / 32; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(16 * ii + 4 * gq + r) * LDW + 16 * j + c16] = acc[2 * half + ii][j][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pass = 0; pass < 32 / RPP; ++pass) {
+      const int row = pass * RPP + lane / LPR, col = (lane % LPR) * 4;
+      const float4 v = ld4(slab + row * LDW + col);
+      const int m = mw + 32 * half + row, n = nw + col;
+      if (m < g.M && n < g.N) {
+        if (partial) st4(partial + (size_t)m * g.N + n, v);
+        else epilogue_vec4(g.epi, v, m, n, g.N);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, int PASSES, bool APL, bool BPL>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams g) {
   constexpr int MI = WM / 16, NI = WN / 16;
   constexpr int WAVES_N = BN / WN;
-  constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;   // one bf16 image
   constexpr int NIMG = PASSES == 3 ? 2 : 1;
+  constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;  // one bf16 image
+  constexpr int A_STAGE = NIMG * A_TILE, B_STAGE = NIMG * B_TILE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds_a = smem;                       // [hi | lo]
-  char* lds_b = smem + NIMG * A_TILE;       // [hi | lo]
+  const bool dbuf = g.dma_stages == 2;       // planes operands double buffered?
+  char* lds_a = smem;
+  char* lds_b = smem + ((APL && dbuf) ? 2 : 1) * A_STAGE;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // XCD-aware grouped rasterisation.  Tiles are first put in strip-major order (strips of 8 tiles along N, row-major
   // inside a strip), so any 64 consecutive tiles form an 8 x 8 patch sharing 8 A panels and 8 B panels; that sequence is
   // cut into 8 equal contiguous chunks, one per XCD (workgroups are dealt round-robin to the XCDs: blockIdx % 8 labels
-  // the XCD group, blockIdx / 8 is the dispatch order inside it).  Each XCD's 64 resident workgroups then walk one
-  // patch in lockstep and its private 4 MiB L2 serves 7 of every 8 operand reads.  Speed only -- the map is a
-  // bijection, any placement gives the same result.
+  // the XCD group, blockIdx / 8 is the dispatch order inside it).  Speed only -- the map is a bijection.
   int tm, tn;
   {
     const int T = g.tiles_m * g.tiles_n;
     const int q = T >> 3, r = T & 7, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int i = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     const int SN = g.tiles_n < 8 ? g.tiles_n : 8;
-    const int full = (g.tiles_n / SN) * g.tiles_m * SN;       // tiles inside full-width strips
+    const int full = (g.tiles_n / SN) * g.tiles_m * SN;  // tiles inside full-width strips
     if (i < full) {
       const int strip = i / (g.tiles_m * SN), rem = i % (g.tiles_m * SN);
       tm = rem / SN;
       tn = strip * SN + rem % SN;
     } else {
-      const int rw = g.tiles_n % SN, rem = i - full;          // last, narrower strip
+      const int rw = g.tiles_n % SN, rem = i - full;  // last, narrower strip
       tm = rem / rw;
       tn = (g.tiles_n / SN) * SN + rem % rw;
     }
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
-  if (g.ablate & 0xff00) {   // experiment: stagger co-resident workgroups
-    const int bit = (g.ablate >> 16) & 31;
-    if (((blockIdx.x >> 3) >> bit) & 1) {
-      const int n = (g.ablate >> 8) & 0xff;
-      for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
-    }
-  }
   const int total_k_tiles = (g.K + BK - 1) / BK;
   const int kt_begin = blockIdx.z * g.k_tiles_per_split;
   int kt_end = kt_begin + g.k_tiles_per_split;
@@ -218,11 +468,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams g) {
 
   __amdgpu_buffer_rsrc_t rsrc_a = uniform_rsrc(g.A, g.a_bytes);
   __amdgpu_buffer_rsrc_t rsrc_b = uniform_rsrc(g.B, g.b_bytes);
+  __amdgpu_buffer_rsrc_t rsrc_a_lo = uniform_rsrc((const char*)g.A + (APL ? g.a_lo_off : 0), g.a_bytes);
+  __amdgpu_buffer_rsrc_t rsrc_b_lo = uniform_rsrc((const char*)g.B + (BPL ? g.b_lo_off : 0), g.b_bytes);
 
-  Stager<BM, TA, PASSES> sa;
-  Stager<BN, TB, PASSES> sb;
-  sa.init(tid, m0, g.lda, kt_begin);
-  sb.init(tid, n0, g.ldb, kt_begin);
+  RegStager<BM, TA, PASSES> ra;
+  RegStager<BN, TB, PASSES> rb;
+  DmaStager<BM, TA, PASSES> da;
+  DmaStager<BN, TB, PASSES> db;
+  if (APL) da.init(wave, lane, m0, g.lda, kt_begin);
+  else ra.init(tid, m0, g.lda, kt_begin);
+  if (BPL) db.init(wave, lane, n0, g.ldb, kt_begin);
+  else rb.init(tid, n0, g.ldb, kt_begin);
 
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
 
@@ -233,147 +489,120 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams g) {
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   if (nt > 0) {
-    sa.load(rsrc_a);
-    sb.load(rsrc_b);
-    sa.store(lds_a);
-    sb.store(lds_b);
+    if (APL) da.issue(rsrc_a, rsrc_a_lo, lds_a, wave);
+    else ra.load(rsrc_a);
+    if (BPL) db.issue(rsrc_b, rsrc_b_lo, lds_b, wave);
+    else rb.load(rsrc_b);
+    if (!APL) ra.store(lds_a);
+    if (!BPL) rb.store(lds_b);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int t = 0; t < nt; ++t) {
     const bool more = (t + 1 < nt);
-    if (more && !(g.ablate & 2)) {  // tile t+1 travels HBM -> VGPR while tile t is multiplied
-      sa.load(rsrc_a);
-      sb.load(rsrc_b);
+    const int cur = t & 1;
+    char* a_cur = lds_a + ((APL && dbuf) ? cur : 0) * A_STAGE;
+    char* b_cur = lds_b + ((BPL && dbuf) ? cur : 0) * B_STAGE;
+    if (more && !(g.ablate & 2)) {  // tile t+1: HBM -> LDS (planes) or HBM -> VGPR (fp32) while tile t is multiplied
+      if (APL) { if (dbuf) da.issue(rsrc_a, rsrc_a_lo, lds_a + (cur ^ 1) * A_STAGE, wave); }
+      else ra.load(rsrc_a);
+      if (BPL) { if (dbuf) db.issue(rsrc_b, rsrc_b_lo, lds_b + (cur ^ 1) * B_STAGE, wave); }
+      else rb.load(rsrc_b);
     }
-    if (!(g.ablate & 8))
-    // Fragment reads run one MFMA group ahead of their use (register double buffering): the A fragments of k-step
-    // ks+1 and the next B fragment are requested before the 3*MI MFMAs of the current (ks, j) group are issued, so
-    // the ~100-cycle LDS latency hides under >= 12 MFMAs instead of stalling the wave at every group.
-    {
-      bf16x8_t ah[2][MI], al[2][MI], bh[2], bl[2];
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        ah[0][i] = read_frag<BM, TA>(lds_a, wm0 + 16 * i, 0, lane);
-        if (PASSES == 3) al[0][i] = read_frag<BM, TA>(lds_a + A_TILE, wm0 + 16 * i, 0, lane);
+    if constexpr ((APL || BPL) && (TA || TB))
+      compute_tile_preload<BM, BN, MI, NI, TA, TB, PASSES>(a_cur, b_cur, wm0, wn0, lane, acc);
+    else
+      compute_tile<BM, BN, MI, NI, TA, TB, PASSES>(a_cur, b_cur, wm0, wn0, lane, acc);
+    if (!APL || !BPL || !dbuf) {
+      __syncthreads();  // every wave is done reading the single-buffered image(s)
+      if (more && !(g.ablate & 4)) {
+        if (!APL) ra.store(lds_a);
+        else if (!dbuf) da.issue(rsrc_a, rsrc_a_lo, lds_a, wave);
+        if (!BPL) rb.store(lds_b);
+        else if (!dbuf) db.issue(rsrc_b, rsrc_b_lo, lds_b, wave);
       }
-      bh[0] = read_frag<BN, TB>(lds_b, wn0, 0, lane);
-      if (PASSES == 3) bl[0] = read_frag<BN, TB>(lds_b + B_TILE, wn0, 0, lane);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const int cur = (ks * NI + j) & 1, nxt = cur ^ 1;
-          const int nj = (j + 1 < NI) ? j + 1 : 0, nks = (j + 1 < NI) ? ks : ks + 1;
-          if (nks < 2) {
-            bh[nxt] = read_frag<BN, TB>(lds_b, wn0 + 16 * nj, nks, lane);
-            if (PASSES == 3) bl[nxt] = read_frag<BN, TB>(lds_b + B_TILE, wn0 + 16 * nj, nks, lane);
-          }
-          if (j == 0 && ks == 0) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-              ah[1][i] = read_frag<BM, TA>(lds_a, wm0 + 16 * i, 1, lane);
-              if (PASSES == 3) al[1][i] = read_frag<BM, TA>(lds_a + A_TILE, wm0 + 16 * i, 1, lane);
-            }
-          }
-          if (g.ablate & 1) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-              asm volatile("" ::"v"(ah[ks][i]), "v"(bh[cur]));
-              if (PASSES == 3) asm volatile("" ::"v"(al[ks][i]), "v"(bl[cur]));
-            }
-            continue;
-          }
-          if (PASSES == 3) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ks][i], bh[cur], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks][i], bl[cur], acc[i][j], 0, 0, 0);
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks][i], bh[cur], acc[i][j], 0, 0, 0);
-        }
-      }
-      // pin the software pipeline in the emitted stream: [prologue reads] then, per (ks, j) group, the reads that
-      // prefetch the NEXT group followed by this group's MFMAs (hipcc otherwise sinks every read to its first use)
-      constexpr int NIMGS = PASSES == 3 ? 2 : 1;
-      constexpr int DS_READ = 0x100, MFMA = 0x008;
-      constexpr int RPF = TB ? 2 : 1, RPA = TA ? 2 : 1;      // LDS read instructions per fragment
-      __builtin_amdgcn_sched_group_barrier(DS_READ, (MI * RPA + RPF) * NIMGS, 0);
-      pin_pipeline<0, 2 * NI, MI * RPA * NIMGS, RPF * NIMGS, MI * PASSES>();
-      (void)MFMA;
     }
-    __syncthreads();  // every wave is done reading tile t
-    if (more && !(g.ablate & 4)) {
-      sa.store(lds_a);
-      sb.store(lds_b);
-    }
-    __syncthreads();  // tile t+1 is visible
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA for tile t+1 has landed
+    __syncthreads();                                   // ... and everyone's; tile t's buffers may be refilled
   }
 
-  // ---- epilogue: C/D layout of the 16x16 MFMA: row = 4*(lane>>4) + r, col = lane & 15 ----
-  const int gq = lane >> 4, c16 = lane & 15;
-  if (g.partial) {
-    float* part = g.partial + (size_t)blockIdx.z * (size_t)g.M * (size_t)g.N;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wm0 + 16 * i + 4 * gq + r, n = n0 + wn0 + 16 * j + c16;
-          if (m < g.M && n < g.N) part[(size_t)m * g.N + n] = acc[i][j][r];
-        }
-  } else {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wm0 + 16 * i + 4 * gq + r, n = n0 + wn0 + 16 * j + c16;
-          if (m < g.M && n < g.N) epilogue_apply(g.epi, acc[i][j][r], m, n, g.N);
-        }
-  }
+  // ---- epilogue through LDS (operand images are dead after the last barrier) ----
+  float* slab = reinterpret_cast<float*>(smem) + wave * (32 * (WN + 4));
+  float* part = g.partial ? g.partial + (size_t)blockIdx.z * (size_t)g.M * (size_t)g.N : nullptr;
+  epilogue_wave<WM, WN, MI, NI>(g, acc, slab, m0 + wm0, n0 + wn0, lane, part);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N,
                                                             Epilogue epi) {
+  const size_t total4 = (size_t)M * (size_t)N / 4;
   const size_t total = (size_t)M * (size_t)N;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += partial[(size_t)z * total + idx];
-    epilogue_apply(epi, s, (int)(idx / N), (int)(idx % N), N);
+  for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * blockDim.x) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {
+      const float4 v = ld4(partial + (size_t)z * total + i4 * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const size_t idx = i4 * 4;
+    epilogue_vec4(epi, s, (int)(idx / N), (int)(idx % N), N);
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, int PASSES>
+// Explicit instantiation of every kernel the dispatcher can reach: hipcc (ROCm 7.2) emits the host launch stub for only
+// a few of the implicit instantiations of this 9-parameter kernel template, leaving the others undefined at load time.
+#define LR2_GEMM_INST(BM, WN, TA, TB, P, APL, BPL) \
+  template __global__ void gemm_kernel<BM, 128, 64, WN, TA, TB, P, APL, BPL>(GemmParams);
+#define LR2_GEMM_INST_SRC(BM, WN, TA, TB, P)    \
+  LR2_GEMM_INST(BM, WN, TA, TB, P, false, false) \
+  LR2_GEMM_INST(BM, WN, TA, TB, P, true, false)  \
+  LR2_GEMM_INST(BM, WN, TA, TB, P, true, true)
+#define LR2_GEMM_INST_FORM(BM, WN, P)           \
+  LR2_GEMM_INST_SRC(BM, WN, false, false, P)     \
+  LR2_GEMM_INST_SRC(BM, WN, false, true, P)      \
+  LR2_GEMM_INST_SRC(BM, WN, true, true, P)
+LR2_GEMM_INST_FORM(128, 64, 1)
+LR2_GEMM_INST_FORM(128, 64, 3)
+LR2_GEMM_INST_FORM(64, 32, 1)
+LR2_GEMM_INST_FORM(64, 32, 3)
+
+template <int BM, int BN, int WM, int WN, bool TA, bool TB, int PASSES, bool APL, bool BPL>
 int launch(const GemmParams& p_in, int splits, hipStream_t stream) {
   GemmParams p = p_in;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   dim3 grid(p.tiles_m * p.tiles_n, 1, splits);
-  const size_t lds = (size_t)(PASSES == 3 ? 2 : 1) * (BM * BK * 2 + BN * BK * 2);
-  auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, PASSES>;
+  constexpr int NIMG = PASSES == 3 ? 2 : 1;
+  const size_t main_lds = (size_t)((APL && p.dma_stages == 2) ? 2 : 1) * NIMG * BM * BK * 2 +
+                          (size_t)((BPL && p.dma_stages == 2) ? 2 : 1) * NIMG * BN * BK * 2;
+  constexpr size_t epi_lds = (size_t)4 * 32 * (WN + 4) * 4;
+  const size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
+  constexpr size_t max_lds = (size_t)2 * NIMG * BM * BK * 2 + (size_t)2 * NIMG * BN * BK * 2;
+  auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, PASSES, APL, BPL>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (lr2_allow_dynamic_lds(kern, lds, "gemm")) return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(kern, max_lds > epi_lds ? max_lds : epi_lds, "gemm")) return LR2_ERR_LAUNCH;
     attr_set = true;
   }
   LR2_LAUNCH(kern, grid, dim3(NTHREADS), lds, stream, p);
   return lr2_launch_status(__func__);
 }
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, bool APL, bool BPL>
 int dispatch(const GemmParams& p, int splits, int bm, int passes, hipStream_t stream) {
   if (passes == 1) {
-    if (bm == 64) return launch<64, 128, 64, 32, TA, TB, 1>(p, splits, stream);
-    return launch<128, 128, 64, 64, TA, TB, 1>(p, splits, stream);
+    if (bm == 64) return launch<64, 128, 64, 32, TA, TB, 1, APL, BPL>(p, splits, stream);
+    return launch<128, 128, 64, 64, TA, TB, 1, APL, BPL>(p, splits, stream);
   }
-  if (bm == 64) return launch<64, 128, 64, 32, TA, TB, 3>(p, splits, stream);
-  return launch<128, 128, 64, 64, TA, TB, 3>(p, splits, stream);
+  if (bm == 64) return launch<64, 128, 64, 32, TA, TB, 3, APL, BPL>(p, splits, stream);
+  return launch<128, 128, 64, 64, TA, TB, 3, APL, BPL>(p, splits, stream);
+}
+
+template <bool APL, bool BPL>
+int dispatch_form(const GemmParams& p, int splits, int bm, int passes, int ta, int tb, hipStream_t s) {
+  if (!ta && !tb) return dispatch<false, false, APL, BPL>(p, splits, bm, passes, s);
+  if (!ta && tb) return dispatch<false, true, APL, BPL>(p, splits, bm, passes, s);
+  if (ta && tb) return dispatch<true, true, APL, BPL>(p, splits, bm, passes, s);
+  return LR2_ERR_ARG;  // (1,0) is not a form the path needs
 }
 
 Epilogue to_device_epilogue(const lr2_epilogue* e) {
@@ -383,6 +612,9 @@ Epilogue to_device_epilogue(const lr2_epilogue* e) {
   d.aux_z = (const float*)e->aux_z;
   d.out = (float*)e->out;
   d.out_z = (float*)e->out_z;
+  d.out_hi = (bf16_t*)e->out_hi;
+  d.lo_off = (size_t)e->out_lo_off;
+  d.ld_planes = e->ld_planes;
   d.ld_resid = e->ld_resid;
   d.ld_aux = e->ld_aux;
   d.ld_out = e->ld_out;
@@ -398,26 +630,35 @@ Epilogue to_device_epilogue(const lr2_epilogue* e) {
   return d;
 }
 
-}  // namespace
+}  // namespace lr2gemm
+using namespace lr2gemm;
 
 extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int trans_a, int trans_b,
-                        uint64_t a_bytes, uint64_t b_bytes, const lr2_epilogue* epi, void* splitk_ws, int splits,
-                        int block_m, int passes, void* stream) {
-  if (!A || !B || M <= 0 || N <= 0 || K <= 0 || !epi || !epi->out) return LR2_ERR_ARG;
+                        uint64_t a_bytes, uint64_t b_bytes, int a_planes, uint64_t a_lo_off, int b_planes,
+                        uint64_t b_lo_off, const lr2_epilogue* epi, void* splitk_ws, int splits, int block_m, int passes,
+                        void* stream) {
+  if (!A || !B || M <= 0 || N <= 0 || K <= 0 || !epi || (!epi->out && !epi->out_hi)) return LR2_ERR_ARG;
   if (passes != 1 && passes != 3) return LR2_ERR_ARG;
   if (block_m != 64) block_m = 128;
-  // K-contiguous operands need whole K tiles (a ragged K would read into the next row, not zeros); ragged M / N
-  // are handled by the zero-filling range check on loads plus masked stores.
+  // K-contiguous operands need whole K tiles (a ragged K would read into the next row, not zeros); ragged M / N are
+  // handled by the zero-filling range check on loads plus masked stores.
   if ((!trans_a || !trans_b) && (K % BK != 0)) return LR2_ERR_SHAPE;
-  if ((lda % 4) || (ldb % 4)) return LR2_ERR_SHAPE;      // 16-byte aligned rows
-  if (a_bytes >= (1ull << 32) || b_bytes >= (1ull << 32)) return LR2_ERR_SHAPE;
+  const int a_align = a_planes ? 8 : 4, b_align = b_planes ? 8 : 4;  // 16-byte rows
+  if ((lda % a_align) || (ldb % b_align) || (N % 4)) return LR2_ERR_SHAPE;
+  if ((epi->out && epi->ld_out % 4) || (epi->out_z && epi->ld_z % 4) || (epi->resid && epi->ld_resid % 4) ||
+      (epi->aux_z && epi->ld_aux % 4) || (epi->out_hi && epi->ld_planes % 4))
+    return LR2_ERR_SHAPE;
+  if (a_bytes >= (1ull << 32) || b_bytes >= (1ull << 32) || a_lo_off >= (1ull << 32) || b_lo_off >= (1ull << 32))
+    return LR2_ERR_SHAPE;
+  if (!a_planes && b_planes) return LR2_ERR_ARG;  // (fp32 A, planes B) is not a combination the path needs
+  if (epi->accumulate && !epi->out) return LR2_ERR_ARG;
   if (splits < 1) splits = 1;
   const int total_k_tiles = (K + BK - 1) / BK;
   if (splits > total_k_tiles) splits = total_k_tiles;
   if (splits > 1 && !splitk_ws) return LR2_ERR_ARG;
   GemmParams p{};
-  p.A = (const float*)A;
-  p.B = (const float*)B;
+  p.A = A;
+  p.B = B;
   p.M = M;
   p.N = N;
   p.K = K;
@@ -425,28 +666,32 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   p.ldb = ldb;
   p.a_bytes = (uint32_t)a_bytes;
   p.b_bytes = (uint32_t)b_bytes;
+  p.a_lo_off = (uint32_t)a_lo_off;
+  p.b_lo_off = (uint32_t)b_lo_off;
   p.k_tiles_per_split = (total_k_tiles + splits - 1) / splits;
   splits = (total_k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
   p.partial = splits > 1 ? (float*)splitk_ws : nullptr;
   p.epi = to_device_epilogue(epi);
   {
-    static int ablate = -1;
+    static int ablate = -1, stages = -1;
     if (ablate < 0) {
       const char* e = getenv("LR2_GEMM_ABLATE");
       ablate = e ? atoi(e) : 0;
+      const char* st = getenv("LR2_GEMM_DMA_STAGES");
+      stages = st ? atoi(st) : 1;   // measured: one image + 2 workgroups/CU beats two images + 1 workgroup/CU
     }
     p.ablate = ablate;
+    p.dma_stages = stages == 1 ? 1 : 2;
   }
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (!trans_a && !trans_b) rc = dispatch<false, false>(p, splits, block_m, passes, s);
-  else if (!trans_a && trans_b) rc = dispatch<false, true>(p, splits, block_m, passes, s);
-  else if (trans_a && trans_b) rc = dispatch<true, true>(p, splits, block_m, passes, s);
-  else return LR2_ERR_ARG;  // (1,0) is not a form the path needs
+  if (a_planes && b_planes) rc = dispatch_form<true, true>(p, splits, block_m, passes, trans_a, trans_b, s);
+  else if (a_planes) rc = dispatch_form<true, false>(p, splits, block_m, passes, trans_a, trans_b, s);
+  else rc = dispatch_form<false, false>(p, splits, block_m, passes, trans_a, trans_b, s);
   if (rc) return rc;
   if (splits > 1) {
-    const size_t total = (size_t)M * N;
-    int blocks = (int)((total + 255) / 256);
+    const size_t total4 = (size_t)M * N / 4;
+    int blocks = (int)((total4 + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     LR2_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)splitk_ws, splits, M, N, p.epi);
     if (lr2_launch_status(__func__)) return LR2_ERR_LAUNCH;

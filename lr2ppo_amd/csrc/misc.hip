@@ -42,15 +42,36 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __res
   }
 }
 
-__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,
-                                                        int D, int group, uint64_t gstride, uint64_t off) {
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes,
+                                                        size_t lo_off, int rows, int D, int group, uint64_t gstride,
+                                                        uint64_t off) {
   const int d4 = D / 4;
   const size_t total = (size_t)rows * d4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int r = (int)(i / d4), c = (int)(i % d4) * 4;
     const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * D + c);
-    *reinterpret_cast<float4*>(dst + (size_t)(r / group) * gstride + (size_t)(r % group) * D + off + c) = v;
+    const size_t o = (size_t)(r / group) * gstride + (size_t)(r % group) * D + off + c;
+    if (planes) store_planes4(reinterpret_cast<bf16_t*>(dst) + o, lo_off, v);
+    else *reinterpret_cast<float4*>(dst + o) = v;
   }
+}
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                           size_t lo_off, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+    store_planes4(dst + i * 4, lo_off, reinterpret_cast<const float4*>(src)[i]);
+}
+
+struct SplitChunk {
+  const float* src;
+  bf16_t* dst_hi;
+  uint64_t lo_off;
+  uint64_t count;
+};
+__global__ __launch_bounds__(256) void split_planes_multi_kernel(const SplitChunk* __restrict__ table) {
+  const SplitChunk c = table[blockIdx.x];
+  const size_t n4 = c.count / 4;
+  for (size_t i = threadIdx.x; i < n4; i += 256) store_planes4(c.dst_hi + i * 4, c.lo_off, reinterpret_cast<const float4*>(c.src)[i]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -407,12 +428,27 @@ extern "C" int lr2_gather_rows_bwd(const void* ddst, const int64_t* index, void*
   CHECK_LAUNCH();
 }
 
-extern "C" int lr2_copy_rows(const void* src, void* dst, int rows, int D, int group, uint64_t dst_gstride,
-                             uint64_t dst_off, void* stream) {
+extern "C" int lr2_copy_rows(const void* src, void* dst, int dst_planes, uint64_t dst_lo_off, int rows, int D, int group,
+                             uint64_t dst_gstride, uint64_t dst_off, void* stream) {
   if (!src || !dst || rows <= 0 || D <= 0 || group <= 0) return LR2_ERR_ARG;
   if (D % 4 || dst_gstride % 4 || dst_off % 4) return LR2_ERR_SHAPE;
   LR2_LAUNCH(copy_rows_kernel, dim3(grid_for((size_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)src, (float*)dst, rows, D, group, dst_gstride, dst_off);
+             (const float*)src, (float*)dst, dst_planes, (size_t)dst_lo_off, rows, D, group, dst_gstride, dst_off);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_split_planes(const void* src, void* dst_hi, uint64_t lo_off, uint64_t n, void* stream) {
+  if (!src || !dst_hi || n == 0) return LR2_ERR_ARG;
+  if (n % 4 || lo_off % 4) return LR2_ERR_SHAPE;
+  LR2_LAUNCH(split_planes_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)src,
+             (bf16_t*)dst_hi, (size_t)lo_off, (size_t)(n / 4));
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_split_planes_multi(const lr2_split_chunk* table_dev, int n_chunks, void* stream) {
+  static_assert(sizeof(lr2_split_chunk) == sizeof(SplitChunk), "chunk layout");
+  if (!table_dev || n_chunks <= 0) return LR2_ERR_ARG;
+  LR2_LAUNCH(split_planes_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const SplitChunk*)table_dev);
   CHECK_LAUNCH();
 }
 

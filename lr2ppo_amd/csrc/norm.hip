@@ -15,6 +15,7 @@ __device__ __forceinline__ size_t mapped_row_offset(int r, int group, uint64_t g
 
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ out,
+                                                            bf16_t* __restrict__ out_hi, size_t out_lo_off,
                                                             float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out, int rows, int D, float eps,
                                                             int mode, int group, uint64_t group_stride) {
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       y.y = (v[i].y - mean) * rstd * g.y + b.y;
       y.z = (v[i].z - mean) * rstd * g.z + b.z;
       y.w = (v[i].w - mean) * rstd * g.w + b.w;
-      *reinterpret_cast<float4*>(out + off + e) = y;
+      if (out) *reinterpret_cast<float4*>(out + off + e) = y;
+      if (out_hi) store_planes4(out_hi + off + e, out_lo_off, y);
     }
   }
 }
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const float* __restrict__ resid_grad, float* __restrict__ dx_f32,
-                                                            float* __restrict__ dx_masked, float drop_scale, uint32_t drop_thr,
+                                                            bf16_t* __restrict__ dxm_hi, size_t dxm_lo_off, float drop_scale, uint32_t drop_thr,
                                                             uint64_t drop_key, float* __restrict__ partials, int rows, int D) {
   __shared__ float red[4][2][MAXV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
           d.x += rg.x; d.y += rg.y; d.z += rg.z; d.w += rg.w;
         }
         if (dx_f32) *reinterpret_cast<float4*>(dx_f32 + o) = d;
-        if (dx_masked) {
+        if (dxm_hi) {
           float4 m = d;
           if (drop_scale != 0.f) {
             m.x = dropout_keep(drop_key, o + 0, drop_thr) ? d.x * drop_scale : 0.f;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             m.z = dropout_keep(drop_key, o + 2, drop_thr) ? d.z * drop_scale : 0.f;
             m.w = dropout_keep(drop_key, o + 3, drop_thr) ? d.w * drop_scale : 0.f;
           }
-          *reinterpret_cast<float4*>(dx_masked + o) = m;
+          store_planes4(dxm_hi + o, dxm_lo_off, m);
         }
       }
     }
@@ -169,8 +171,9 @@ __global__ __launch_bounds__(256) void partials_finish_kernel(const float* __res
   }
 }
 
-// thread <-> 4 adjacent columns, block <-> 1024 columns x one row chunk
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int rows, int cols, int ld,
+// thread <-> 4 adjacent columns, block <-> 1024 columns x one row chunk; fp32 input or bf16 hi/lo planes
+template <bool PLANES>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x_, size_t lo_off, int rows, int cols, int ld,
                                                      float* __restrict__ partials) {
   const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (c >= cols) return;
@@ -180,30 +183,40 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   if (r1 > rows) r1 = rows;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int r = r0; r < r1; ++r) {
-    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ld + c);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    if (PLANES) {
+      const bf16_t* p = (const bf16_t*)x_ + (size_t)r * ld + c;
+      const u32x2_t h = *reinterpret_cast<const u32x2_t*>(p), l = *reinterpret_cast<const u32x2_t*>(p + lo_off);
+      s.x += __uint_as_float(h[0] << 16) + __uint_as_float(l[0] << 16);
+      s.y += __uint_as_float(h[0] & 0xffff0000u) + __uint_as_float(l[0] & 0xffff0000u);
+      s.z += __uint_as_float(h[1] << 16) + __uint_as_float(l[1] << 16);
+      s.w += __uint_as_float(h[1] & 0xffff0000u) + __uint_as_float(l[1] & 0xffff0000u);
+    } else {
+      const float4 v = *reinterpret_cast<const float4*>((const float*)x_ + (size_t)r * ld + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
   *reinterpret_cast<float4*>(partials + (size_t)blockIdx.y * cols + c) = s;
 }
 
 }  // namespace
 
-extern "C" int lr2_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* out, void* mean, void* rstd,
-                                 int rows, int D, float eps, int mode, int group, uint64_t group_stride, void* stream) {
-  if (!x || !gamma || !beta || !out || rows <= 0) return LR2_ERR_ARG;
+extern "C" int lr2_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* out, void* out_hi,
+                                 uint64_t out_lo_off, void* mean, void* rstd, int rows, int D, float eps, int mode,
+                                 int group, uint64_t group_stride, void* stream) {
+  if (!x || !gamma || !beta || (!out && !out_hi) || rows <= 0) return LR2_ERR_ARG;
   if (D % 4 != 0 || D > MAXV * 256 || D < 4) return LR2_ERR_SHAPE;
   if (group <= 0) { group = rows; group_stride = 0; }
   LR2_LAUNCH(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                     (const float*)gamma, (const float*)beta, (float*)out, (float*)mean, (float*)rstd, rows, D, eps,
-                     mode, group, group_stride);
+             (const float*)gamma, (const float*)beta, (float*)out, (bf16_t*)out_hi, (size_t)out_lo_off, (float*)mean,
+             (float*)rstd, rows, D, eps, mode, group, group_stride);
   return lr2_launch_status(__func__);
 }
 
 extern "C" int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_stride, const void* x, const void* gamma,
-                                 const void* mean, const void* rstd, const void* resid_grad, void* dx, void* dx_masked,
-                                 float drop_p, uint64_t drop_seed, uint32_t drop_site, void* partials, int nblocks,
-                                 int rows, int D, void* stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !partials || (!dx && !dx_masked) || rows <= 0 || nblocks <= 0)
+                                 const void* mean, const void* rstd, const void* resid_grad, void* dx, void* dxm_hi,
+                                 uint64_t dxm_lo_off, float drop_p, uint64_t drop_seed, uint32_t drop_site, void* partials,
+                                 int nblocks, int rows, int D, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !partials || (!dx && !dxm_hi) || rows <= 0 || nblocks <= 0)
     return LR2_ERR_ARG;
   if (D % 4 != 0 || D > MAXV * 256 || D < 4) return LR2_ERR_SHAPE;
   if (group <= 0) { group = rows; group_stride = 0; }
@@ -215,9 +228,9 @@ extern "C" int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_strid
     thr = dropout_threshold(drop_p);
     key = (((uint64_t)drop_site) << 40) ^ (drop_seed * 0x9E3779B97F4A7C15ull);
   }
-  LR2_LAUNCH(layernorm_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, group,
-                     group_stride, (const float*)x, (const float*)gamma, (const float*)mean, (const float*)rstd,
-                     (const float*)resid_grad, (float*)dx, (float*)dx_masked, scale, thr, key, (float*)partials, rows, D);
+  LR2_LAUNCH(layernorm_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, group, group_stride,
+             (const float*)x, (const float*)gamma, (const float*)mean, (const float*)rstd, (const float*)resid_grad,
+             (float*)dx, (bf16_t*)dxm_hi, (size_t)dxm_lo_off, scale, thr, key, (float*)partials, rows, D);
   return lr2_launch_status(__func__);
 }
 
@@ -229,14 +242,16 @@ extern "C" int lr2_colsum_partials_finish(const void* partials, int nblocks, int
   return lr2_launch_status(__func__);
 }
 
-extern "C" int lr2_colsum(const void* x, int rows, int cols, int ld, void* partials, int nblocks, void* out,
-                          void* stream) {
+extern "C" int lr2_colsum(const void* x, int is_planes, uint64_t lo_off, int rows, int cols, int ld, void* partials,
+                          int nblocks, void* out, void* stream) {
   if (!x || !partials || !out || rows <= 0 || cols <= 0 || nblocks <= 0) return LR2_ERR_ARG;
   if (cols % 4 != 0 || ld % 4 != 0) return LR2_ERR_SHAPE;
   if (nblocks > rows) nblocks = rows;
   dim3 grid((cols + 1023) / 1024, nblocks);
-  LR2_LAUNCH(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, cols, ld,
-                     (float*)partials);
+  if (is_planes)
+    LR2_LAUNCH(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, (size_t)lo_off, rows, cols, ld, (float*)partials);
+  else
+    LR2_LAUNCH(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, (size_t)0, rows, cols, ld, (float*)partials);
   if (lr2_launch_status(__func__)) return LR2_ERR_LAUNCH;
   return lr2_colsum_partials_finish(partials, nblocks, cols, cols, out, 0, stream);
 }

@@ -6,16 +6,22 @@ activations in a grow-only workspace (288 GB of HBM: nothing is re-allocated on 
 one kernel launch per fused group, gradients written straight into persistent fp32 grad buffers.
 The same schedule is used by the autograd wrapper (drop-in nn.Module path) and by train_model/bench.
 
-Everything is fp32 in HBM; GEMMs run as split-bf16 on MFMA (ops.gemm).
+Numerics: everything the reference keeps in fp32 is fp32 here (parameters, optimizer state, residual stream,
+pre-activations, attention inputs, gradients).  Tensors whose ONLY consumers are GEMMs are stored as bf16 hi/lo
+"planes" (ops.Planes: x = hi + lo, same bytes as fp32) by the kernel that produces them -- LayerNorm outputs, GELU
+outputs, attention outputs, masked gradients, and a per-forward split of the (small) token-GEMM weights -- so the
+split-bf16 GEMMs stream their operands by LDS-DMA with no conversion work.  The 2 GB out_layer.fc1 weight is read as
+fp32 and split inside the GEMM (it is streamed exactly once per pass; a split copy would double optimizer traffic).
 """
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import torch
 
-from . import ops
+from . import _native, ops
+from .ops import Planes
 
 SEQ_LEN = 196   # hard-coded in the reference (finetune/ppo.py:219-220)
 XIT_HEADS = 8   # finetune/xit.py:114
@@ -23,7 +29,7 @@ DROP_P = 0.1    # finetune/xit.py:26-28
 
 
 class Workspace:
-    """Named grow-only fp32 device buffers."""
+    """Named grow-only device buffers (fp32 matrices and bf16-planes matrices)."""
 
     def __init__(self, device):
         self.device = device
@@ -39,8 +45,18 @@ class Workspace:
     def mat(self, name: str, rows: int, cols: int) -> torch.Tensor:
         return self.vec(name, rows * cols).view(rows, cols)
 
+    def planes(self, name: str, rows: int, cols: int) -> Planes:
+        """[2][rows][cols] bf16 (hi plane, lo plane) -- the same bytes as mat(name, rows, cols)."""
+        key = "pl:" + name
+        b = self._bufs.get(key)
+        need = 2 * rows * cols
+        if b is None or b.numel() < need:
+            b = torch.empty(max(need, 8), dtype=torch.int16, device=self.device)
+            self._bufs[key] = b
+        return Planes(b, rows, cols)
+
     def bytes(self) -> int:
-        return sum(b.numel() * 4 for b in self._bufs.values())
+        return sum(b.numel() * b.element_size() for b in self._bufs.values())
 
     def release(self):
         self._bufs.clear()
@@ -56,13 +72,75 @@ class DropCfg:
         return ops.Drop(self.p, self.seed, self.site_base + i) if self.p > 0 else None
 
 
+class WeightPlanes:
+    """bf16 hi/lo planes of a model's GEMM weights, re-split from the fp32 parameters by ONE kernel launch at the
+    start of every forward (19 M parameters: ~30 us) -- no cache to invalidate when an optimizer, load_state_dict or
+    the user changes the parameters."""
+
+    CHUNK = 1 << 16
+
+    def __init__(self, named: Dict[str, torch.Tensor], names: List[str]):
+        import ctypes as C
+        dev = named[names[0]].device
+        total = sum(2 * named[n].numel() for n in names)
+        self.buf = torch.empty(total, dtype=torch.int16, device=dev)
+        self.planes: Dict[str, Planes] = {}
+        self._sig = tuple((n, named[n].data_ptr()) for n in names)
+        rows, off = [], 0
+        for n in names:
+            w = named[n]
+            if w.dim() != 2 or not w.is_contiguous() or w.numel() % 4:
+                raise ValueError(f"weight {n} must be a contiguous 2-D tensor")
+            k = w.numel()
+            self.planes[n] = Planes(self.buf[off:off + 2 * k], w.shape[0], w.shape[1])
+            hi_ptr = self.buf.data_ptr() + 2 * off
+            o = 0
+            while o < k:
+                c = min(self.CHUNK, k - o)
+                rows.append((w.data_ptr() + 4 * o, hi_ptr + 2 * o, k, c))
+                o += c
+            off += 2 * k
+        arr = (_native.SplitChunk * len(rows))()
+        for i, (src, dst, lo, cnt) in enumerate(rows):
+            arr[i].src, arr[i].dst_hi, arr[i].lo_off, arr[i].count = src, dst, lo, cnt
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.n_chunks = len(rows)
+
+    def matches(self, named: Dict[str, torch.Tensor]) -> bool:
+        return all(n in named and named[n].data_ptr() == p for n, p in self._sig)
+
+    def refresh(self):
+        ops.split_planes_multi(self.table, self.n_chunks)
+
+
+_INPUT_PLANES: Dict[int, tuple] = {}
+
+
+def input_planes(owner: torch.Tensor, x2d: torch.Tensor) -> Planes:
+    """Planes of an external fp32 input (text / image features).  The rollout feeds the same batch tensor to actor,
+    critic and reward: the split is done once per live tensor OBJECT and version (never per address: a freed batch's
+    address is reused by the next one) and shared through a small LRU."""
+    import weakref
+    hit = _INPUT_PLANES.get(id(owner))
+    if hit is not None and hit[0]() is owner and hit[1] == owner._version and hit[2].rows == x2d.shape[0]:
+        return hit[2]
+    pl = Planes.empty(x2d.shape[0], x2d.shape[1], x2d.device)
+    ops.split_planes(x2d, pl)
+    for k in [k for k, v in _INPUT_PLANES.items() if v[0]() is None]:
+        del _INPUT_PLANES[k]
+    if len(_INPUT_PLANES) >= 8:
+        _INPUT_PLANES.pop(next(iter(_INPUT_PLANES)))
+    _INPUT_PLANES[id(owner)] = (weakref.ref(owner), owner._version, pl)
+    return pl
+
+
 def _splitk_ws(ws: Workspace, M, N, K, trans_a=False):
     bm, sp = ops.choose_tiling(M, N, K, trans_a)
     return (ws.vec("splitk", sp * M * N), sp, bm) if sp > 1 else (None, 1, bm)
 
 
 def linear_fwd(ws, x, w, b, out, M, N, K, **kw):
-    """out[M,N] = x[M,K] @ w[N,K]^T + b (+ fused epilogue)."""
+    """out[M,N] = x[M,K] @ w[N,K]^T + b (+ fused epilogue); x / w fp32 tensors or Planes."""
     skw, sp, bm = _splitk_ws(ws, M, N, K)
     return ops.gemm(x, w, out, M, N, K, bias=b, splitk_ws=skw, splits=sp, block_m=bm, **kw)
 
@@ -106,107 +184,107 @@ class XitKeys:
         self.f2_w, self.f2_b = f"{f}.1.3.weight", f"{f}.1.3.bias"
         self.lnf_w, self.lnf_b = f"{prefix}.1.0.weight", f"{prefix}.1.0.bias"
 
+    def gemm_weights(self) -> List[str]:
+        return [self.q_w, self.k_w, self.v_w, self.p_w, self.f1_w, self.f2_w]
 
-def xit_forward(ws: Workspace, tag: str, P: Dict[str, torch.Tensor], keys: XitKeys, x: torch.Tensor, y: torch.Tensor,
-                batch: int, Lq: int, Lk: int, E: int, out: torch.Tensor, *, save: bool, drop: Optional[DropCfg] = None,
+
+def xit_forward(ws: Workspace, tag: str, P, W: Dict[str, Planes], keys: XitKeys, x: torch.Tensor, y: torch.Tensor,
+                batch: int, Lq: int, Lk: int, E: int, out, *, save: bool, drop: Optional[DropCfg] = None,
                 out_group: int = 0, out_gstride: int = 0, heads: int = XIT_HEADS):
-    """x: [batch*Lq, E] residual stream, y: [batch*Lk, E]; writes LN_final(block(x, y)) to `out`
-    (row r at out + (r//out_group)*out_gstride + (r%out_group)*E when out_group>0)."""
+    """x: [batch*Lq, E] fp32 residual stream, y: [batch*Lk, E] fp32; W: weight planes.  Writes LN_final(block(x, y)) to
+    `out` (fp32 tensor or Planes; row r at (r//out_group)*out_gstride + (r%out_group)*E when out_group>0)."""
     Mq, Mk, F = batch * Lq, batch * Lk, 4 * E
     hd = E // heads
     t = tag
     d0 = drop.site(0) if drop else None
     d1 = drop.site(1) if drop else None
     d2 = drop.site(2) if drop else None
-    xn, yn = ws.mat(t + "xn", Mq, E), ws.mat(t + "yn", Mk, E)
+    xn, yn = ws.planes(t + "xn", Mq, E), ws.planes(t + "yn", Mk, E)
     st = {n: ws.vec(t + n, r) for n, r in (("mx", Mq), ("rx", Mq), ("my", Mk), ("ry", Mk), ("m1", Mq), ("r1", Mq),
                                            ("mf", Mq), ("rf", Mq))}
-    ops.layernorm_fwd(x, P[keys.ln_x_w], P[keys.ln_x_b], xn, st["mx"], st["rx"], rows=Mq, D=E)
-    ops.layernorm_fwd(y, P[keys.ln_y_w], P[keys.ln_y_b], yn, st["my"], st["ry"], rows=Mk, D=E)
+    ops.layernorm_fwd(x, P[keys.ln_x_w], P[keys.ln_x_b], None, st["mx"], st["rx"], rows=Mq, D=E, out_planes=xn)
+    ops.layernorm_fwd(y, P[keys.ln_y_w], P[keys.ln_y_b], None, st["my"], st["ry"], rows=Mk, D=E, out_planes=yn)
     q, k, v = ws.mat(t + "q", Mq, E), ws.mat(t + "k", Mk, E), ws.mat(t + "v", Mk, E)
-    linear_fwd(ws, xn, P[keys.q_w], P[keys.q_b], q, Mq, E, E)
-    linear_fwd(ws, yn, P[keys.k_w], P[keys.k_b], k, Mk, E, E)
-    linear_fwd(ws, yn, P[keys.v_w], P[keys.v_b], v, Mk, E, E)
-    o = ws.mat(t + "o", Mq, E)
+    linear_fwd(ws, xn, W[keys.q_w], P[keys.q_b], q, Mq, E, E)
+    linear_fwd(ws, yn, W[keys.k_w], P[keys.k_b], k, Mk, E, E)
+    linear_fwd(ws, yn, W[keys.v_w], P[keys.v_b], v, Mk, E, E)
+    o = ws.planes(t + "o", Mq, E)
     ops.xattn_fwd(q, k, v, o, batch=batch, heads=heads, Lq=Lq, Lk=Lk, head_dim=hd, post_scale=1.0 / math.sqrt(E))
     x1 = ws.mat(t + "x1", Mq, E)
-    linear_fwd(ws, o, P[keys.p_w], P[keys.p_b], x1, Mq, E, E, drop=d0, resid=x)
-    x1n = ws.mat(t + "x1n", Mq, E)
-    ops.layernorm_fwd(x1, P[keys.ln2_w], P[keys.ln2_b], x1n, st["m1"], st["r1"], rows=Mq, D=E)
-    hf = ws.mat(t + "hf", Mq, F)
+    linear_fwd(ws, o, W[keys.p_w], P[keys.p_b], x1, Mq, E, E, drop=d0, resid=x)
+    x1n = ws.planes(t + "x1n", Mq, E)
+    ops.layernorm_fwd(x1, P[keys.ln2_w], P[keys.ln2_b], None, st["m1"], st["r1"], rows=Mq, D=E, out_planes=x1n)
+    hf = ws.planes(t + "hf", Mq, F)
     zf = ws.mat(t + "zf", Mq, F) if save else None
-    linear_fwd(ws, x1n, P[keys.f1_w], P[keys.f1_b], hf, Mq, F, E, act=1, out_z=zf, drop=d1)
+    linear_fwd(ws, x1n, W[keys.f1_w], P[keys.f1_b], None, Mq, F, E, act=1, out_z=zf, drop=d1, out_planes=hf)
     x2 = ws.mat(t + "x2", Mq, E)
-    linear_fwd(ws, hf, P[keys.f2_w], P[keys.f2_b], x2, Mq, E, F, drop=d2, resid=x1)
-    ops.layernorm_fwd(x2, P[keys.lnf_w], P[keys.lnf_b], out, st["mf"], st["rf"], rows=Mq, D=E, group=out_group,
-                      group_stride=out_gstride)
+    linear_fwd(ws, hf, W[keys.f2_w], P[keys.f2_b], x2, Mq, E, F, drop=d2, resid=x1)
+    out_pl = out if isinstance(out, Planes) else None
+    ops.layernorm_fwd(x2, P[keys.lnf_w], P[keys.lnf_b], None if out_pl else out, st["mf"], st["rf"], rows=Mq, D=E,
+                      group=out_group, group_stride=out_gstride, out_planes=out_pl)
     return out
 
 
-def xit_backward(ws: Workspace, tag: str, P, G, keys: XitKeys, x, y, d_out, batch, Lq, Lk, E, dx_out, dy_out, *,
+def xit_backward(ws: Workspace, tag: str, P, W, G, keys: XitKeys, x, y, d_out, batch, Lq, Lk, E, dx_out, dy_out, *,
                  drop: Optional[DropCfg] = None, out_group=0, out_gstride=0, dy_extra=None, heads: int = XIT_HEADS,
-                 same_xy: bool = False):
-    """Backward of xit_forward.  d_out has the (out_group, out_gstride) row mapping of the forward output.
-    dx_out <- dL/dx, dy_out <- dL/dy (+ dy_extra).  With same_xy (x is y, the `xitt` self-attention of
-    finetune/ppo.py:290) only dx_out is produced and holds the sum.  Parameter grads go to G[name]."""
+                 same_xy: bool = False, dx_planes: Optional[Planes] = None, dy_planes: Optional[Planes] = None):
+    """Backward of xit_forward.  d_out (fp32) has the (out_group, out_gstride) row mapping of the forward output.
+    dx_out <- dL/dx, dy_out <- dL/dy (+ dy_extra), both fp32; dx_planes / dy_planes additionally receive them as planes
+    (operands of the caller's next GEMMs).  With same_xy (x is y, the `xitt` self-attention of finetune/ppo.py:290) only
+    dx_out is produced and holds the sum.  Parameter grads go to G[name]."""
     Mq, Mk, F = batch * Lq, batch * Lk, 4 * E
     hd = E // heads
     t = tag
     d0 = drop.site(0) if drop else None
     d1 = drop.site(1) if drop else None
     d2 = drop.site(2) if drop else None
-    g = lambda n: ws.mat(t + n, *_shape(n, Mq, Mk, E, F))  # noqa: E731
     st = lambda n, r: ws.vec(t + n, r)  # noqa: E731
-    xn, yn, q, k, v, o = g("xn"), g("yn"), g("q"), g("k"), g("v"), g("o")
-    x1, x1n, hf, zf, x2 = g("x1"), g("x1n"), g("hf"), g("zf"), g("x2")
+    xn, yn, o = ws.planes(t + "xn", Mq, E), ws.planes(t + "yn", Mk, E), ws.planes(t + "o", Mq, E)
+    x1n, hf = ws.planes(t + "x1n", Mq, E), ws.planes(t + "hf", Mq, F)
+    q, k, v = ws.mat(t + "q", Mq, E), ws.mat(t + "k", Mk, E), ws.mat(t + "v", Mk, E)
+    x1, zf, x2 = ws.mat(t + "x1", Mq, E), ws.mat(t + "zf", Mq, F), ws.mat(t + "x2", Mq, E)
     # final LN
     dx2 = ws.mat(t + "dx2", Mq, E)
-    dx2m = ws.mat(t + "dxm", Mq, E) if d2 else None
+    dF2 = ws.planes(t + "dxm", Mq, E)
     _ln_bwd(ws, d_out, x2, P[keys.lnf_w], st("mf", Mq), st("rf", Mq), dx2, G[keys.lnf_w], G[keys.lnf_b], Mq, E,
-            group=out_group, group_stride=out_gstride, dx_masked=dx2m, drop=d2)
-    dF2 = dx2m if d2 else dx2
+            group=out_group, group_stride=out_gstride, dx_planes=dF2, drop=d2)
     # FFN
     linear_wgrad(ws, dF2, hf, G[keys.f2_w], G[keys.f2_b], Mq, F, E)
-    dzf = ws.mat(t + "dzf", Mq, F)
-    linear_dgrad(ws, dF2, P[keys.f2_w], dzf, Mq, F, E, act=2, aux_z=zf, drop=d1)
+    dzf = ws.planes(t + "dzf", Mq, F)
+    linear_dgrad(ws, dF2, W[keys.f2_w], None, Mq, F, E, act=2, aux_z=zf, drop=d1, out_planes=dzf)
     linear_wgrad(ws, dzf, x1n, G[keys.f1_w], G[keys.f1_b], Mq, E, F)
     dx1n = ws.mat(t + "dtmp", Mq, E)
-    linear_dgrad(ws, dzf, P[keys.f1_w], dx1n, Mq, E, F)
+    linear_dgrad(ws, dzf, W[keys.f1_w], dx1n, Mq, E, F)
     dx1 = ws.mat(t + "dx1", Mq, E)
-    dx1m = ws.mat(t + "dxm", Mq, E) if d0 else None
+    dA = ws.planes(t + "dxm", Mq, E)
     _ln_bwd(ws, dx1n, x1, P[keys.ln2_w], st("m1", Mq), st("r1", Mq), dx1, G[keys.ln2_w], G[keys.ln2_b], Mq, E,
-            resid_grad=dx2, dx_masked=dx1m, drop=d0)
-    dA = dx1m if d0 else dx1
+            resid_grad=dx2, dx_planes=dA, drop=d0)
     # attention
     linear_wgrad(ws, dA, o, G[keys.p_w], G[keys.p_b], Mq, E, E)
     do = ws.mat(t + "dtmp", Mq, E)
-    linear_dgrad(ws, dA, P[keys.p_w], do, Mq, E, E)
-    dq, dk, dv = ws.mat(t + "dq", Mq, E), ws.mat(t + "dk", Mk, E), ws.mat(t + "dv", Mk, E)
+    linear_dgrad(ws, dA, W[keys.p_w], do, Mq, E, E)
+    dq, dk, dv = ws.planes(t + "dq", Mq, E), ws.planes(t + "dk", Mk, E), ws.planes(t + "dv", Mk, E)
     ops.xattn_bwd(q, k, v, do, dq, dk, dv, batch=batch, heads=heads, Lq=Lq, Lk=Lk, head_dim=hd,
                   post_scale=1.0 / math.sqrt(E))
     linear_wgrad(ws, dq, xn, G[keys.q_w], G[keys.q_b], Mq, E, E)
     linear_wgrad(ws, dk, yn, G[keys.k_w], G[keys.k_b], Mk, E, E)
     linear_wgrad(ws, dv, yn, G[keys.v_w], G[keys.v_b], Mk, E, E)
     dxn = ws.mat(t + "dtmp", Mq, E)
-    linear_dgrad(ws, dq, P[keys.q_w], dxn, Mq, E, E)
+    linear_dgrad(ws, dq, W[keys.q_w], dxn, Mq, E, E)
     dyn = ws.mat(t + "dyn", Mk, E)
-    linear_dgrad(ws, dk, P[keys.k_w], dyn, Mk, E, E)
-    linear_dgrad(ws, dv, P[keys.v_w], dyn, Mk, E, E, accumulate=True)
-    _ln_bwd(ws, dxn, x, P[keys.ln_x_w], st("mx", Mq), st("rx", Mq), dx_out, G[keys.ln_x_w], G[keys.ln_x_b], Mq, E,
-            resid_grad=dx1)
+    linear_dgrad(ws, dk, W[keys.k_w], dyn, Mk, E, E)
+    linear_dgrad(ws, dv, W[keys.v_w], dyn, Mk, E, E, accumulate=True)
     if same_xy:
-        dsum = ws.mat(t + "dsum", Mq, E)
-        _ln_bwd(ws, dyn, y, P[keys.ln_y_w], st("my", Mk), st("ry", Mk), dsum, G[keys.ln_y_w], G[keys.ln_y_b], Mk, E,
-                resid_grad=dx_out)
-        dx_out.copy_(dsum)
+        dpart = ws.mat(t + "dpart", Mq, E)
+        _ln_bwd(ws, dxn, x, P[keys.ln_x_w], st("mx", Mq), st("rx", Mq), dpart, G[keys.ln_x_w], G[keys.ln_x_b], Mq, E,
+                resid_grad=dx1)
+        _ln_bwd(ws, dyn, y, P[keys.ln_y_w], st("my", Mk), st("ry", Mk), dx_out, G[keys.ln_y_w], G[keys.ln_y_b], Mk, E,
+                resid_grad=dpart, dx_planes=dx_planes)
     else:
+        _ln_bwd(ws, dxn, x, P[keys.ln_x_w], st("mx", Mq), st("rx", Mq), dx_out, G[keys.ln_x_w], G[keys.ln_x_b], Mq, E,
+                resid_grad=dx1, dx_planes=dx_planes)
         _ln_bwd(ws, dyn, y, P[keys.ln_y_w], st("my", Mk), st("ry", Mk), dy_out, G[keys.ln_y_w], G[keys.ln_y_b], Mk, E,
-                resid_grad=dy_extra)
-
-
-def _shape(n, Mq, Mk, E, F):
-    return {"xn": (Mq, E), "yn": (Mk, E), "q": (Mq, E), "k": (Mk, E), "v": (Mk, E), "o": (Mq, E), "x1": (Mq, E),
-            "x1n": (Mq, E), "hf": (Mq, F), "zf": (Mq, F), "x2": (Mq, E)}[n]
+                resid_grad=dy_extra, dx_planes=dy_planes)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -214,6 +292,9 @@ def _shape(n, Mq, Mk, E, F):
 # ---------------------------------------------------------------------------------------------
 XIT = XitKeys("xit")
 XITT = XitKeys("xitt")
+TRUNK_GEMM_WEIGHTS = ["text_proj.fc1.weight", "text_proj.fc2.weight", "img_proj.fc1.weight", "img_proj.fc2.weight",
+                      "out_layer.fc2.weight"] + XIT.gemm_weights()
+FC1 = "out_layer.fc1.weight"   # 2 GB: stays fp32, split inside the GEMM
 
 
 def _img_shared(img_emb: torch.Tensor) -> bool:
@@ -222,24 +303,24 @@ def _img_shared(img_emb: torch.Tensor) -> bool:
     return img_emb.dim() == 3 or (img_emb.dim() == 4 and img_emb.stride(1) == 0)
 
 
-def trunk_forward(ws: Workspace, P, text: torch.Tensor, img: torch.Tensor, bs: int, tags: int, n_img: int, E: int, *,
-                  save: bool, drop: Optional[DropCfg] = None, img_shared: bool = False) -> torch.Tensor:
-    """text: [bs*tags*196, E] fp32; img: [bs*tags*n_img, E] (or [bs*n_img, E] when img_shared).
-    Returns g2 [bs*tags, E] = out_layer(concat(xit(text_proj, img_proj), img_proj))."""
+def trunk_forward(ws: Workspace, P, W, text, img, bs: int, tags: int, n_img: int, E: int, *, save: bool,
+                  drop: Optional[DropCfg] = None, img_shared: bool = False) -> torch.Tensor:
+    """text: Planes [bs*tags*196, E]; img: Planes [bs*tags*n_img, E] (or [bs*n_img, E] when img_shared).
+    Returns g2 [bs*tags, E] (fp32) = out_layer(concat(xit(text_proj, img_proj), img_proj))."""
     N = bs * tags
     Mt, F = N * SEQ_LEN, 4 * E
     Mi_src = (bs if img_shared else N) * n_img
     Mi = N * n_img
-    h1 = ws.mat("h1", Mt, F)
+    h1 = ws.planes("h1", Mt, F)
     z1 = ws.mat("z1", Mt, F) if save else None
-    linear_fwd(ws, text, P["text_proj.fc1.weight"], P["text_proj.fc1.bias"], h1, Mt, F, E, act=1, out_z=z1)
+    linear_fwd(ws, text, W["text_proj.fc1.weight"], P["text_proj.fc1.bias"], None, Mt, F, E, act=1, out_z=z1, out_planes=h1)
     tf = ws.mat("tf", Mt, E)
-    linear_fwd(ws, h1, P["text_proj.fc2.weight"], P["text_proj.fc2.bias"], tf, Mt, E, F)
-    hi = ws.mat("hi", Mi_src, F)
+    linear_fwd(ws, h1, W["text_proj.fc2.weight"], P["text_proj.fc2.bias"], tf, Mt, E, F)
+    hi = ws.planes("hi", Mi_src, F)
     zi = ws.mat("zi", Mi_src, F) if save else None
-    linear_fwd(ws, img, P["img_proj.fc1.weight"], P["img_proj.fc1.bias"], hi, Mi_src, F, E, act=1, out_z=zi)
+    linear_fwd(ws, img, W["img_proj.fc1.weight"], P["img_proj.fc1.bias"], None, Mi_src, F, E, act=1, out_z=zi, out_planes=hi)
     imf_src = ws.mat("imf_src", Mi_src, E)
-    linear_fwd(ws, hi, P["img_proj.fc2.weight"], P["img_proj.fc2.bias"], imf_src, Mi_src, E, F)
+    linear_fwd(ws, hi, W["img_proj.fc2.weight"], P["img_proj.fc2.bias"], imf_src, Mi_src, E, F)
     if img_shared and tags > 1:
         imf = ws.mat("imf", Mi, E)       # replicate the projected image tokens over tags (cheap: [N*n_img, E])
         ops.gather_rows(imf_src, None, imf.view(bs, tags, n_img * E), B=bs, t_in=1, t_out=tags, row_elems=n_img * E,
@@ -247,58 +328,63 @@ def trunk_forward(ws: Workspace, P, text: torch.Tensor, img: torch.Tensor, bs: i
     else:
         imf = imf_src
     Wflat = (SEQ_LEN + n_img) * E
-    flat = ws.mat("flat", N, Wflat)
+    flat = ws.planes("flat", N, Wflat)
     ops.copy_rows(imf, flat, rows=Mi, D=E, group=n_img, dst_gstride=Wflat, dst_off=SEQ_LEN * E)
-    xit_forward(ws, "xit.", P, XIT, tf, imf, N, SEQ_LEN, n_img, E, flat, save=save, drop=drop, out_group=SEQ_LEN,
+    xit_forward(ws, "xit.", P, W, XIT, tf, imf, N, SEQ_LEN, n_img, E, flat, save=save, drop=drop, out_group=SEQ_LEN,
                 out_gstride=Wflat)
-    g1 = ws.mat("g1", N, F)
+    g1 = ws.planes("g1", N, F)
     zo = ws.mat("zo", N, F) if save else None
-    linear_fwd(ws, flat, P["out_layer.fc1.weight"], P["out_layer.fc1.bias"], g1, N, F, Wflat, act=1, out_z=zo)
+    linear_fwd(ws, flat, P[FC1], P["out_layer.fc1.bias"], None, N, F, Wflat, act=1, out_z=zo, out_planes=g1)
     g2 = ws.mat("g2", N, E)
-    linear_fwd(ws, g1, P["out_layer.fc2.weight"], P["out_layer.fc2.bias"], g2, N, E, F)
+    linear_fwd(ws, g1, W["out_layer.fc2.weight"], P["out_layer.fc2.bias"], g2, N, E, F)
     return g2
 
 
-def trunk_backward(ws: Workspace, P, G, text, img, dg2, bs, tags, n_img, E, *, drop: Optional[DropCfg] = None,
+def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *, drop: Optional[DropCfg] = None,
                    img_shared: bool = False):
     """Backward of trunk_forward(save=True); fills G[...] for every trunk parameter (inputs get no gradient:
-    text/img embeddings are data, finetune/ppo.py:827-835)."""
+    text/img embeddings are data, finetune/ppo.py:827-835).  dg2: fp32 [bs*tags, E]."""
     N = bs * tags
     Mt, F = N * SEQ_LEN, 4 * E
     Mi_src = (bs if img_shared else N) * n_img
     Mi = N * n_img
     Wflat = (SEQ_LEN + n_img) * E
-    h1, z1, tf = ws.mat("h1", Mt, F), ws.mat("z1", Mt, F), ws.mat("tf", Mt, E)
-    hi, zi = ws.mat("hi", Mi_src, F), ws.mat("zi", Mi_src, F)
+    h1, z1, tf = ws.planes("h1", Mt, F), ws.mat("z1", Mt, F), ws.mat("tf", Mt, E)
+    hi, zi = ws.planes("hi", Mi_src, F), ws.mat("zi", Mi_src, F)
     imf = ws.mat("imf", Mi, E) if (img_shared and tags > 1) else ws.mat("imf_src", Mi_src, E)
-    flat, g1, zo = ws.mat("flat", N, Wflat), ws.mat("g1", N, F), ws.mat("zo", N, F)
+    flat, g1, zo = ws.planes("flat", N, Wflat), ws.planes("g1", N, F), ws.mat("zo", N, F)
     # out_layer
-    linear_wgrad(ws, dg2, g1, G["out_layer.fc2.weight"], G["out_layer.fc2.bias"], N, F, E)
-    dzo = ws.mat("dzo", N, F)
-    linear_dgrad(ws, dg2, P["out_layer.fc2.weight"], dzo, N, F, E, act=2, aux_z=zo)
-    linear_wgrad(ws, dzo, flat, G["out_layer.fc1.weight"], G["out_layer.fc1.bias"], N, Wflat, F)
+    dg2p = ws.planes("dg2p", N, E)
+    ops.split_planes(dg2, dg2p)
+    linear_wgrad(ws, dg2p, g1, G["out_layer.fc2.weight"], G["out_layer.fc2.bias"], N, F, E)
+    dzo = ws.planes("dzo", N, F)
+    linear_dgrad(ws, dg2p, W["out_layer.fc2.weight"], None, N, F, E, act=2, aux_z=zo, out_planes=dzo)
+    linear_wgrad(ws, dzo, flat, G[FC1], G["out_layer.fc1.bias"], N, Wflat, F)
     dflat = ws.mat("dflat", N, Wflat)
-    linear_dgrad(ws, dzo, P["out_layer.fc1.weight"], dflat, N, Wflat, F)
+    linear_dgrad(ws, dzo, P[FC1], dflat, N, Wflat, F)
     # image part of the concat -> dense [Mi, E] gradient
     dimf_cat = ws.mat("dimf_cat", Mi, E)
     ops.gather_rows(dflat[:, SEQ_LEN * E:], None, dimf_cat.view(N, 1, n_img * E), B=N, t_in=1, t_out=1,
                     row_elems=n_img * E, src_bstride=Wflat, src_tstride=0)
     dtf, dimf = ws.mat("dtf", Mt, E), ws.mat("dimf", Mi, E)
-    xit_backward(ws, "xit.", P, G, XIT, tf, imf, dflat, N, SEQ_LEN, n_img, E, dtf, dimf, drop=drop, out_group=SEQ_LEN,
-                 out_gstride=Wflat, dy_extra=dimf_cat)
+    dtf_p = ws.planes("dtf_p", Mt, E)
+    shared = img_shared and tags > 1
+    dimf_p = None if shared else ws.planes("dimf_p", Mi, E)
+    xit_backward(ws, "xit.", P, W, G, XIT, tf, imf, dflat, N, SEQ_LEN, n_img, E, dtf, dimf, drop=drop, out_group=SEQ_LEN,
+                 out_gstride=Wflat, dy_extra=dimf_cat, dx_planes=dtf_p, dy_planes=dimf_p)
     # text_proj
-    linear_wgrad(ws, dtf, h1, G["text_proj.fc2.weight"], G["text_proj.fc2.bias"], Mt, F, E)
-    dz1 = ws.mat("dz1", Mt, F)
-    linear_dgrad(ws, dtf, P["text_proj.fc2.weight"], dz1, Mt, F, E, act=2, aux_z=z1)
+    linear_wgrad(ws, dtf_p, h1, G["text_proj.fc2.weight"], G["text_proj.fc2.bias"], Mt, F, E)
+    dz1 = ws.planes("dz1", Mt, F)
+    linear_dgrad(ws, dtf_p, W["text_proj.fc2.weight"], None, Mt, F, E, act=2, aux_z=z1, out_planes=dz1)
     linear_wgrad(ws, dz1, text, G["text_proj.fc1.weight"], G["text_proj.fc1.bias"], Mt, E, F)
     # img_proj
-    if img_shared and tags > 1:
+    if shared:
         dimf_src = ws.mat("dimf_src", Mi_src, E)   # sum the per-tag gradients of the shared image tokens
         ops.gather_rows_bwd(dimf.view(bs, tags, n_img * E), torch.zeros(bs, tags, dtype=torch.int64, device=ws.device),
                             dimf_src.view(bs, 1, n_img * E), B=bs, t_in=1, t_out=tags, row_elems=n_img * E)
-    else:
-        dimf_src = dimf
-    linear_wgrad(ws, dimf_src, hi, G["img_proj.fc2.weight"], G["img_proj.fc2.bias"], Mi_src, F, E)
-    dzi = ws.mat("dzi", Mi_src, F)
-    linear_dgrad(ws, dimf_src, P["img_proj.fc2.weight"], dzi, Mi_src, F, E, act=2, aux_z=zi)
+        dimf_p = ws.planes("dimf_p", Mi_src, E)
+        ops.split_planes(dimf_src, dimf_p)
+    linear_wgrad(ws, dimf_p, hi, G["img_proj.fc2.weight"], G["img_proj.fc2.bias"], Mi_src, F, E)
+    dzi = ws.planes("dzi", Mi_src, F)
+    linear_dgrad(ws, dimf_p, W["img_proj.fc2.weight"], None, Mi_src, F, E, act=2, aux_z=zi, out_planes=dzi)
     linear_wgrad(ws, dzi, img, G["img_proj.fc1.weight"], G["img_proj.fc1.bias"], Mi_src, E, F)

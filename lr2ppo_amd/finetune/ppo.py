@@ -176,6 +176,7 @@ class _Head(nn.Module):
         self.out_layer = Mlp((args.seq_length + args.max_imgs) * args.visual_feat_dim, FEAT * 4, FEAT, nn.GELU, 0)
         self.head = nn.Linear(FEAT, 1)
         self._ws: Optional[engine.Workspace] = None
+        self._wp: Optional[engine.WeightPlanes] = None
         self._G: Optional[Dict[str, torch.Tensor]] = None
         self._flat_grad: Optional[torch.Tensor] = None
         self._saved = None
@@ -188,6 +189,17 @@ class _Head(nn.Module):
 
     def _P(self) -> Dict[str, torch.Tensor]:
         return {n: p.data for n, p in self.named_parameters()}
+
+    def _weights(self, P, refresh: bool = True) -> Dict[str, ops.Planes]:
+        """bf16 hi/lo planes of the token-GEMM weights (everything but the 2 GB out_layer.fc1), re-split from the
+        fp32 parameters at the start of every forward."""
+        if self._wp is None or not self._wp.matches(P):
+            names = engine.TRUNK_GEMM_WEIGHTS + (engine.XITT.gemm_weights() if self.has_tail else [])
+            self._wp = engine.WeightPlanes(P, names)
+            refresh = True
+        if refresh:
+            self._wp.refresh()
+        return self._wp.planes
 
     GRAD_ORDER_FIRST = ("out_layer.fc2.weight", "out_layer.fc2.bias", "out_layer.fc1.weight", "out_layer.fc1.bias")
 
@@ -232,7 +244,8 @@ class _Head(nn.Module):
             img2 = (img_emb if img_emb.dim() == 3 else img_emb[:, 0]).contiguous().view(bs * n_img, FEAT)
         else:
             img2 = img_emb.contiguous().view(bs * tags * n_img, FEAT)
-        return text_emb.contiguous().view(bs * tags * SEQ_LEN, FEAT), img2, bs, tags, n_img, shared
+        text2 = text_emb.contiguous().view(bs * tags * SEQ_LEN, FEAT)
+        return engine.input_planes(text_emb, text2), engine.input_planes(img_emb, img2), bs, tags, n_img, shared
 
     def _drop_cfg(self, site_base=0):
         return runtime.next_drop(engine.DROP_P, site_base) if self.training else None
@@ -254,8 +267,9 @@ class Actor(_Head):
     def engine_forward(self, text_emb, img_emb, *, save: bool) -> torch.Tensor:
         text2, img2, bs, tags, n_img, shared = self._prep_inputs(text_emb, img_emb)
         ws, P = self._workspace(text_emb.device), self._P()
+        W = self._weights(P)
         drop = self._drop_cfg(0)
-        g2 = engine.trunk_forward(ws, P, text2, img2, bs, tags, n_img, FEAT, save=save, drop=drop, img_shared=shared)
+        g2 = engine.trunk_forward(ws, P, W, text2, img2, bs, tags, n_img, FEAT, save=save, drop=drop, img_shared=shared)
         logits = torch.empty(bs * tags, device=text_emb.device)
         ops.head_fwd(g2, P["head.weight"], P["head.bias"], logits, rows=bs * tags, D=FEAT)
         if save:
@@ -265,12 +279,13 @@ class Actor(_Head):
     def engine_backward(self, dlogits: torch.Tensor):
         """Gradients of sum(dlogits * logits) into the flat gradient buffer (call after engine_forward(save=True))."""
         text2, img2, bs, tags, n_img, shared, drop = self._saved
-        ws, P, G = self._workspace(text2.device), self._P(), self.grad_buffers()
+        P, G = self._P(), self.grad_buffers()
+        ws, W = self._workspace(dlogits.device), self._weights(P, refresh=False)
         N = bs * tags
         g2 = ws.mat("g2", N, FEAT)
         dg2 = ws.mat("dg2", N, FEAT)
         ops.head_bwd(g2, P["head.weight"], dlogits.contiguous().view(-1), dg2, G["head.weight"], G["head.bias"], rows=N, D=FEAT)
-        engine.trunk_backward(ws, P, G, text2, img2, dg2, bs, tags, n_img, FEAT, drop=drop, img_shared=shared)
+        engine.trunk_backward(ws, P, W, G, text2, img2, dg2, bs, tags, n_img, FEAT, drop=drop, img_shared=shared)
         self._saved = None
 
 
@@ -298,6 +313,7 @@ class _TailHead(_Head):
         t_out = index.shape[1]
         self._n_pos(t_out)
         ws, P = self._workspace(dev), self._P()
+        W = self._weights(P)
         n_img = img_emb.shape[-2]
         if save:
             # train mode: gather the inputs by index exactly like the reference (ppo.py:267-271), then run the trunk
@@ -309,15 +325,18 @@ class _TailHead(_Head):
             ops.gather_rows(img_src, index, img_g, B=bs, t_in=tags_in, t_out=t_out, row_elems=n_img * FEAT,
                             src_bstride=(n_img * FEAT) if shared_in else tags_in * n_img * FEAT,
                             src_tstride=0 if shared_in else n_img * FEAT)
+            text_p, img_p = ws.planes("text_gp", bs * t_out * SEQ_LEN, FEAT), ws.planes("img_gp", bs * t_out * n_img, FEAT)
+            ops.split_planes(text_g, text_p)
+            ops.split_planes(img_g, img_p)
             drop = self._drop_cfg(0)
-            g2 = engine.trunk_forward(ws, P, text_g, img_g, bs, t_out, n_img, FEAT, save=True, drop=drop, img_shared=False)
+            g2 = engine.trunk_forward(ws, P, W, text_p, img_p, bs, t_out, n_img, FEAT, save=True, drop=drop, img_shared=False)
             drop_t = engine.DropCfg(drop.p, drop.seed, 3) if drop else None
         else:
             # no-grad: every (item, tag) pair goes through the trunk once; duplicates in `index` are gathered
             # from the [bs, tags, 768] trunk output (the trunk is per-pair, so this is bit-identical)
             text2, img2, _, _, _, shared = self._prep_inputs(text_emb, img_emb)
             drop = self._drop_cfg(0)
-            g2_all = engine.trunk_forward(ws, P, text2, img2, bs, tags_in, n_img, FEAT, save=False, drop=drop, img_shared=shared)
+            g2_all = engine.trunk_forward(ws, P, W, text2, img2, bs, tags_in, n_img, FEAT, save=False, drop=drop, img_shared=shared)
             g2 = ws.mat("g2_g", bs * t_out, FEAT)
             ops.gather_rows(g2_all, index, g2, B=bs, t_in=tags_in, t_out=t_out, row_elems=FEAT)
             drop_t = engine.DropCfg(drop.p, drop.seed, 3) if drop else None
@@ -325,27 +344,28 @@ class _TailHead(_Head):
         xin = ws.mat("xin", M, FEAT)
         ops.add_period_rows(g2, P["pos_emb.weight"], xin, rows=M, D=FEAT, period=t_out)
         xo = ws.mat("xo", M, FEAT)
-        engine.xit_forward(ws, "xitt.", P, engine.XITT, xin, xin, bs, t_out, t_out, FEAT, xo, save=save, drop=drop_t)
+        engine.xit_forward(ws, "xitt.", P, W, engine.XITT, xin, xin, bs, t_out, t_out, FEAT, xo, save=save, drop=drop_t)
         value = torch.empty(bs, device=dev)
         ops.head_fwd(xo, P["head.weight"], P["head.bias"], value, rows=bs, D=FEAT, row_step=t_out, row_off=t_out - 1)
         if save:
-            self._saved = (text_g, img_g, bs, t_out, n_img, drop, drop_t)
+            self._saved = (text_p, img_p, bs, t_out, n_img, drop, drop_t)
         return value
 
     def engine_backward(self, dvalue: torch.Tensor):
         text_g, img_g, bs, t_out, n_img, drop, drop_t = self._saved
-        ws, P, G = self._workspace(text_g.device), self._P(), self.grad_buffers()
+        P, G = self._P(), self.grad_buffers()
+        ws, W = self._workspace(dvalue.device), self._weights(P, refresh=False)
         M = bs * t_out
         xo, xin = ws.mat("xo", M, FEAT), ws.mat("xin", M, FEAT)
         dxo = ws.mat("dxo", M, FEAT)
         ops.head_bwd(xo, P["head.weight"], dvalue.contiguous().view(-1), dxo, G["head.weight"], G["head.bias"], rows=bs,
                      D=FEAT, row_step=t_out, row_off=t_out - 1, total_rows=M)
         dxin = ws.mat("dxin", M, FEAT)
-        engine.xit_backward(ws, "xitt.", P, G, engine.XITT, xin, xin, dxo, bs, t_out, t_out, FEAT, dxin, None,
+        engine.xit_backward(ws, "xitt.", P, W, G, engine.XITT, xin, xin, dxo, bs, t_out, t_out, FEAT, dxin, None,
                             drop=drop_t, same_xy=True)
         G["pos_emb.weight"].zero_()
         ops.period_rows_grad(dxin, G["pos_emb.weight"], rows=M, D=FEAT, period=t_out)
-        engine.trunk_backward(ws, P, G, text_g, img_g, dxin, bs, t_out, n_img, FEAT, drop=drop, img_shared=False)
+        engine.trunk_backward(ws, P, W, G, text_g, img_g, dxin, bs, t_out, n_img, FEAT, drop=drop, img_shared=False)
         self._saved = None
 
 

@@ -112,13 +112,15 @@ class _XitFn(torch.autograd.Function):
             mod._ws = engine.Workspace(x.device)
         ws = mod._ws
         P = {"xit." + n: p.data for n, p in mod.named_parameters()}
+        wp = engine.WeightPlanes(P, mod._keys.gemm_weights())
+        wp.refresh()
         x2 = x.detach().contiguous().view(b * Lq, E).clone()
         same = y is x
         y2 = x2 if same else y.detach().contiguous().view(b * Lk, E).clone()
         drop = runtime.next_drop(mod.drop_p, 0) if mod.training else None
         out = torch.empty(b * Lq, E, device=x.device)
-        engine.xit_forward(ws, "s.", P, mod._keys, x2, y2, b, Lq, Lk, E, out, save=True, drop=drop, heads=8)
-        ctx.mod, ctx.drop, ctx.dims, ctx.same = mod, drop, (b, Lq, Lk, E), same
+        engine.xit_forward(ws, "s.", P, wp.planes, mod._keys, x2, y2, b, Lq, Lk, E, out, save=True, drop=drop, heads=8)
+        ctx.mod, ctx.drop, ctx.dims, ctx.same, ctx.wp = mod, drop, (b, Lq, Lk, E), same, wp
         ctx.save_for_backward(x2, y2)
         return out.view(b, Lq, E)
 
@@ -132,7 +134,7 @@ class _XitFn(torch.autograd.Function):
         G = {"xit." + n: torch.empty_like(p.data) for n, p in mod.named_parameters()}
         dx = torch.empty(b * Lq, E, device=x2.device)
         dy = None if ctx.same else torch.empty(b * Lk, E, device=x2.device)
-        engine.xit_backward(ws, "s.", P, G, mod._keys, x2, y2, d_out.contiguous().view(b * Lq, E), b, Lq, Lk, E, dx, dy,
-                            drop=ctx.drop, same_xy=ctx.same, heads=8)
+        engine.xit_backward(ws, "s.", P, ctx.wp.planes, G, mod._keys, x2, y2, d_out.contiguous().view(b * Lq, E), b, Lq, Lk,
+                            E, dx, dy, drop=ctx.drop, same_xy=ctx.same, heads=8)
         grads = [G["xit." + n] for n, _ in mod.named_parameters()]
         return (None, dx.view(b, Lq, E), None if ctx.same else dy.view(b, Lk, E), *grads)

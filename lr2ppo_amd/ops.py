@@ -94,6 +94,48 @@ class Drop:
         self.p, self.seed, self.site = float(p), int(seed), int(site)
 
 
+class Planes:
+    """A matrix stored as two bf16 planes [hi | lo] (x = hi + lo) -- the operand format of the split-bf16 GEMM.
+    Same bytes as the fp32 [rows, cols] tensor it replaces.  `lo_off` = elements from the hi plane to the lo plane."""
+    __slots__ = ("buf", "rows", "cols", "lo_off")
+
+    def __init__(self, buf: torch.Tensor, rows: int, cols: int, lo_off: Optional[int] = None):
+        if buf.dtype != torch.int16 or not buf.is_cuda:
+            raise TypeError("Planes storage must be an int16 HIP tensor")
+        self.buf, self.rows, self.cols = buf, rows, cols
+        self.lo_off = rows * cols if lo_off is None else lo_off
+        if buf.numel() < self.lo_off + rows * cols:
+            raise ValueError("Planes storage too small")
+
+    @staticmethod
+    def empty(rows: int, cols: int, device) -> "Planes":
+        return Planes(torch.empty(2 * rows * cols, dtype=torch.int16, device=device), rows, cols)
+
+    def data_ptr(self) -> int:
+        return self.buf.data_ptr()
+
+    def plane_bytes(self) -> int:
+        return self.rows * self.cols * 2
+
+    def to_float(self) -> torch.Tensor:
+        """hi + lo as fp32 (tests / debugging only)."""
+        n = self.rows * self.cols
+        hi = self.buf[:n].view(torch.bfloat16).float()
+        lo = self.buf[self.lo_off:self.lo_off + n].view(torch.bfloat16).float()
+        return (hi + lo).view(self.rows, self.cols)
+
+
+def split_planes(src: torch.Tensor, dst: Planes):
+    _chk_f32(src)
+    n = src.numel()
+    _nat.check(_nat.lib().lr2_split_planes(src.data_ptr(), dst.data_ptr(), dst.lo_off, n, _stream()), "lr2_split_planes")
+    return dst
+
+
+def split_planes_multi(table_dev: torch.Tensor, n_chunks: int):
+    _nat.check(_nat.lib().lr2_split_planes_multi(table_dev.data_ptr(), n_chunks, _stream()), "lr2_split_planes_multi")
+
+
 def choose_tiling(M: int, N: int, K: int, trans_a: bool):
     """(block_m, splits).  256 CUs hold 2 (BM=128) or 3 (BM=64) workgroups each; pick the split-K factor that minimises
     rounds x (K-tiles per workgroup + fixed prologue/epilogue cost) + the cost of writing/reading the partial slabs, so
@@ -116,14 +158,17 @@ def choose_tiling(M: int, N: int, K: int, trans_a: bool):
     return bm, best
 
 
-def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, *, trans_a=False, trans_b=False,
+def gemm(a, b, out: Optional[torch.Tensor], M: int, N: int, K: int, *, trans_a=False, trans_b=False,
          lda: Optional[int] = None, ldb: Optional[int] = None, ld_out: Optional[int] = None,
          bias: Optional[torch.Tensor] = None, act: int = 0, out_z: Optional[torch.Tensor] = None,
          aux_z: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, drop: Optional[Drop] = None,
-         accumulate: bool = False, alpha: float = 1.0, splitk_ws: Optional[torch.Tensor] = None,
-         splits: Optional[int] = None, block_m: Optional[int] = None, passes: Optional[int] = None):
-    """out[M,N] = op(a) @ op(b) with the fused epilogue; see lr2_gemm in include/lr2ppo_hip.h."""
-    _chk_f32(a, b, out, bias, out_z, aux_z, resid)
+         accumulate: bool = False, alpha: float = 1.0, out_planes: Optional[Planes] = None,
+         splitk_ws: Optional[torch.Tensor] = None, splits: Optional[int] = None, block_m: Optional[int] = None,
+         passes: Optional[int] = None):
+    """out[M,N] = op(a) @ op(b) with the fused epilogue; a / b are fp32 tensors or Planes; the result goes to `out`
+    (fp32) and/or `out_planes`.  See lr2_gemm in include/lr2ppo_hip.h."""
+    a_pl, b_pl = isinstance(a, Planes), isinstance(b, Planes)
+    _chk_f32(None if a_pl else a, None if b_pl else b, out, bias, out_z, aux_z, resid)
     if lda is None:
         lda = M if trans_a else K
     if ldb is None:
@@ -142,68 +187,92 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, M: int, N: int, K:
     e = _nat.Epilogue()
     e.bias, e.resid, e.aux_z, e.out, e.out_z = _ptr(bias), _ptr(resid), _ptr(aux_z), _ptr(out), _ptr(out_z)
     e.ld_resid, e.ld_aux, e.ld_out, e.ld_z = _ld(resid, N), _ld(aux_z, N), ld_out, _ld(out_z, N)
+    if out_planes is not None:
+        e.out_hi, e.out_lo_off, e.ld_planes = out_planes.data_ptr(), out_planes.lo_off, out_planes.cols
     e.act, e.accumulate, e.alpha = act, 1 if accumulate else 0, alpha
     if drop is not None and drop.p > 0.0:
         e.drop_p, e.drop_seed, e.drop_site = drop.p, drop.seed, drop.site
-    a_bytes, b_bytes = a.numel() * 4, b.numel() * 4
+    a_bytes = a.plane_bytes() if a_pl else a.numel() * 4
+    b_bytes = b.plane_bytes() if b_pl else b.numel() * 4
     form = "TN" if trans_a else ("NN" if trans_b else "NT")
-    with _Timed(f"gemm_{form}_M{M}_N{N}_K{K}", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)):
+    src = ("p" if a_pl else "f") + ("p" if b_pl else "f")
+    with _Timed(f"gemm_{form}_{src}_M{M}_N{N}_K{K}", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)):
         rc = _nat.lib().lr2_gemm(a.data_ptr(), b.data_ptr(), M, N, K, lda, ldb, 1 if trans_a else 0, 1 if trans_b else 0,
-                                 a_bytes, b_bytes, C.byref(e), _ptr(splitk_ws), sp, bm, passes or _PASSES, _stream())
-    _nat.check(rc, f"lr2_gemm(M={M},N={N},K={K},ta={trans_a},tb={trans_b})")
-    return out
+                                 a_bytes, b_bytes, 1 if a_pl else 0, a.lo_off * 2 if a_pl else 0, 1 if b_pl else 0,
+                                 b.lo_off * 2 if b_pl else 0, C.byref(e), _ptr(splitk_ws), sp, bm, passes or _PASSES,
+                                 _stream())
+    _nat.check(rc, f"lr2_gemm(M={M},N={N},K={K},ta={trans_a},tb={trans_b},planes={src})")
+    return out if out is not None else out_planes
 
 
 def _ld(t: Optional[torch.Tensor], default: int) -> int:
     return default if t is None else t.shape[-1]
 
 
-def layernorm_fwd(x, gamma, beta, out, mean=None, rstd=None, *, rows, D, eps=1e-5, mode=0, group=0, group_stride=0):
+def layernorm_fwd(x, gamma, beta, out, mean=None, rstd=None, *, rows, D, eps=1e-5, mode=0, group=0, group_stride=0,
+                  out_planes: Optional[Planes] = None):
+    """out (fp32) and/or out_planes receive LN(x); both use the (group, group_stride) row mapping."""
     _chk_f32(x, gamma, beta, out, mean, rstd)
-    rc = _nat.lib().lr2_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), _ptr(mean),
-                                   _ptr(rstd), rows, D, eps, mode, group, group_stride, _stream())
+    rc = _nat.lib().lr2_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(out),
+                                      out_planes.data_ptr() if out_planes is not None else None,
+                                      out_planes.lo_off if out_planes is not None else 0, _ptr(mean), _ptr(rstd), rows, D, eps,
+                                      mode, group, group_stride, _stream())
     _nat.check(rc, "lr2_layernorm_fwd")
-    return out
+    return out if out is not None else out_planes
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partials, dgamma, dbeta, *, rows, D, group=0, group_stride=0,
-                  resid_grad=None, dx_masked=None, drop: Optional[Drop] = None, nblocks=256):
-    _chk_f32(dy, x, gamma, mean, rstd, dx, partials, dgamma, dbeta, resid_grad, dx_masked)
+                  resid_grad=None, dx_planes: Optional[Planes] = None, drop: Optional[Drop] = None, nblocks=256):
+    """dx (fp32) = LN'(dy) + resid_grad; dx_planes = planes of dropout_mask(dx)/(1-p) (p = 0: of dx)."""
+    _chk_f32(dy, x, gamma, mean, rstd, dx, partials, dgamma, dbeta, resid_grad)
     nb = min(nblocks, (rows + 3) // 4)
     if partials.numel() < nb * 2 * D:
         raise ValueError("layernorm_bwd partials workspace too small")
     p, seed, site = (drop.p, drop.seed, drop.site) if drop is not None else (0.0, 0, 0)
     L = _nat.lib()
     rc = L.lr2_layernorm_bwd(dy.data_ptr(), group, group_stride, x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                             rstd.data_ptr(), _ptr(resid_grad), _ptr(dx), _ptr(dx_masked), p, seed, site,
+                             rstd.data_ptr(), _ptr(resid_grad), _ptr(dx),
+                             dx_planes.data_ptr() if dx_planes is not None else None,
+                             dx_planes.lo_off if dx_planes is not None else 0, p, seed, site,
                              partials.data_ptr(), nb, rows, D, _stream())
     _nat.check(rc, "lr2_layernorm_bwd")
     _nat.check(L.lr2_colsum_partials_finish(partials.data_ptr(), nb, D, 2 * D, dgamma.data_ptr(), 0, _stream()), "finish")
     _nat.check(L.lr2_colsum_partials_finish(partials.data_ptr() + 4 * D, nb, D, 2 * D, dbeta.data_ptr(), 0, _stream()),
-            "finish")
+               "finish")
 
 
 def colsum(x, out, partials, *, rows, cols, ld=None, nblocks=128):
-    _chk_f32(x, out, partials)
+    """Column sums of an fp32 matrix or a Planes matrix -> fp32 [cols]."""
+    is_pl = isinstance(x, Planes)
+    _chk_f32(None if is_pl else x, out, partials)
     nb = min(nblocks, rows)
     if partials.numel() < nb * cols:
         raise ValueError("colsum partials workspace too small")
-    rc = _nat.lib().lr2_colsum(x.data_ptr(), rows, cols, ld or cols, partials.data_ptr(), nb, out.data_ptr(), _stream())
+    rc = _nat.lib().lr2_colsum(x.data_ptr(), 1 if is_pl else 0, x.lo_off if is_pl else 0, rows, cols, ld or cols,
+                               partials.data_ptr(), nb, out.data_ptr(), _stream())
     _nat.check(rc, "lr2_colsum")
     return out
 
 
 def xattn_fwd(q, k, v, o, *, batch, heads, Lq, Lk, head_dim, post_scale):
-    _chk_f32(q, k, v, o)
-    _nat.check(_nat.lib().lr2_xattn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), batch, heads, Lq, Lk, head_dim,
-                                  post_scale, _stream()), "lr2_xattn_fwd")
+    """o: fp32 tensor or Planes."""
+    o_pl = isinstance(o, Planes)
+    _chk_f32(q, k, v, None if o_pl else o)
+    _nat.check(_nat.lib().lr2_xattn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), 1 if o_pl else 0,
+                                        o.lo_off if o_pl else 0, batch, heads, Lq, Lk, head_dim, post_scale, _stream()),
+               "lr2_xattn_fwd")
     return o
 
 
 def xattn_bwd(q, k, v, do, dq, dk, dv, *, batch, heads, Lq, Lk, head_dim, post_scale):
-    _chk_f32(q, k, v, do, dq, dk, dv)
+    """dq / dk / dv: all fp32 tensors or all Planes."""
+    pl = isinstance(dq, Planes)
+    _chk_f32(q, k, v, do)
+    if not pl:
+        _chk_f32(dq, dk, dv)
     _nat.check(_nat.lib().lr2_xattn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-                                  dv.data_ptr(), batch, heads, Lq, Lk, head_dim, post_scale, _stream()), "lr2_xattn_bwd")
+                                        dv.data_ptr(), 1 if pl else 0, dq.lo_off if pl else 0, dk.lo_off if pl else 0, batch,
+                                        heads, Lq, Lk, head_dim, post_scale, _stream()), "lr2_xattn_bwd")
 
 
 def self_attn_fwd(q, k, v, seg, o, *, batch, heads, L, head_dim, scale):
@@ -233,9 +302,11 @@ def gather_rows_bwd(ddst, index, dsrc, *, B, t_in, t_out, row_elems):
 
 
 def copy_rows(src, dst, *, rows, D, group, dst_gstride, dst_off):
-    _chk_f32(src, dst)
-    _nat.check(_nat.lib().lr2_copy_rows(src.data_ptr(), dst.data_ptr(), rows, D, group, dst_gstride, dst_off, _stream()),
-            "lr2_copy_rows")
+    """dst: fp32 tensor or Planes (the concat buffer of finetune/ppo.py:224)."""
+    pl = isinstance(dst, Planes)
+    _chk_f32(src, None if pl else dst)
+    _nat.check(_nat.lib().lr2_copy_rows(src.data_ptr(), dst.data_ptr(), 1 if pl else 0, dst.lo_off if pl else 0, rows, D,
+                                        group, dst_gstride, dst_off, _stream()), "lr2_copy_rows")
     return dst
 
 

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=int, nargs="*", default=None, help="indices into SHAPES")
+    ap.add_argument("--planes", action="store_true", help="operands as pre-split bf16 hi/lo planes (LDS-DMA path)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
@@ -33,6 +34,10 @@ def main():
         A = torch.randn((K, M) if ta else (M, K), device=dev, generator=g)
         B = torch.randn((K, N) if tb else (N, K), device=dev, generator=g)
         out = torch.empty(M, N, device=dev)
+        if a.planes and not (M == 64 and K > 100000) and not (N > 100000 and form == "NN"):
+            Ap, Bp = ops.Planes.empty(*A.shape, dev), ops.Planes.empty(*B.shape, dev)
+            ops.split_planes(A, Ap), ops.split_planes(B, Bp)
+            A, B = Ap, Bp
         bm, sp = ops.choose_tiling(M, N, K, ta)
         ws = torch.empty(max(1, sp) * M * N, device=dev) if sp > 1 else None
         for _ in range(3):
