@@ -201,11 +201,12 @@ class _Head(nn.Module):
             self._wp.refresh()
         return self._wp.planes
 
-    GRAD_ORDER_FIRST = ("out_layer.fc2.weight", "out_layer.fc2.bias", "out_layer.fc1.weight", "out_layer.fc1.bias")
+    GRAD_ORDER_FIRST = ("out_layer.fc1.weight",)
 
     def grad_buffers(self) -> Dict[str, torch.Tensor]:
-        """Persistent gradient storage: one flat fp32 buffer, out_layer (96 % of the bytes, produced first in
-        backward) at the front so its all-reduce can start while the rest of backward runs."""
+        """Persistent gradient storage: one flat fp32 buffer with out_layer.fc1.weight (96 % of the bytes) in front.
+        In data-parallel runs that block is never communicated (its rank-64 factors are, engine.trunk_backward);
+        everything behind `_bucket_split` is averaged with ONE all-reduce."""
         dev = next(self.parameters()).device
         if self._G is not None and self._flat_grad.device == dev:
             return self._G
@@ -276,7 +277,7 @@ class Actor(_Head):
             self._saved = (text2, img2, bs, tags, n_img, shared, drop)
         return logits
 
-    def engine_backward(self, dlogits: torch.Tensor):
+    def engine_backward(self, dlogits: torch.Tensor, dp=None):
         """Gradients of sum(dlogits * logits) into the flat gradient buffer (call after engine_forward(save=True))."""
         text2, img2, bs, tags, n_img, shared, drop = self._saved
         P, G = self._P(), self.grad_buffers()
@@ -285,7 +286,7 @@ class Actor(_Head):
         g2 = ws.mat("g2", N, FEAT)
         dg2 = ws.mat("dg2", N, FEAT)
         ops.head_bwd(g2, P["head.weight"], dlogits.contiguous().view(-1), dg2, G["head.weight"], G["head.bias"], rows=N, D=FEAT)
-        engine.trunk_backward(ws, P, W, G, text2, img2, dg2, bs, tags, n_img, FEAT, drop=drop, img_shared=shared)
+        engine.trunk_backward(ws, P, W, G, text2, img2, dg2, bs, tags, n_img, FEAT, drop=drop, img_shared=shared, dp=dp)
         self._saved = None
 
 
@@ -351,7 +352,7 @@ class _TailHead(_Head):
             self._saved = (text_p, img_p, bs, t_out, n_img, drop, drop_t)
         return value
 
-    def engine_backward(self, dvalue: torch.Tensor):
+    def engine_backward(self, dvalue: torch.Tensor, dp=None):
         text_g, img_g, bs, t_out, n_img, drop, drop_t = self._saved
         P, G = self._P(), self.grad_buffers()
         ws, W = self._workspace(dvalue.device), self._weights(P, refresh=False)
@@ -365,7 +366,7 @@ class _TailHead(_Head):
                             drop=drop_t, same_xy=True)
         G["pos_emb.weight"].zero_()
         ops.period_rows_grad(dxin, G["pos_emb.weight"], rows=M, D=FEAT, period=t_out)
-        engine.trunk_backward(ws, P, W, G, text_g, img_g, dxin, bs, t_out, n_img, FEAT, drop=drop, img_shared=False)
+        engine.trunk_backward(ws, P, W, G, text_g, img_g, dxin, bs, t_out, n_img, FEAT, drop=drop, img_shared=False, dp=dp)
         self._saved = None
 
 
@@ -519,19 +520,54 @@ def rollout_step(model, reward_model, text_emb, img_emb, tgts, state=None):
 
 
 class _DataParallel:
-    """Gradient exchange for the north-star DP mode: all-reduce(avg) of the flat gradient buffers over RCCL,
-    the 2 GB out_layer bucket first and on a side stream so it overlaps the rest of backward."""
+    """Gradient exchange of the north-star data-parallel mode (the reference trains independent replicas,
+    finetune/ppo.py has no DDP).  Per model and minibatch:
+      * out_layer.fc1.weight (2 GB of the 2.08 GB of gradients) is NOT all-reduced: its gradient is the product of two
+        thin factors, dW = dZ^T X with dZ [N,3072] and X [N,162816] per rank, so the ranks all-gather the factors
+        (42 MB each, as bf16 hi/lo planes) and every rank multiplies the concatenation locally (engine.trunk_backward);
+      * everything else (19-26 M parameters) is averaged with ONE all-reduce over the tail of the flat gradient buffer.
+    Collectives are issued with async_op on RCCL's stream and waited for right before their consumer, so they overlap
+    the rest of backward."""
 
     def __init__(self):
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self.stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
+        self.backend = dist.get_backend() if self.world > 1 else None
 
-    def reduce(self, head: _Head):
+    def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
+        out, inp = out.view(torch.uint8), inp.view(torch.uint8)   # raw bytes: int16 is not a NCCL/gloo element type
+        if self.backend == "nccl":
+            return dist.all_gather_into_tensor(out, inp, async_op=True)
+        return dist.all_gather(list(out.view(self.world, -1).unbind(0)), inp, async_op=True)
+
+    def gather_planes_start(self, pl: ops.Planes, ws, name: str):
+        """Start all-gathering a [rows, cols] planes tensor along rows -> ([world*rows, cols] planes, handles)."""
+        n = pl.rows * pl.cols
+        out = ws.planes(name, pl.rows * self.world, pl.cols)
+        works = [self._all_gather(out.buf[:n * self.world], pl.buf[:n]),
+                 self._all_gather(out.buf[out.lo_off:out.lo_off + n * self.world], pl.buf[pl.lo_off:pl.lo_off + n])]
+        return out, works
+
+    def gather_planes_finish(self, pending):
+        out, works = pending
+        for w in works:
+            w.wait()
+        return out
+
+    def reduce_start(self, head: "_Head"):
+        """Average every gradient except out_layer.fc1.weight (handled through its factors)."""
         if self.world == 1:
-            return
-        flat = head._flat_grad
-        flat.div_(self.world)
-        dist.all_reduce(flat)
+            return None
+        tail = head._flat_grad[head._bucket_split:]
+        tail.div_(self.world)
+        return dist.all_reduce(tail, async_op=True)
+
+    @staticmethod
+    def finish(work):
+        if work is not None:
+            work.wait()
+
+    def reduce(self, head: "_Head"):
+        self.finish(self.reduce_start(head))
 
 
 def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
@@ -550,11 +586,13 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
     ops.ppo_loss(logits.view(bs, tags), old_scores.contiguous(), rewards.contiguous(), old_value.contiguous(), value,
                  next_state.contiguous(), scal, per, dscores, dvalue, B=bs, T=tags, kl_w=args.kl_div_loss_weight,
                  ent_w=args.entropy_weight, value_clip=args.value_clip, margin=0.01, adv_eps=-0.1)
-    actor.engine_backward(dscores)
-    dp.reduce(actor)
+    actor.engine_backward(dscores, dp)
+    wa = dp.reduce_start(actor)            # overlaps the critic's backward
+    critic.engine_backward(dvalue, dp)
+    wc = dp.reduce_start(critic)
+    dp.finish(wa)
     optimizer.step()
-    critic.engine_backward(dvalue)
-    dp.reduce(critic)
+    dp.finish(wc)
     critic_optim.step()
     pm = per.mean(dim=1)
     metrics = torch.stack([scal[0], scal[1], pm[0], old_value.mean(), value.mean(), rewards.mean(), pm[2], pm[3], scal[2],

@@ -23,8 +23,17 @@ def _free_port():
 class _FakeHead:
     """Stands in for an Actor/Critic: only the flat gradient buffer matters to the exchange."""
 
-    def __init__(self, flat):
+    def __init__(self, flat, split=0):
         self._flat_grad = flat
+        self._bucket_split = split
+
+
+class _FakeWs:
+    def planes(self, name, rows, cols):
+        from lr2ppo_amd.ops import Planes
+        p = Planes.__new__(Planes)
+        p.buf, p.rows, p.cols, p.lo_off = torch.zeros(2 * rows * cols, dtype=torch.int16), rows, cols, rows * cols
+        return p
 
 
 def _worker(rank, world, port, q):
@@ -37,12 +46,32 @@ def _worker(rank, world, port, q):
     g = torch.Generator().manual_seed(100 + rank)
     flat = torch.randn(1000, generator=g)
     mine = flat.clone()
-    head = _FakeHead(flat)
+    head = _FakeHead(flat, split=300)
     dp.reduce(head)
     gathered = [torch.zeros(1000) for _ in range(world)]
     dist.all_gather(gathered, mine)
     want = torch.stack(gathered).mean(0)
-    ok_avg = torch.allclose(head._flat_grad, want, atol=1e-6)
+    # the tail is averaged, the out_layer.fc1.weight block in front is left alone (it travels as factors)
+    ok_avg = torch.allclose(head._flat_grad[300:], want[300:], atol=1e-6) and torch.equal(head._flat_grad[:300], mine[:300])
+    # factor all-gather: planes [rows, cols] of every rank concatenated along rows, hi and lo planes separately
+    from lr2ppo_amd.ops import Planes
+    rows, cols = 3, 8
+    pl = Planes.__new__(Planes)
+    pl.rows, pl.cols, pl.lo_off = rows, cols, rows * cols
+    pl.buf = (torch.arange(2 * rows * cols, dtype=torch.int16) + 1000 * rank)
+    out = dp.gather_planes_finish(dp.gather_planes_start(pl, _FakeWs(), "x"))
+    exp_hi = torch.cat([torch.arange(rows * cols, dtype=torch.int16) + 1000 * r for r in range(world)])
+    exp_lo = torch.cat([torch.arange(rows * cols, 2 * rows * cols, dtype=torch.int16) + 1000 * r for r in range(world)])
+    ok_avg = ok_avg and out.rows == world * rows and torch.equal(out.buf[:world * rows * cols], exp_hi) \
+        and torch.equal(out.buf[out.lo_off:out.lo_off + world * rows * cols], exp_lo)
+    # the identity the scheme rests on: sum_r dZ_r^T X_r == concat(dZ)^T concat(X)
+    dz, xx = torch.randn(4, 5, generator=g), torch.randn(4, 7, generator=g)
+    dzs, xxs = [torch.zeros(4, 5) for _ in range(world)], [torch.zeros(4, 7) for _ in range(world)]
+    dist.all_gather(dzs, dz)
+    dist.all_gather(xxs, xx)
+    local = dz.t() @ xx
+    dist.all_reduce(local)
+    ok_avg = ok_avg and torch.allclose(local, torch.cat(dzs).t() @ torch.cat(xxs), atol=1e-5)
     # replicas initialised per rank (the reference's quirk 17) become identical after the rank-0 broadcast
     torch.manual_seed(7 + rank)
     p = torch.randn(64)

@@ -228,3 +228,40 @@ def test_single_bf16_pass_is_not_good_enough(dev):
         ops.set_gemm_passes(3)
     err = _maxerr(lg, g["actor_logits"])
     assert 2e-4 < err < 2e-2, err
+
+
+def test_dp_factor_gather_path_equals_local_gradient(dev):
+    """Data-parallel schedule on one GPU with a mock 2-rank exchange that returns this rank's factors twice: the
+    averaged out_layer.fc1 gradient (one K = 2N wgrad GEMM with alpha = 1/2) must reproduce the local gradient."""
+    from lr2ppo_amd import ops
+    from lr2ppo_amd.finetune import ppo
+
+    class MockDP:
+        world = 2
+
+        def gather_planes_start(self, pl, ws, name):
+            n = pl.rows * pl.cols
+            out = ws.planes(name, pl.rows * 2, pl.cols)
+            for r in range(2):
+                out.buf[r * n:(r + 1) * n].copy_(pl.buf[:n])
+                out.buf[out.lo_off + r * n:out.lo_off + (r + 1) * n].copy_(pl.buf[pl.lo_off:pl.lo_off + n])
+            return out, []
+
+        def gather_planes_finish(self, pending):
+            return pending[0]
+
+    bs, tags = 2, 2
+    text, img, _ = O.seeded_head_inputs(91, bs, tags)
+    actor = ppo.Actor(_ns(**ARGS), None)
+    actor.load_state_dict(O.seeded_params(O.head_param_spec("actor"), seed=7), strict=True)
+    actor = actor.to(dev).eval()
+    w = torch.randn(bs * tags, generator=torch.Generator().manual_seed(3)).to(dev)
+    actor.engine_forward(text.to(dev), img.to(dev), save=True)
+    actor.engine_backward(w)
+    ref = {n: g.clone() for n, g in actor.grad_buffers().items()}
+    actor.engine_forward(text.to(dev), img.to(dev), save=True)
+    actor.engine_backward(w, MockDP())
+    G = actor.grad_buffers()
+    for n in ref:
+        scale = float(ref[n].abs().max())
+        assert _maxerr(G[n], ref[n]) <= 1e-9 + 1e-4 * scale, n
