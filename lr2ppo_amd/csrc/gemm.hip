@@ -43,7 +43,6 @@
 
 namespace lr2gemm {
 
-constexpr int BK = 64;
 constexpr int NTHREADS = 256;
 
 struct GemmParams {
@@ -62,9 +61,16 @@ struct GemmParams {
 };
 
 // ---- LDS image helpers (units of 16 bytes = 8 bf16) -------------------------------------------
-// K-contiguous tile: [R rows][8 units]; unit u of row r lives at unit (u ^ ((r >> 1) & 7)).
-__device__ __forceinline__ int swz_kc(int r) { return (r >> 1) & 7; }
-// contraction-strided tile: [64 k-rows][UPR units]; XOR on 32-byte chunks (bit 0 of the unit untouched).
+// K-contiguous tile: [R rows][BK/8 units].  BK = 64 (128-B rows): unit u of row r lives at unit u ^ ((r >> 1) & 7).
+// BK = 32 (64-B rows, four rows per 256-B bank row): unit u lives at u ^ {0,3,2,1}[(r >> 2) & 3], which makes the four
+// rows of a residue class mod 4 that one ds_read_b128 lane group touches land on four different 16-B slots.
+template <int BK>
+__device__ __forceinline__ int swz_kc(int r) {
+  if (BK == 64) return (r >> 1) & 7;
+  const int t = (r >> 2) & 3;
+  return (4 - t) & 3;
+}
+// contraction-strided tile: [BK k-rows][UPR units]; XOR on 32-byte chunks (bit 0 of the unit untouched).
 template <int UPR>
 __device__ __forceinline__ int swz_tr(int k) {
   return ((((k & 3) | (((k >> 3) & 1) << 2))) << 1) & (UPR - 1);
@@ -80,11 +86,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, ui
 }
 
 // ---- operand source 1: fp32 in HBM, split in registers ---------------------------------------
-template <int BR, bool TR, int PASSES>
+template <int BR, int BK, bool TR, int PASSES>
 struct RegStager {
   static constexpr int NV = BR * BK / 4 / NTHREADS;  // float4 per thread per tile
-  static constexpr int UPR = TR ? BR / 8 : 8;
+  static constexpr int UPR = TR ? BR / 8 : BK / 8;
   static constexpr int TILE_BYTES = BR * BK * 2;
+  static constexpr int VPK = BK / 4;                 // float4 per row of a K-contiguous tile
   u32x4_t regs[NV];
   uint32_t voff, qstep, kstep;
   int tid;
@@ -92,9 +99,9 @@ struct RegStager {
   __device__ __forceinline__ void init(int tid_, int r0, int ld, int ktile0) {
     tid = tid_;
     if (!TR) {
-      const int row = tid >> 4, kg = tid & 15;
+      const int row = tid / VPK, kg = tid % VPK;
       voff = (uint32_t)((((uint64_t)(r0 + row)) * (uint64_t)ld + (uint64_t)kg * 4u) * 4u);
-      qstep = (uint32_t)ld * 4u * 16u;
+      qstep = (uint32_t)ld * 4u * (NTHREADS / VPK);
       kstep = BK * 4u;
     } else {
       constexpr int VPR = BR / 4;  // float4 per k-row
@@ -112,8 +119,8 @@ struct RegStager {
   }
   __device__ __forceinline__ int lds_offset(int q) const {
     if (!TR) {
-      const int row = q * 16 + (tid >> 4), kg = tid & 15;
-      return (row * 8 + ((kg >> 1) ^ swz_kc(row))) * 16 + (kg & 1) * 8;
+      const int row = q * (NTHREADS / VPK) + tid / VPK, kg = tid % VPK;
+      return (row * UPR + ((kg >> 1) ^ swz_kc<BK>(row))) * 16 + (kg & 1) * 8;
     } else {
       constexpr int VPR = BR / 4;
       const int k = q * (NTHREADS / VPR) + tid / VPR, rg = tid % VPR;
@@ -144,11 +151,11 @@ struct RegStager {
 // ---- operand source 2: bf16 hi/lo planes in HBM, LDS-DMA ---------------------------------------
 // LDS-DMA writes lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
 // address; the LDS image is then identical to the one RegStager writes and read_frag() serves both.
-template <int BR, bool TR, int PASSES>
+template <int BR, int BK, bool TR, int PASSES>
 struct DmaStager {
-  static constexpr int UNITS = BR * 8;             // 16-byte units per plane tile (BR x 64 bf16)
+  static constexpr int UNITS = BR * BK / 8;        // 16-byte units per plane tile (BR x BK bf16)
   static constexpr int PER_WAVE = UNITS / 64 / 4;  // DMA instructions per wave per plane
-  static constexpr int UPR = TR ? BR / 8 : 8;
+  static constexpr int UPR = TR ? BR / 8 : BK / 8;
   static constexpr int TILE_BYTES = BR * BK * 2;
   uint32_t voff[PER_WAVE];
   uint32_t kstep;
@@ -158,7 +165,7 @@ struct DmaStager {
     for (int q = 0; q < PER_WAVE; ++q) {
       const int p = (wave * PER_WAVE + q) * 64 + lane;
       if (!TR) {
-        const int row = p >> 3, u = (p & 7) ^ swz_kc(row);
+        const int row = p / UPR, u = (p % UPR) ^ swz_kc<BK>(row);
         voff[q] = (uint32_t)(((uint64_t)(r0 + row) * (uint64_t)ld) * 2u + (uint32_t)u * 16u);
       } else {
         const int k = p / UPR, u = (p % UPR) ^ swz_tr<UPR>(k);
@@ -180,12 +187,12 @@ struct DmaStager {
 };
 
 // fragment for v_mfma_f32_16x16x32_bf16: lane l holds X[row l&15][k = 8*(l>>4) + j], j = 0..7
-template <int BR, bool TR>
+template <int BR, int BK, bool TR>
 __device__ __forceinline__ bf16x8_t read_frag(const char* tile, int rbase, int ks, int lane) {
   if (!TR) {
     const int row = rbase + (lane & 15);
-    const int u = (4 * ks + (lane >> 4)) ^ swz_kc(row);
-    return *reinterpret_cast<const bf16x8_t*>(tile + (row * 8 + u) * 16);
+    const int u = (4 * ks + (lane >> 4)) ^ swz_kc<BK>(row);
+    return *reinterpret_cast<const bf16x8_t*>(tile + (row * (BK / 8) + u) * 16);
   } else {
     constexpr int UPR = BR / 8;
     const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
@@ -227,21 +234,22 @@ __device__ __forceinline__ bf16x8_t read_frag_tr_asm(const char* tile, int rbase
 // K-tile multiply for planes (LDS-DMA) operands with at least one contraction-strided operand: all fragments of the
 // tile are requested up front (strided ones by asm, see above), the k-step-0 MFMAs start once the first half of the
 // LDS queue has drained (LDS returns in order, so a counted lgkmcnt is exact), k-step 1 after the rest.
-template <int BM, int BN, int MI, int NI, bool TA, bool TB, int PASSES>
+template <int BM, int BN, int BK, int MI, int NI, bool TA, bool TB, int PASSES>
 __device__ __forceinline__ void compute_tile_preload(const char* a_hi, const char* b_hi, int wm0, int wn0, int lane,
                                                      f32x4_t (&acc)[MI][NI]) {
   constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;
-  bf16x8_t ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+  constexpr int KS = BK / 32;
+  bf16x8_t ah[KS][MI], al[KS][MI], bh[KS][NI], bl[KS][NI];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
+  for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       if (TA) {
         ah[ks][i] = read_frag_tr_asm<BM>(a_hi, wm0 + 16 * i, ks, lane);
         if (PASSES == 3) al[ks][i] = read_frag_tr_asm<BM>(a_hi + A_TILE, wm0 + 16 * i, ks, lane);
       } else {
-        ah[ks][i] = read_frag<BM, false>(a_hi, wm0 + 16 * i, ks, lane);
-        if (PASSES == 3) al[ks][i] = read_frag<BM, false>(a_hi + A_TILE, wm0 + 16 * i, ks, lane);
+        ah[ks][i] = read_frag<BM, BK, false>(a_hi, wm0 + 16 * i, ks, lane);
+        if (PASSES == 3) al[ks][i] = read_frag<BM, BK, false>(a_hi + A_TILE, wm0 + 16 * i, ks, lane);
       }
     }
 #pragma unroll
@@ -250,18 +258,18 @@ __device__ __forceinline__ void compute_tile_preload(const char* a_hi, const cha
         bh[ks][j] = read_frag_tr_asm<BN>(b_hi, wn0 + 16 * j, ks, lane);
         if (PASSES == 3) bl[ks][j] = read_frag_tr_asm<BN>(b_hi + B_TILE, wn0 + 16 * j, ks, lane);
       } else {
-        bh[ks][j] = read_frag<BN, false>(b_hi, wn0 + 16 * j, ks, lane);
-        if (PASSES == 3) bl[ks][j] = read_frag<BN, false>(b_hi + B_TILE, wn0 + 16 * j, ks, lane);
+        bh[ks][j] = read_frag<BN, BK, false>(b_hi, wn0 + 16 * j, ks, lane);
+        if (PASSES == 3) bl[ks][j] = read_frag<BN, BK, false>(b_hi + B_TILE, wn0 + 16 * j, ks, lane);
       }
     }
-    if (ks == 0) __builtin_amdgcn_sched_barrier(0);   // keep the k-step-0 requests ahead of the k-step-1 ones
+    if (ks == 0 && KS == 2) __builtin_amdgcn_sched_barrier(0);   // keep the k-step-0 requests ahead of the k-step-1 ones
   }
   constexpr int NIMGS = PASSES == 3 ? 2 : 1;
   constexpr int PER_KS = (MI * (TA ? 2 : 1) + NI * (TB ? 2 : 1)) * NIMGS;   // LDS instructions per k-step
   // s_waitcnt immediate (gfx9 encoding): vmcnt = 63 and expcnt = 7 (no wait), lgkmcnt in bits [11:8]
-  constexpr int WAIT_HALF = 0xC07F | ((PER_KS <= 15 ? PER_KS : 0) << 8);
+  constexpr int WAIT_HALF = 0xC07F | (((KS == 2 && PER_KS <= 15) ? PER_KS : 0) << 8);
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
+  for (int ks = 0; ks < KS; ++ks) {
     if (ks == 0) __builtin_amdgcn_s_waitcnt(WAIT_HALF);   // the k-step-0 fragments have landed (LDS returns in order)
     else __builtin_amdgcn_s_waitcnt(0xC07F);              // everything has
     __builtin_amdgcn_sched_barrier(0);
@@ -295,33 +303,34 @@ __device__ __forceinline__ void pin_pipeline() {
 // One K-tile of MFMA work for a wave.  Fragment reads run one MFMA group ahead of their use (register double
 // buffering, pinned with sched_group_barrier: hipcc otherwise sinks every read to its first use and drains
 // lgkmcnt(0) ten times per tile).
-template <int BM, int BN, int MI, int NI, bool TA, bool TB, int PASSES>
+template <int BM, int BN, int BK, int MI, int NI, bool TA, bool TB, int PASSES>
 __device__ __forceinline__ void compute_tile(const char* a_hi, const char* b_hi, int wm0, int wn0, int lane,
                                              f32x4_t (&acc)[MI][NI]) {
   constexpr int A_TILE = BM * BK * 2, B_TILE = BN * BK * 2;
-  bf16x8_t ah[2][MI], al[2][MI], bh[2], bl[2];
+  constexpr int KS = BK / 32;
+  bf16x8_t ah[KS][MI], al[KS][MI], bh[2], bl[2];
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    ah[0][i] = read_frag<BM, TA>(a_hi, wm0 + 16 * i, 0, lane);
-    if (PASSES == 3) al[0][i] = read_frag<BM, TA>(a_hi + A_TILE, wm0 + 16 * i, 0, lane);
+    ah[0][i] = read_frag<BM, BK, TA>(a_hi, wm0 + 16 * i, 0, lane);
+    if (PASSES == 3) al[0][i] = read_frag<BM, BK, TA>(a_hi + A_TILE, wm0 + 16 * i, 0, lane);
   }
-  bh[0] = read_frag<BN, TB>(b_hi, wn0, 0, lane);
-  if (PASSES == 3) bl[0] = read_frag<BN, TB>(b_hi + B_TILE, wn0, 0, lane);
+  bh[0] = read_frag<BN, BK, TB>(b_hi, wn0, 0, lane);
+  if (PASSES == 3) bl[0] = read_frag<BN, BK, TB>(b_hi + B_TILE, wn0, 0, lane);
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
+  for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int cur = (ks * NI + j) & 1, nxt = cur ^ 1;
       const int nj = (j + 1 < NI) ? j + 1 : 0, nks = (j + 1 < NI) ? ks : ks + 1;
-      if (nks < 2) {
-        bh[nxt] = read_frag<BN, TB>(b_hi, wn0 + 16 * nj, nks, lane);
-        if (PASSES == 3) bl[nxt] = read_frag<BN, TB>(b_hi + B_TILE, wn0 + 16 * nj, nks, lane);
+      if (nks < KS) {
+        bh[nxt] = read_frag<BN, BK, TB>(b_hi, wn0 + 16 * nj, nks, lane);
+        if (PASSES == 3) bl[nxt] = read_frag<BN, BK, TB>(b_hi + B_TILE, wn0 + 16 * nj, nks, lane);
       }
-      if (j == 0 && ks == 0) {
+      if (j == 0 && ks == 0 && KS == 2) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-          ah[1][i] = read_frag<BM, TA>(a_hi, wm0 + 16 * i, 1, lane);
-          if (PASSES == 3) al[1][i] = read_frag<BM, TA>(a_hi + A_TILE, wm0 + 16 * i, 1, lane);
+          ah[KS - 1][i] = read_frag<BM, BK, TA>(a_hi, wm0 + 16 * i, KS - 1, lane);
+          if (PASSES == 3) al[KS - 1][i] = read_frag<BM, BK, TA>(a_hi + A_TILE, wm0 + 16 * i, KS - 1, lane);
         }
       }
       if (PASSES == 3) {
@@ -338,7 +347,7 @@ __device__ __forceinline__ void compute_tile(const char* a_hi, const char* b_hi,
   constexpr int NIMGS = PASSES == 3 ? 2 : 1;
   constexpr int RPF = TB ? 2 : 1, RPA = TA ? 2 : 1;  // LDS read instructions per fragment
   __builtin_amdgcn_sched_group_barrier(0x100, (MI * RPA + RPF) * NIMGS, 0);
-  pin_pipeline<0, 2 * NI, MI * RPA * NIMGS, RPF * NIMGS, MI * PASSES>();
+  pin_pipeline<0, KS * NI, (KS == 2 ? MI * RPA * NIMGS : 0), RPF * NIMGS, MI * PASSES>();
 }
 
 // ---- epilogue ------------------------------------------------------------------------------------
@@ -421,7 +430,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmParams& g, f32x4_t (&acc
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, int PASSES, bool APL, bool BPL>
+template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int PASSES, bool APL, bool BPL>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams g) {
   constexpr int MI = WM / 16, NI = WN / 16;
   constexpr int WAVES_N = BN / WN;
@@ -471,10 +480,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams g) {
   __amdgpu_buffer_rsrc_t rsrc_a_lo = uniform_rsrc((const char*)g.A + (APL ? g.a_lo_off : 0), g.a_bytes);
   __amdgpu_buffer_rsrc_t rsrc_b_lo = uniform_rsrc((const char*)g.B + (BPL ? g.b_lo_off : 0), g.b_bytes);
 
-  RegStager<BM, TA, PASSES> ra;
-  RegStager<BN, TB, PASSES> rb;
-  DmaStager<BM, TA, PASSES> da;
-  DmaStager<BN, TB, PASSES> db;
+  RegStager<BM, BK, TA, PASSES> ra;
+  RegStager<BN, BK, TB, PASSES> rb;
+  DmaStager<BM, BK, TA, PASSES> da;
+  DmaStager<BN, BK, TB, PASSES> db;
   if (APL) da.init(wave, lane, m0, g.lda, kt_begin);
   else ra.init(tid, m0, g.lda, kt_begin);
   if (BPL) db.init(wave, lane, n0, g.ldb, kt_begin);
@@ -511,9 +520,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams g) {
       else rb.load(rsrc_b);
     }
     if constexpr ((APL || BPL) && (TA || TB))
-      compute_tile_preload<BM, BN, MI, NI, TA, TB, PASSES>(a_cur, b_cur, wm0, wn0, lane, acc);
+      compute_tile_preload<BM, BN, BK, MI, NI, TA, TB, PASSES>(a_cur, b_cur, wm0, wn0, lane, acc);
     else
-      compute_tile<BM, BN, MI, NI, TA, TB, PASSES>(a_cur, b_cur, wm0, wn0, lane, acc);
+      compute_tile<BM, BN, BK, MI, NI, TA, TB, PASSES>(a_cur, b_cur, wm0, wn0, lane, acc);
     if (!APL || !BPL || !dbuf) {
       __syncthreads();  // every wave is done reading the single-buffered image(s)
       if (more && !(g.ablate & 4)) {
@@ -550,12 +559,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // Explicit instantiation of every kernel the dispatcher can reach: hipcc (ROCm 7.2) emits the host launch stub for only
 // a few of the implicit instantiations of this 9-parameter kernel template, leaving the others undefined at load time.
-#define LR2_GEMM_INST(BM, WN, TA, TB, P, APL, BPL) \
-  template __global__ void gemm_kernel<BM, 128, 64, WN, TA, TB, P, APL, BPL>(GemmParams);
-#define LR2_GEMM_INST_SRC(BM, WN, TA, TB, P)    \
-  LR2_GEMM_INST(BM, WN, TA, TB, P, false, false) \
-  LR2_GEMM_INST(BM, WN, TA, TB, P, true, false)  \
-  LR2_GEMM_INST(BM, WN, TA, TB, P, true, true)
+#define LR2_GEMM_INST(BM, BK, WN, TA, TB, P, APL, BPL) \
+  template __global__ void gemm_kernel<BM, 128, BK, 64, WN, TA, TB, P, APL, BPL>(GemmParams);
+#define LR2_GEMM_INST_SRC(BM, WN, TA, TB, P)        \
+  LR2_GEMM_INST(BM, 64, WN, TA, TB, P, false, false) \
+  LR2_GEMM_INST(BM, 64, WN, TA, TB, P, true, false)  \
+  LR2_GEMM_INST(BM, 64, WN, TA, TB, P, true, true)   \
+  LR2_GEMM_INST(BM, 32, WN, TA, TB, P, true, true)
 #define LR2_GEMM_INST_FORM(BM, WN, P)           \
   LR2_GEMM_INST_SRC(BM, WN, false, false, P)     \
   LR2_GEMM_INST_SRC(BM, WN, false, true, P)      \
@@ -565,7 +575,7 @@ LR2_GEMM_INST_FORM(128, 64, 3)
 LR2_GEMM_INST_FORM(64, 32, 1)
 LR2_GEMM_INST_FORM(64, 32, 3)
 
-template <int BM, int BN, int WM, int WN, bool TA, bool TB, int PASSES, bool APL, bool BPL>
+template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int PASSES, bool APL, bool BPL>
 int launch(const GemmParams& p_in, int splits, hipStream_t stream) {
   GemmParams p = p_in;
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -577,7 +587,7 @@ int launch(const GemmParams& p_in, int splits, hipStream_t stream) {
   constexpr size_t epi_lds = (size_t)4 * 32 * (WN + 4) * 4;
   const size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
   constexpr size_t max_lds = (size_t)2 * NIMG * BM * BK * 2 + (size_t)2 * NIMG * BN * BK * 2;
-  auto kern = gemm_kernel<BM, BN, WM, WN, TA, TB, PASSES, APL, BPL>;
+  auto kern = gemm_kernel<BM, BN, BK, WM, WN, TA, TB, PASSES, APL, BPL>;
   static bool attr_set = false;
   if (!attr_set) {
     if (lr2_allow_dynamic_lds(kern, max_lds > epi_lds ? max_lds : epi_lds, "gemm")) return LR2_ERR_LAUNCH;
@@ -587,21 +597,21 @@ int launch(const GemmParams& p_in, int splits, hipStream_t stream) {
   return lr2_launch_status(__func__);
 }
 
-template <bool TA, bool TB, bool APL, bool BPL>
+template <int BK, bool TA, bool TB, bool APL, bool BPL>
 int dispatch(const GemmParams& p, int splits, int bm, int passes, hipStream_t stream) {
   if (passes == 1) {
-    if (bm == 64) return launch<64, 128, 64, 32, TA, TB, 1, APL, BPL>(p, splits, stream);
-    return launch<128, 128, 64, 64, TA, TB, 1, APL, BPL>(p, splits, stream);
+    if (bm == 64) return launch<64, 128, BK, 64, 32, TA, TB, 1, APL, BPL>(p, splits, stream);
+    return launch<128, 128, BK, 64, 64, TA, TB, 1, APL, BPL>(p, splits, stream);
   }
-  if (bm == 64) return launch<64, 128, 64, 32, TA, TB, 3, APL, BPL>(p, splits, stream);
-  return launch<128, 128, 64, 64, TA, TB, 3, APL, BPL>(p, splits, stream);
+  if (bm == 64) return launch<64, 128, BK, 64, 32, TA, TB, 3, APL, BPL>(p, splits, stream);
+  return launch<128, 128, BK, 64, 64, TA, TB, 3, APL, BPL>(p, splits, stream);
 }
 
-template <bool APL, bool BPL>
+template <int BK, bool APL, bool BPL>
 int dispatch_form(const GemmParams& p, int splits, int bm, int passes, int ta, int tb, hipStream_t s) {
-  if (!ta && !tb) return dispatch<false, false, APL, BPL>(p, splits, bm, passes, s);
-  if (!ta && tb) return dispatch<false, true, APL, BPL>(p, splits, bm, passes, s);
-  if (ta && tb) return dispatch<true, true, APL, BPL>(p, splits, bm, passes, s);
+  if (!ta && !tb) return dispatch<BK, false, false, APL, BPL>(p, splits, bm, passes, s);
+  if (!ta && tb) return dispatch<BK, false, true, APL, BPL>(p, splits, bm, passes, s);
+  if (ta && tb) return dispatch<BK, true, true, APL, BPL>(p, splits, bm, passes, s);
   return LR2_ERR_ARG;  // (1,0) is not a form the path needs
 }
 
@@ -642,6 +652,18 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   if (block_m != 64) block_m = 128;
   // K-contiguous operands need whole K tiles (a ragged K would read into the next row, not zeros); ragged M / N are
   // handled by the zero-filling range check on loads plus masked stores.
+  static int bk_env = -1, ablate = -1, stages = -1;
+  if (ablate < 0) {
+    const char* e = getenv("LR2_GEMM_ABLATE");
+    ablate = e ? atoi(e) : 0;
+    const char* st = getenv("LR2_GEMM_DMA_STAGES");
+    stages = st ? atoi(st) : 0;
+    const char* bk = getenv("LR2_GEMM_BK");
+    bk_env = bk ? (atoi(bk) == 64 ? 64 : 32) : 0;
+  }
+  // planes x planes with a contraction-strided B (NN, TN): 32-deep K tiles, two LDS stages (64 KB), two workgroups per
+  // CU -- measured +10-14 % on the wgrad shapes; NT and anything with an fp32 operand: 64-deep tiles, one stage.
+  const int BK = (a_planes && b_planes) ? (bk_env ? bk_env : (trans_b ? 32 : 64)) : 64;
   if ((!trans_a || !trans_b) && (K % BK != 0)) return LR2_ERR_SHAPE;
   const int a_align = a_planes ? 8 : 4, b_align = b_planes ? 8 : 4;  // 16-byte rows
   if ((lda % a_align) || (ldb % b_align) || (N % 4)) return LR2_ERR_SHAPE;
@@ -672,22 +694,15 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   splits = (total_k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
   p.partial = splits > 1 ? (float*)splitk_ws : nullptr;
   p.epi = to_device_epilogue(epi);
-  {
-    static int ablate = -1, stages = -1;
-    if (ablate < 0) {
-      const char* e = getenv("LR2_GEMM_ABLATE");
-      ablate = e ? atoi(e) : 0;
-      const char* st = getenv("LR2_GEMM_DMA_STAGES");
-      stages = st ? atoi(st) : 1;   // measured: one image + 2 workgroups/CU beats two images + 1 workgroup/CU
-    }
-    p.ablate = ablate;
-    p.dma_stages = stages == 1 ? 1 : 2;
-  }
+  p.ablate = ablate;
+  // 64-deep planes tiles: one image + 2 workgroups/CU measured faster than two images + 1 workgroup/CU
+  p.dma_stages = stages ? (stages == 1 ? 1 : 2) : (BK == 32 ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (a_planes && b_planes) rc = dispatch_form<true, true>(p, splits, block_m, passes, trans_a, trans_b, s);
-  else if (a_planes) rc = dispatch_form<true, false>(p, splits, block_m, passes, trans_a, trans_b, s);
-  else rc = dispatch_form<false, false>(p, splits, block_m, passes, trans_a, trans_b, s);
+  if (a_planes && b_planes && BK == 32) rc = dispatch_form<32, true, true>(p, splits, block_m, passes, trans_a, trans_b, s);
+  else if (a_planes && b_planes) rc = dispatch_form<64, true, true>(p, splits, block_m, passes, trans_a, trans_b, s);
+  else if (a_planes) rc = dispatch_form<64, true, false>(p, splits, block_m, passes, trans_a, trans_b, s);
+  else rc = dispatch_form<64, false, false>(p, splits, block_m, passes, trans_a, trans_b, s);
   if (rc) return rc;
   if (splits > 1) {
     const size_t total4 = (size_t)M * N / 4;

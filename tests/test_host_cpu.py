@@ -23,39 +23,40 @@ def native():
     return _native
 
 
-def test_state_dict_keys_match_reference_checkpoints():
+@pytest.fixture(scope="module")
+def small_models():
+    """One ActorCritic and one Reward for the whole module (each head holds a 1.9 GB out_layer.fc1 even at
+    max_imgs=1, the smallest the architecture allows -- only that layer's input width depends on max_imgs)."""
     from lr2ppo_amd.finetune import ppo
+    small = argparse.Namespace(**{**ARGS, "max_imgs": 1})
+    ac = ppo.ActorCritic(small, None)
+    return {"actor": ac.actor, "critic": ac.critic, "reward": ppo.Reward(small, None), "actor_critic": ac}
+
+
+def test_state_dict_keys_match_reference_checkpoints(small_models):
     with open(os.path.join(GOLD, "keys.json")) as f:
         keys = json.load(f)
-    # max_imgs=1 keeps the allocation small; only out_layer.fc1's input width depends on it
-    small = argparse.Namespace(**{**ARGS, "max_imgs": 1})
-    for kind, cls in (("actor", ppo.Actor), ("critic", ppo.Critic), ("reward", ppo.Reward)):
-        mod = cls(small, None)
+    for kind in ("actor", "critic", "reward"):
+        mod = small_models[kind]
         got = [(n, list(p.shape)) for n, p in mod.named_parameters()]
         want = [(n, s if n != "out_layer.fc1.weight" else [3072, 197 * 768]) for n, s in keys[kind]]
         assert got == want, kind
         assert list(mod.state_dict().keys()) == [n for n, _ in keys[kind]]
-    ac = ppo.ActorCritic(small, None)
+    ac = small_models["actor_critic"]
     assert sorted({k.split(".")[0] for k in ac.state_dict()}) == keys["actor_critic_prefixes"]
 
 
-def test_decay_groups_follow_the_substring_rule():
+def test_decay_groups_follow_the_substring_rule(small_models):
     from lr2ppo_amd.finetune import ppo
-    small = argparse.Namespace(**{**ARGS, "max_imgs": 1})
-    groups = ppo._grouped(list(ppo.Critic(small, None).named_parameters()))
-    named = dict(ppo.Critic(small, None).named_parameters())
-    n_decay = len(groups[0]["params"])
-    n_nodecay = len(groups[1]["params"])
+    c = small_models["critic"]
+    named = dict(c.named_parameters())
+    groups = ppo._grouped(list(named.items()))
     names = list(named)
-    assert n_nodecay == sum(1 for n in names if "bias" in n)          # no gamma/beta names in the head
-    assert n_decay == len(names) - n_nodecay
+    assert len(groups[1]["params"]) == sum(1 for n in names if "bias" in n)   # no gamma/beta names in the head
+    assert len(groups[0]["params"]) == len(names) - len(groups[1]["params"])
     # LayerNorm *weights* and pos_emb are decayed (SURVEY quirk 14)
     decayed = {id(p) for p in groups[0]["params"]}
-    c = ppo.Critic(small, None)
-    g2 = ppo._grouped(list(c.named_parameters()))
-    d2 = {id(p) for p in g2[0]["params"]}
-    assert id(dict(c.named_parameters())["xit.1.0.weight"]) in d2 and id(dict(c.named_parameters())["pos_emb.weight"]) in d2
-    assert decayed is not None
+    assert id(named["xit.1.0.weight"]) in decayed and id(named["pos_emb.weight"]) in decayed
 
 
 def test_linear_schedule_matches_reference_table():
@@ -117,15 +118,32 @@ def test_header_symbols_are_declared_bound_and_exported(native):
     exported = set(re.findall(r" T (lr2_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
     lib = native.lib()
-    assert lib.lr2_abi_version() == 1
-    assert ctypes.sizeof(native.Epilogue) == 5 * 8 + 4 * 4 + 2 * 4 + 4 + 4 + 4 + 4 + 8
-    assert ctypes.sizeof(native.AdamChunk) == 48
+    assert lib.lr2_abi_version() == int(re.search(r"#define LR2_ABI_VERSION (\d+)", hdr).group(1)) == 2
 
 
-def test_no_cpu_fallback_and_bad_arguments_are_errors(native):
+def test_ctypes_structs_have_the_layout_the_c_compiler_gives_the_header(native, tmp_path):
+    """sizeof / offsetof of every struct in include/lr2ppo_hip.h, as gcc lays it out, against the ctypes mirrors."""
+    structs = {"lr2_epilogue": native.Epilogue, "lr2_adamw_chunk": native.AdamChunk, "lr2_split_chunk": native.SplitChunk}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "lr2ppo_hip.h"', 'int main(void) {']
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, ct in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
+
+
+def test_no_cpu_fallback_and_bad_arguments_are_errors(native, small_models):
     from lr2ppo_amd.finetune import ppo
-    small = argparse.Namespace(**{**ARGS, "max_imgs": 1})
-    actor = ppo.Actor(small, None)
+    actor = small_models["actor"]
     with pytest.raises(TypeError):
         actor(torch.zeros(1, 2, 196, 768), torch.zeros(1, 2, 1, 768), None)     # CPU tensors: refuse, don't emulate
     with pytest.raises(NotImplementedError):
@@ -134,8 +152,8 @@ def test_no_cpu_fallback_and_bad_arguments_are_errors(native):
         ppo.Actor(argparse.Namespace(**{**ARGS, "seq_length": 128}), None)
     # the C entry points validate before launching anything (no GPU is touched by a rejected call)
     lib = native.lib()
-    assert lib.lr2_gemm(None, None, 1, 128, 64, 64, 64, 0, 0, 0, 0, None, None, 1, 128, 3, None) == -1
-    assert lib.lr2_layernorm_fwd(None, None, None, None, None, None, 1, 768, 1e-5, 0, 0, 0, None) == -1
+    assert lib.lr2_gemm(None, None, 1, 128, 64, 64, 64, 0, 0, 0, 0, 0, 0, 0, 0, None, None, 1, 128, 3, None) == -1
+    assert lib.lr2_layernorm_fwd(None, None, None, None, None, 0, None, None, 1, 768, 1e-5, 0, 0, 0, None) == -1
     assert lib.lr2_adamw_multi(None, 0, 1e-3, 0.9, 0.999, 1e-6, None) == -1
 
 

@@ -417,7 +417,7 @@ def test_split_planes_roundtrip_is_17_bit(ops, dev):
                                                   ("TN", 384, 128, 1000, 128, 3), ("NT", 333, 128, 768, 128, 3)])
 def test_gemm_planes_operands_all_forms(ops, dev, form, M, N, K, bm, splits):
     """Both operands as LDS-DMA planes; ragged M / N and ragged contraction (TN) rely on the descriptor's zero fill.
-    The result must equal the fp32-operand kernel bit for bit (same split, same accumulation order)."""
+    Without split-K the result must equal the fp32-operand kernel bit for bit (same accumulation order)."""
     g = torch.Generator().manual_seed(M + N + K)
     ta, tb = form == "TN", form in ("NN", "TN")
     a = _rand(g, K, M) if ta else _rand(g, M, K)
@@ -430,7 +430,10 @@ def test_gemm_planes_operands_all_forms(ops, dev, form, M, N, K, bm, splits):
     _close(out_p, ref, atol=6e-5 * math.sqrt(K), rtol=5e-5, what=f"planes {form}")
     out_f = torch.empty((M, N), device=dev)
     ops.gemm(a.to(dev), b.to(dev), out_f, M, N, K, trans_a=ta, trans_b=tb, block_m=bm, splits=splits, splitk_ws=ws)
-    assert torch.equal(out_p, out_f), f"planes vs fp32 operands differ: {(out_p - out_f).abs().max().item()}"
+    if splits == 1:
+        assert torch.equal(out_p, out_f), f"planes vs fp32 operands differ: {(out_p - out_f).abs().max().item()}"
+    else:  # the planes kernel may cut K into 32-deep tiles, so its split boundaries (summation order) can differ
+        _close(out_p, out_f.double(), atol=2e-5 * math.sqrt(K), rtol=2e-5, what=f"planes vs fp32 {form}")
 
 
 @pytest.mark.parametrize("form,M,N,K,bm", [("NT", 64, 256, 1024, 64), ("NN", 64, 1280, 128, 64), ("NT", 200, 256, 192, 128)])
