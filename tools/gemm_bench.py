@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=int, nargs="*", default=None, help="indices into SHAPES")
     ap.add_argument("--planes", action="store_true", help="operands as pre-split bf16 hi/lo planes (LDS-DMA path)")
+    ap.add_argument("--bm", type=int, default=None, help="override block_m")
+    ap.add_argument("--splits", type=int, default=None, help="override split-K factor")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
@@ -39,14 +41,16 @@ def main():
             ops.split_planes(A, Ap), ops.split_planes(B, Bp)
             A, B = Ap, Bp
         bm, sp = ops.choose_tiling(M, N, K, ta)
+        bm = a.bm or bm
+        sp = a.splits or sp
         ws = torch.empty(max(1, sp) * M * N, device=dev) if sp > 1 else None
         for _ in range(3):
-            ops.gemm(A, B, out, M, N, K, trans_a=ta, trans_b=tb, splitk_ws=ws, passes=a.passes)
+            ops.gemm(A, B, out, M, N, K, trans_a=ta, trans_b=tb, splitk_ws=ws, passes=a.passes, block_m=bm, splits=sp)
         torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         for _ in range(a.iters):
-            ops.gemm(A, B, out, M, N, K, trans_a=ta, trans_b=tb, splitk_ws=ws, passes=a.passes)
+            ops.gemm(A, B, out, M, N, K, trans_a=ta, trans_b=tb, splitk_ws=ws, passes=a.passes, block_m=bm, splits=sp)
         e.record()
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / a.iters
