@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 2
+#define LR2_ABI_VERSION 3
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -50,6 +50,14 @@ typedef struct lr2_epilogue {
   uint32_t drop_site;
   uint32_t _pad;
   uint64_t drop_seed;
+  /* Fused optimizer step (weight-gradient GEMMs): when adam_p is set the result g[m,n] (after alpha) is not stored but
+   * consumed by the AdamW update of lr2_adamw_multi on (adam_p, adam_m, adam_v)[m, ld_out*m + n]; `out` may be NULL.
+   * The 2 GB gradient of out_layer.fc1.weight is then never written to or read back from HBM.
+   * replaces: the fc1.weight slice of optimizers.py:344-402 + the .grad write of loss.backward(). */
+  void* adam_p;
+  void* adam_m;
+  void* adam_v;
+  double adam_lr, adam_beta1, adam_beta2, adam_eps, adam_weight_decay;
 } lr2_epilogue;
 
 /* C[M,N] = op(A).op(B), fp32 in / fp32 out, computed on bf16 MFMA with fp32 accumulation.

@@ -61,7 +61,10 @@ class Epilogue(C.Structure):
                 ("out_z", C.c_void_p), ("out_hi", C.c_void_p), ("out_lo_off", C.c_uint64), ("ld_planes", C.c_int32),
                 ("ld_resid", C.c_int32), ("ld_aux", C.c_int32), ("ld_out", C.c_int32),
                 ("ld_z", C.c_int32), ("act", C.c_int32), ("accumulate", C.c_int32), ("alpha", C.c_float),
-                ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("_pad", C.c_uint32), ("drop_seed", C.c_uint64)]
+                ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("_pad", C.c_uint32), ("drop_seed", C.c_uint64),
+                ("adam_p", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_lr", C.c_double),
+                ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
+                ("adam_weight_decay", C.c_double)]
 
 
 class SplitChunk(C.Structure):
@@ -132,7 +135,7 @@ def lib() -> C.CDLL:
                 raise RuntimeError(f"lr2ppo_amd: {LIB_PATH} does not export {name}") from e
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        if handle.lr2_abi_version() != 2:
+        if handle.lr2_abi_version() != 3:
             raise RuntimeError("lr2ppo_amd: ABI version mismatch between python package and native library")
         _lib = handle
         return _lib

@@ -106,7 +106,24 @@ struct Epilogue {
   float drop_scale;      // 1/(1-p) or 0 when dropout is off
   uint32_t drop_thr;
   uint64_t drop_key;
+  float* adam_p;         // fused AdamW step on the result (weight-gradient GEMMs); NULL = store the result
+  float* adam_m;
+  float* adam_v;
+  float adam_lr, adam_b1, adam_b2, adam_ob1, adam_ob2, adam_eps, adam_wd;
 };
+
+// One AdamW element update, TencentPretrain semantics (correct_bias=False; eps outside the sqrt; decay after the
+// update, on the updated weight).  Shared by adamw_kernel and the GEMM's fused epilogue so both give the same bits.
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float lr, float b1, float b2,
+                                            float ob1, float ob2, float eps, float wd) {
+  // every rounding pinned (no compiler-chosen contraction): the two call sites must agree bit for bit
+#pragma clang fp contract(off)
+  m = __builtin_fmaf(g, ob1, m * b1);
+  v = __builtin_fmaf(g * g, ob2, v * b2);
+  const float upd = m / (sqrtf(v) + eps);
+  p = __builtin_fmaf(-lr, upd, p);
+  if (wd > 0.f) p = __builtin_fmaf(p, -(lr * wd), p);
+}
 
 // hipGetLastError() reports the calling thread's most recent error from ANY runtime call, including benign ones
 // made by the host framework (hipErrorNotReady from event queries).  Clear the slot before a launch so that the

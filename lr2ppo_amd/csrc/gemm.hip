@@ -382,6 +382,16 @@ __device__ __forceinline__ void epilogue_vec4(const Epilogue& e, float4 v, int m
     const float4 r = ld4(e.resid + (size_t)m * e.ld_resid + n);
     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
   }
+  if (e.adam_p) {  // fused optimizer step (reached through the split-K reducer; the direct path prefetches, see below)
+    const size_t off = (size_t)m * e.ld_out + n;
+    float4 p = ld4(e.adam_p + off), mm = ld4(e.adam_m + off), vv = ld4(e.adam_v + off);
+    adam_update(p.x, v.x, mm.x, vv.x, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
+    adam_update(p.y, v.y, mm.y, vv.y, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
+    adam_update(p.z, v.z, mm.z, vv.z, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
+    adam_update(p.w, v.w, mm.w, vv.w, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
+    st4(e.adam_p + off, p); st4(e.adam_m + off, mm); st4(e.adam_v + off, vv);
+    return;
+  }
   if (e.out) {
     float* p = e.out + (size_t)m * e.ld_out + n;
     if (e.accumulate) {
@@ -423,6 +433,58 @@ __device__ __forceinline__ void epilogue_wave(const GemmParams& g, f32x4_t (&acc
       if (m < g.M && n < g.N) {
         if (partial) st4(partial + (size_t)m * g.N + n, v);
         else epilogue_vec4(g.epi, v, m, n, g.N);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Fused AdamW epilogue: the weight, exp_avg and exp_avg_sq vectors of all 32 rows of a slab are requested BEFORE the
+// accumulators are transposed through LDS (24 independent 16-B loads per lane in flight; with the loads issued one
+// slab pass at a time the 12 GB p/m/v stream of out_layer.fc1 would be latency-bound at ~3 TB/s).
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void epilogue_wave_adam(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw,
+                                                   int nw, int lane) {
+  constexpr int LDW = WN + 4;
+  constexpr int LPR = WN / 4;
+  constexpr int RPP = 64 / LPR;
+  constexpr int NP = 32 / RPP;
+  const Epilogue& e = g.epi;
+  const int gq = lane >> 4, c16 = lane & 15;
+#pragma unroll
+  for (int half = 0; half < WM / 32; ++half) {
+    float4 p4[NP], m4[NP], v4[NP];
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+      const int m = mw + 32 * half + pass * RPP + lane / LPR, n = nw + (lane % LPR) * 4;
+      if (m < g.M && n < g.N) {
+        const size_t off = (size_t)m * e.ld_out + n;
+        p4[pass] = ld4(e.adam_p + off);
+        m4[pass] = ld4(e.adam_m + off);
+        v4[pass] = ld4(e.adam_v + off);
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(16 * ii + 4 * gq + r) * LDW + 16 * j + c16] = acc[2 * half + ii][j][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+      const int row = pass * RPP + lane / LPR, col = (lane % LPR) * 4;
+      float4 v = ld4(slab + row * LDW + col);
+      const int m = mw + 32 * half + row, n = nw + col;
+      if (m < g.M && n < g.N) {
+        v.x *= e.alpha; v.y *= e.alpha; v.z *= e.alpha; v.w *= e.alpha;
+        float4 p = p4[pass], mm = m4[pass], vv = v4[pass];
+        adam_update(p.x, v.x, mm.x, vv.x, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
+        adam_update(p.y, v.y, mm.y, vv.y, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
+        adam_update(p.z, v.z, mm.z, vv.z, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
+        adam_update(p.w, v.w, mm.w, vv.w, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
+        const size_t off = (size_t)m * e.ld_out + n;
+        st4(e.adam_p + off, p); st4(e.adam_m + off, mm); st4(e.adam_v + off, vv);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -539,7 +601,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams g) {
   // ---- epilogue through LDS (operand images are dead after the last barrier) ----
   float* slab = reinterpret_cast<float*>(smem) + wave * (32 * (WN + 4));
   float* part = g.partial ? g.partial + (size_t)blockIdx.z * (size_t)g.M * (size_t)g.N : nullptr;
-  epilogue_wave<WM, WN, MI, NI>(g, acc, slab, m0 + wm0, n0 + wn0, lane, part);
+  if (g.epi.adam_p && !part) epilogue_wave_adam<WM, WN, MI, NI>(g, acc, slab, m0 + wm0, n0 + wn0, lane);
+  else epilogue_wave<WM, WN, MI, NI>(g, acc, slab, m0 + wm0, n0 + wn0, lane, part);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N,
@@ -637,6 +700,18 @@ Epilogue to_device_epilogue(const lr2_epilogue* e) {
     d.drop_thr = dropout_threshold(e->drop_p);
     d.drop_key = (((uint64_t)e->drop_site) << 40) ^ (e->drop_seed * 0x9E3779B97F4A7C15ull);
   }
+  if (e->adam_p) {  // same double -> float conversions as lr2_adamw_multi
+    d.adam_p = (float*)e->adam_p;
+    d.adam_m = (float*)e->adam_m;
+    d.adam_v = (float*)e->adam_v;
+    d.adam_lr = (float)e->adam_lr;
+    d.adam_b1 = (float)e->adam_beta1;
+    d.adam_b2 = (float)e->adam_beta2;
+    d.adam_ob1 = (float)(1.0 - e->adam_beta1);
+    d.adam_ob2 = (float)(1.0 - e->adam_beta2);
+    d.adam_eps = (float)e->adam_eps;
+    d.adam_wd = (float)e->adam_weight_decay;
+  }
   return d;
 }
 
@@ -647,7 +722,8 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
                         uint64_t a_bytes, uint64_t b_bytes, int a_planes, uint64_t a_lo_off, int b_planes,
                         uint64_t b_lo_off, const lr2_epilogue* epi, void* splitk_ws, int splits, int block_m, int passes,
                         void* stream) {
-  if (!A || !B || M <= 0 || N <= 0 || K <= 0 || !epi || (!epi->out && !epi->out_hi)) return LR2_ERR_ARG;
+  if (!A || !B || M <= 0 || N <= 0 || K <= 0 || !epi || (!epi->out && !epi->out_hi && !epi->adam_p)) return LR2_ERR_ARG;
+  if (epi->adam_p && (!epi->adam_m || !epi->adam_v || epi->out || epi->out_hi || epi->ld_out % 4)) return LR2_ERR_ARG;
   if (passes != 1 && passes != 3) return LR2_ERR_ARG;
   if (block_m != 64) block_m = 128;
   // K-contiguous operands need whole K tiles (a ragged K would read into the next row, not zeros); ragged M / N are

@@ -310,18 +310,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict_
                                                     float ob1, float ob2, float eps) {
   const AdamChunk c = table[blockIdx.x];
   const uint64_t n4 = c.count / 4;
-  const float decay = lr * c.wd;
   float4* p4 = reinterpret_cast<float4*>(c.p);
   const float4* g4 = reinterpret_cast<const float4*>(c.g);
   float4* m4 = reinterpret_cast<float4*>(c.m);
   float4* v4 = reinterpret_cast<float4*>(c.v);
-#define ADAM1(P, G, M, V)                     \
-  {                                           \
-    M = M * b1 + G * ob1;                     \
-    V = V * b2 + G * G * ob2;                 \
-    P = P - lr * (M / (sqrtf(V) + eps));      \
-    if (c.wd > 0.f) P = P + P * (-decay);     \
-  }
+#define ADAM1(P, G, M, V) adam_update(P, G, M, V, lr, b1, b2, ob1, ob2, eps, c.wd);
   for (uint64_t i = threadIdx.x; i < n4; i += 256) {
     float4 p = p4[i], g = g4[i], m = m4[i], v = v4[i];
     ADAM1(p.x, g.x, m.x, v.x) ADAM1(p.y, g.y, m.y, v.y) ADAM1(p.z, g.z, m.z, v.z) ADAM1(p.w, g.w, m.w, v.w)

@@ -134,8 +134,8 @@ def input_planes(owner: torch.Tensor, x2d: torch.Tensor) -> Planes:
     return pl
 
 
-def _splitk_ws(ws: Workspace, M, N, K, trans_a=False):
-    bm, sp = ops.choose_tiling(M, N, K, trans_a)
+def _splitk_ws(ws: Workspace, M, N, K, trans_a=False, trans_b=False):
+    bm, sp = ops.choose_tiling(M, N, K, trans_a, trans_b)
     return (ws.vec("splitk", sp * M * N), sp, bm) if sp > 1 else (None, 1, bm)
 
 
@@ -147,13 +147,13 @@ def linear_fwd(ws, x, w, b, out, M, N, K, **kw):
 
 def linear_dgrad(ws, dy, w, out, M, N_in, N_out, **kw):
     """out[M,N_in] = dy[M,N_out] @ w[N_out,N_in]."""
-    skw, sp, bm = _splitk_ws(ws, M, N_in, N_out)
+    skw, sp, bm = _splitk_ws(ws, M, N_in, N_out, trans_b=True)
     return ops.gemm(dy, w, out, M, N_in, N_out, trans_b=True, splitk_ws=skw, splits=sp, block_m=bm, **kw)
 
 
 def linear_wgrad(ws, dy, x, dw, db, M, N_in, N_out):
     """dw[N_out,N_in] = dy[M,N_out]^T @ x[M,N_in];  db[N_out] = colsum(dy)."""
-    skw, sp, bm = _splitk_ws(ws, N_out, N_in, M, trans_a=True)
+    skw, sp, bm = _splitk_ws(ws, N_out, N_in, M, trans_a=True, trans_b=True)
     ops.gemm(dy, x, dw, N_out, N_in, M, trans_a=True, trans_b=True, lda=N_out, ldb=N_in, splitk_ws=skw, splits=sp,
              block_m=bm)
     if db is not None:
@@ -341,9 +341,11 @@ def trunk_forward(ws: Workspace, P, W, text, img, bs: int, tags: int, n_img: int
 
 
 def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *, drop: Optional[DropCfg] = None,
-                   img_shared: bool = False, dp=None):
+                   img_shared: bool = False, dp=None, fc1_update=None):
     """Backward of trunk_forward(save=True); fills G[...] for every trunk parameter (inputs get no gradient:
-    text/img embeddings are data, finetune/ppo.py:827-835).  dg2: fp32 [bs*tags, E]."""
+    text/img embeddings are data, finetune/ppo.py:827-835).  dg2: fp32 [bs*tags, E].
+    fc1_update (ops.AdamArgs): apply the optimizer step of out_layer.fc1.weight inside its weight-gradient GEMM, issued
+    after the last reader of the old weight (the input-gradient GEMM); G[out_layer.fc1.weight] is then left untouched."""
     N = bs * tags
     Mt, F = N * SEQ_LEN, 4 * E
     Mi_src = (bs if img_shared else N) * n_img
@@ -368,7 +370,11 @@ def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *
         fc1_pending = (dp.gather_planes_start(dzo, ws, "dzo_all"), dp.gather_planes_start(flat, ws, "flat_all"))
     else:
         fc1_pending = None
-        linear_wgrad(ws, dzo, flat, G[FC1], G["out_layer.fc1.bias"], N, Wflat, F)
+        if fc1_update is None:
+            linear_wgrad(ws, dzo, flat, G[FC1], G["out_layer.fc1.bias"], N, Wflat, F)
+        else:
+            nb = min(128, N)
+            ops.colsum(dzo, G["out_layer.fc1.bias"], ws.vec("colsum_partials", nb * F), rows=N, cols=F, nblocks=nb)
     dflat = ws.mat("dflat", N, Wflat)
     linear_dgrad(ws, dzo, P[FC1], dflat, N, Wflat, F)
     # image part of the concat -> dense [Mi, E] gradient
@@ -397,9 +403,12 @@ def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *
     dzi = ws.planes("dzi", Mi_src, F)
     linear_dgrad(ws, dimf_p, W["img_proj.fc2.weight"], None, Mi_src, F, E, act=2, aux_z=zi, out_planes=dzi)
     linear_wgrad(ws, dzi, img, G["img_proj.fc1.weight"], G["img_proj.fc1.bias"], Mi_src, E, F)
-    if fc1_pending is not None:
-        dzo_all, flat_all = dp.gather_planes_finish(fc1_pending[0]), dp.gather_planes_finish(fc1_pending[1])
-        Kall = N * dp.world
-        skw, sp, bm = _splitk_ws(ws, F, Wflat, Kall, trans_a=True)
-        ops.gemm(dzo_all, flat_all, G[FC1], F, Wflat, Kall, trans_a=True, trans_b=True, lda=F, ldb=Wflat, splitk_ws=skw,
-                 splits=sp, block_m=bm, alpha=1.0 / dp.world)     # already the rank average
+    if fc1_pending is not None or fc1_update is not None:
+        if fc1_pending is not None:
+            dzo_all, flat_all = dp.gather_planes_finish(fc1_pending[0]), dp.gather_planes_finish(fc1_pending[1])
+            Kall, alpha = N * dp.world, 1.0 / dp.world            # already the rank average
+        else:
+            dzo_all, flat_all, Kall, alpha = dzo, flat, N, 1.0
+        skw, sp, bm = _splitk_ws(ws, F, Wflat, Kall, trans_a=True, trans_b=True)
+        ops.gemm(dzo_all, flat_all, None if fc1_update is not None else G[FC1], F, Wflat, Kall, trans_a=True, trans_b=True,
+                 lda=F, ldb=Wflat, splitk_ws=skw, splits=sp, block_m=bm, alpha=alpha, adam=fc1_update)

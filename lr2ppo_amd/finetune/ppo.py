@@ -277,7 +277,7 @@ class Actor(_Head):
             self._saved = (text2, img2, bs, tags, n_img, shared, drop)
         return logits
 
-    def engine_backward(self, dlogits: torch.Tensor, dp=None):
+    def engine_backward(self, dlogits: torch.Tensor, dp=None, fc1_update=None):
         """Gradients of sum(dlogits * logits) into the flat gradient buffer (call after engine_forward(save=True))."""
         text2, img2, bs, tags, n_img, shared, drop = self._saved
         P, G = self._P(), self.grad_buffers()
@@ -286,7 +286,8 @@ class Actor(_Head):
         g2 = ws.mat("g2", N, FEAT)
         dg2 = ws.mat("dg2", N, FEAT)
         ops.head_bwd(g2, P["head.weight"], dlogits.contiguous().view(-1), dg2, G["head.weight"], G["head.bias"], rows=N, D=FEAT)
-        engine.trunk_backward(ws, P, W, G, text2, img2, dg2, bs, tags, n_img, FEAT, drop=drop, img_shared=shared, dp=dp)
+        engine.trunk_backward(ws, P, W, G, text2, img2, dg2, bs, tags, n_img, FEAT, drop=drop, img_shared=shared, dp=dp,
+                              fc1_update=fc1_update)
         self._saved = None
 
 
@@ -352,7 +353,7 @@ class _TailHead(_Head):
             self._saved = (text_p, img_p, bs, t_out, n_img, drop, drop_t)
         return value
 
-    def engine_backward(self, dvalue: torch.Tensor, dp=None):
+    def engine_backward(self, dvalue: torch.Tensor, dp=None, fc1_update=None):
         text_g, img_g, bs, t_out, n_img, drop, drop_t = self._saved
         P, G = self._P(), self.grad_buffers()
         ws, W = self._workspace(dvalue.device), self._weights(P, refresh=False)
@@ -366,7 +367,8 @@ class _TailHead(_Head):
                             drop=drop_t, same_xy=True)
         G["pos_emb.weight"].zero_()
         ops.period_rows_grad(dxin, G["pos_emb.weight"], rows=M, D=FEAT, period=t_out)
-        engine.trunk_backward(ws, P, W, G, text_g, img_g, dxin, bs, t_out, n_img, FEAT, drop=drop, img_shared=False, dp=dp)
+        engine.trunk_backward(ws, P, W, G, text_g, img_g, dxin, bs, t_out, n_img, FEAT, drop=drop, img_shared=False, dp=dp,
+                              fc1_update=fc1_update)
         self._saved = None
 
 
@@ -586,9 +588,15 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
     ops.ppo_loss(logits.view(bs, tags), old_scores.contiguous(), rewards.contiguous(), old_value.contiguous(), value,
                  next_state.contiguous(), scal, per, dscores, dvalue, B=bs, T=tags, kl_w=args.kl_div_loss_weight,
                  ent_w=args.entropy_weight, value_clip=args.value_clip, margin=0.01, adv_eps=-0.1)
-    actor.engine_backward(dscores, dp)
+    # out_layer.fc1.weight (96 % of each model): gradient GEMM and AdamW step in one kernel, the 2 GB gradient is never
+    # materialised (args.fuse_fc1_update=False restores the separate wgrad + optimizer passes; same bits either way)
+    fuse = getattr(args, "fuse_fc1_update", True) and hasattr(optimizer, "external_update") \
+        and hasattr(critic_optim, "external_update")
+    fa = optimizer.external_update(actor.out_layer.fc1.weight) if fuse else None
+    fc = critic_optim.external_update(critic.out_layer.fc1.weight) if fuse else None
+    actor.engine_backward(dscores, dp, fc1_update=fa)
     wa = dp.reduce_start(actor)            # overlaps the critic's backward
-    critic.engine_backward(dvalue, dp)
+    critic.engine_backward(dvalue, dp, fc1_update=fc)
     wc = dp.reduce_start(critic)
     dp.finish(wa)
     optimizer.step()

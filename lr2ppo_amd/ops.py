@@ -29,12 +29,16 @@ def get_gemm_passes() -> int:
 
 # ---- optional per-launch timing (bench.py): HIP events on the launch stream around selected entry points ----
 _PROF = None
+_PROF_ONLY = None
 
 
-def profile_start():
-    """Start collecting (start, end) HIP events per kernel signature; see profile_stop()."""
-    global _PROF
+def profile_start(only=None):
+    """Start collecting (start, end) HIP events per kernel signature; see profile_stop().  `only`: a collection of
+    signatures to restrict the collection to (two event records per launch cost ~25 us of host time; with ~120 timed
+    launches per PPO step that alone can make the step host-bound)."""
+    global _PROF, _PROF_ONLY
     _PROF = {}
+    _PROF_ONLY = None if only is None else frozenset(only)
 
 
 def profile_stop():
@@ -56,13 +60,14 @@ class _Timed:
         self.key, self.flops, self.bytes = key, flops, nbytes
 
     def __enter__(self):
-        if _PROF is not None:
+        self.s = None
+        if _PROF is not None and (_PROF_ONLY is None or self.key in _PROF_ONLY):
             self.s = torch.cuda.Event(enable_timing=True)
             self.s.record()
         return self
 
     def __exit__(self, *exc):
-        if _PROF is not None:
+        if self.s is not None and _PROF is not None:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             rec = _PROF.setdefault(self.key, {"ev": [], "flops": self.flops, "bytes": self.bytes})
@@ -136,12 +141,29 @@ def split_planes_multi(table_dev: torch.Tensor, n_chunks: int):
     _nat.check(_nat.lib().lr2_split_planes_multi(table_dev.data_ptr(), n_chunks, _stream()), "lr2_split_planes_multi")
 
 
-def choose_tiling(M: int, N: int, K: int, trans_a: bool):
+class AdamArgs:
+    """AdamW step fused into a weight-gradient GEMM (lr2_epilogue.adam_*): the GEMM result is the gradient of `p` and is
+    consumed on the fly -- m, v, p are updated exactly as lr2_adamw_multi would, the gradient never reaches HBM."""
+    __slots__ = ("p", "m", "v", "lr", "beta1", "beta2", "eps", "weight_decay")
+
+    def __init__(self, p, m, v, lr, beta1, beta2, eps, weight_decay):
+        _chk_f32(p, m, v)
+        if not (p.is_contiguous() and m.is_contiguous() and v.is_contiguous() and p.shape == m.shape == v.shape):
+            raise ValueError("AdamArgs: p, m, v must be contiguous and of one shape")
+        self.p, self.m, self.v = p, m, v
+        self.lr, self.beta1, self.beta2, self.eps, self.weight_decay = lr, beta1, beta2, eps, weight_decay
+
+
+def choose_tiling(M: int, N: int, K: int, trans_a: bool, trans_b: bool = False):
     """(block_m, splits).  256 CUs hold 2 (BM=128) or 3 (BM=64) workgroups each; pick the split-K factor that minimises
     rounds x (K-tiles per workgroup + fixed prologue/epilogue cost) + the cost of writing/reading the partial slabs, so
     that skinny GEMMs fill the chip without wave-quantisation tails (576 workgroups on 512 slots = 2 rounds)."""
     bm = 64 if (M <= 64 and not trans_a) else 128
     tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
+    if bm == 128 and not trans_a and not trans_b and 512 < tiles < 1024:
+        # NT with between one and two rounds of 128-row tiles (M=12544, N=768: 588 tiles on 512 slots): the half-empty
+        # second round costs more than the lower intensity of 64-row tiles (measured +9..11 %)
+        return 64, 1
     k_tiles = (K + 63) // 64
     slots = 768 if bm == 64 else 512
     if tiles >= slots or k_tiles < 8:
@@ -164,9 +186,10 @@ def gemm(a, b, out: Optional[torch.Tensor], M: int, N: int, K: int, *, trans_a=F
          aux_z: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, drop: Optional[Drop] = None,
          accumulate: bool = False, alpha: float = 1.0, out_planes: Optional[Planes] = None,
          splitk_ws: Optional[torch.Tensor] = None, splits: Optional[int] = None, block_m: Optional[int] = None,
-         passes: Optional[int] = None):
+         passes: Optional[int] = None, adam: Optional[AdamArgs] = None):
     """out[M,N] = op(a) @ op(b) with the fused epilogue; a / b are fp32 tensors or Planes; the result goes to `out`
-    (fp32) and/or `out_planes`.  See lr2_gemm in include/lr2ppo_hip.h."""
+    (fp32) and/or `out_planes`, or -- with `adam` -- straight into the AdamW update of adam.p[M,N].
+    See lr2_gemm in include/lr2ppo_hip.h."""
     a_pl, b_pl = isinstance(a, Planes), isinstance(b, Planes)
     _chk_f32(None if a_pl else a, None if b_pl else b, out, bias, out_z, aux_z, resid)
     if lda is None:
@@ -175,7 +198,7 @@ def gemm(a, b, out: Optional[torch.Tensor], M: int, N: int, K: int, *, trans_a=F
         ldb = N if trans_b else K
     if ld_out is None:
         ld_out = N
-    bm, sp = choose_tiling(M, N, K, trans_a)
+    bm, sp = choose_tiling(M, N, K, trans_a, trans_b)
     if block_m is not None:
         bm = block_m
     if splits is not None:
@@ -192,11 +215,19 @@ def gemm(a, b, out: Optional[torch.Tensor], M: int, N: int, K: int, *, trans_a=F
     e.act, e.accumulate, e.alpha = act, 1 if accumulate else 0, alpha
     if drop is not None and drop.p > 0.0:
         e.drop_p, e.drop_seed, e.drop_site = drop.p, drop.seed, drop.site
+    if adam is not None:
+        if out is not None or out_planes is not None or adam.p.numel() != M * N or ld_out != N:
+            raise ValueError("gemm(adam=...): the result is consumed by the update; p must be [M, N] and out/out_planes None")
+        e.adam_p, e.adam_m, e.adam_v = adam.p.data_ptr(), adam.m.data_ptr(), adam.v.data_ptr()
+        e.adam_lr, e.adam_beta1, e.adam_beta2 = adam.lr, adam.beta1, adam.beta2
+        e.adam_eps, e.adam_weight_decay = adam.eps, adam.weight_decay
     a_bytes = a.plane_bytes() if a_pl else a.numel() * 4
     b_bytes = b.plane_bytes() if b_pl else b.numel() * 4
     form = "TN" if trans_a else ("NN" if trans_b else "NT")
     src = ("p" if a_pl else "f") + ("p" if b_pl else "f")
-    with _Timed(f"gemm_{form}_{src}_M{M}_N{N}_K{K}", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)):
+    label = f"gemm_{form}_{src}_M{M}_N{N}_K{K}" + ("_adamw" if adam is not None else "")
+    alg_bytes = 4.0 * (M * K + N * K) + (24.0 if adam is not None else 4.0) * M * N
+    with _Timed(label, 2.0 * M * N * K, alg_bytes):
         rc = _nat.lib().lr2_gemm(a.data_ptr(), b.data_ptr(), M, N, K, lda, ldb, 1 if trans_a else 0, 1 if trans_b else 0,
                                  a_bytes, b_bytes, 1 if a_pl else 0, a.lo_off * 2 if a_pl else 0, 1 if b_pl else 0,
                                  b.lo_off * 2 if b_pl else 0, C.byref(e), _ptr(splitk_ws), sp, bm, passes or _PASSES,

@@ -36,26 +36,51 @@ class AdamW(Optimizer):
             raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
         self._tables = {}
+        self._external = set()
+
+    def _ensure_state(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p.data)
+            st["exp_avg_sq"] = torch.zeros_like(p.data)
+        return st
+
+    def external_update(self, p) -> "ops.AdamArgs":
+        """Take parameter `p` out of the next step(): its update is done by a kernel that produces the gradient and
+        applies this optimizer's rule in one pass (ops.gemm(adam=...), used for the 2 GB out_layer.fc1.weight).
+        Returns the state tensors and the hyper-parameters the next step() would have used; p.grad is not read."""
+        for group in self.param_groups:
+            if any(q is p for q in group["params"]):
+                break
+        else:
+            raise ValueError("external_update: parameter is not managed by this optimizer")
+        if group["correct_bias"]:
+            raise NotImplementedError("external_update needs correct_bias=False (what LR2PPO uses)")
+        if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+            raise RuntimeError("lr2ppo_amd AdamW needs contiguous float32 HIP parameters")
+        st = self._ensure_state(p)
+        st["step"] += 1
+        self._external.add(id(p))
+        return ops.AdamArgs(p.data, st["exp_avg"], st["exp_avg_sq"], group["lr"], group["betas"][0], group["betas"][1],
+                            group["eps"], group["weight_decay"])
 
     def _table(self, gi: int, group):
-        ps = [p for p in group["params"] if p.grad is not None]
+        ps = [p for p in group["params"] if p.grad is not None and id(p) not in self._external]
         if not ps:
-            return None, 0, ps
+            return None, 0, ps, 0
         sig = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
+        gi = (gi, len(ps))        # separate cached tables with / without externally updated parameters
         cached = self._tables.get(gi)
         if cached is not None and cached[0] == sig:
-            return cached[1], cached[2], ps
+            return cached[1], cached[2], ps, cached[3]
         rows = []
         for p in ps:
             if p.grad.is_sparse:
                 raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
             if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or not p.grad.is_contiguous():
                 raise RuntimeError("lr2ppo_amd AdamW needs contiguous float32 HIP parameters and gradients")
-            st = self.state[p]
-            if len(st) == 0:
-                st["step"] = 0
-                st["exp_avg"] = torch.zeros_like(p.data)
-                st["exp_avg_sq"] = torch.zeros_like(p.data)
+            st = self._ensure_state(p)
             n, off = p.numel(), 0
             while off < n:
                 c = min(CHUNK_ELEMS, n - off)
@@ -68,7 +93,7 @@ class AdamW(Optimizer):
         dev = ps[0].device
         table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self._tables[gi] = (sig, table, len(rows), sum(p.numel() for p in ps))
-        return table, len(rows), ps
+        return table, len(rows), ps, self._tables[gi][3]
 
     @torch.no_grad()
     def step(self, closure: Callable = None):
@@ -77,7 +102,7 @@ class AdamW(Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
-            table, n, ps = self._table(gi, group)
+            table, n, ps, n_params = self._table(gi, group)
             if table is None:
                 continue
             beta1, beta2 = group["betas"]
@@ -90,7 +115,8 @@ class AdamW(Optimizer):
                 if group["weight_decay"] > 0.0 and step_size != group["lr"]:
                     # decay must use the raw lr (optimizers.py:399-400): run the decay-free update, then decay
                     raise NotImplementedError("correct_bias=True with weight decay is not used by LR2PPO")
-            ops.adamw_multi(table, n, step_size, beta1, beta2, group["eps"], n_params=self._tables[gi][3])
+            ops.adamw_multi(table, n, step_size, beta1, beta2, group["eps"], n_params=n_params)
+        self._external.clear()
         return loss
 
 

@@ -491,3 +491,30 @@ def test_planes_outputs_of_layernorm_attention_copy(ops, dev):
     got = flat.to_float().cpu()
     _close(got[:, 24:], src.view(3, 16), 1e-6, 3e-5, "copy_rows planes")
     assert torch.all(got[:, :24] == 0)
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(256, 384, 64, 1), (200, 264, 128, 1), (128, 128, 1000, 3)])
+def test_gemm_fused_adamw_epilogue_equals_gemm_then_adamw(ops, dev, M, N, K, splits):
+    """Weight-gradient form (TN) with the optimizer step in the epilogue: p, exp_avg, exp_avg_sq must come out with
+    the same bits as lr2_gemm -> grad followed by lr2_adamw_multi (two steps, decay on)."""
+    from lr2ppo_amd.tencentpretrain.utils.optimizers import AdamW
+    g = torch.Generator().manual_seed(M + N + K)
+    p0 = _rand(g, M, N).to(dev)
+    ws = torch.empty(max(1, splits) * M * N, device=dev)
+    pa, pb = torch.nn.Parameter(p0.clone()), torch.nn.Parameter(p0.clone())
+    oa = AdamW([{"params": [pa], "weight_decay": 0.01}], lr=1e-3, correct_bias=False)
+    ob = AdamW([{"params": [pb], "weight_decay": 0.01}], lr=1e-3, correct_bias=False)
+    pa.grad = torch.zeros_like(pa)
+    pb.grad = torch.full_like(pb, float("nan"))          # never read on the fused path
+    for step in range(2):
+        a, b = _rand(g, K, M), _rand(g, K, N)
+        ap, bp = _planes(ops, a, dev), _planes(ops, b, dev)
+        ops.gemm(ap, bp, pa.grad, M, N, K, trans_a=True, trans_b=True, splits=splits, splitk_ws=ws, alpha=0.5)
+        oa.step()
+        ops.gemm(ap, bp, None, M, N, K, trans_a=True, trans_b=True, splits=splits, splitk_ws=ws, alpha=0.5,
+                 adam=ob.external_update(pb))
+        ob.step()                                        # nothing left to do for pb; clears the hand-over
+        assert torch.equal(pa.detach(), pb.detach()), f"step {step}: weights differ by {(pa - pb).abs().max().item()}"
+        assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"])
+        assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
+    assert not torch.equal(pa.detach(), p0) and oa.state[pa]["step"] == ob.state[pb]["step"] == 2

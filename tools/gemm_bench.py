@@ -40,7 +40,7 @@ def main():
             Ap, Bp = ops.Planes.empty(*A.shape, dev), ops.Planes.empty(*B.shape, dev)
             ops.split_planes(A, Ap), ops.split_planes(B, Bp)
             A, B = Ap, Bp
-        bm, sp = ops.choose_tiling(M, N, K, ta)
+        bm, sp = ops.choose_tiling(M, N, K, ta, tb)
         bm = a.bm or bm
         sp = a.splits or sp
         ws = torch.empty(max(1, sp) * M * N, device=dev) if sp > 1 else None
