@@ -161,8 +161,18 @@ __global__ __launch_bounds__(256) void partials_finish_kernel(const float* __res
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  if (c < cols)
-    for (int b = slice; b < nblocks; b += 4) s += partials[(size_t)b * ld + c];
+  if (c < cols) {
+    // 8 independent loads in flight per thread (the loop is latency-bound: 32 dependent 1-us round trips otherwise);
+    // the association is fixed, so the result does not depend on timing
+    int b = slice;
+    for (; b + 28 < nblocks; b += 32) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = partials[(size_t)(b + 4 * u) * ld + c];
+      s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    for (; b < nblocks; b += 4) s += partials[(size_t)b * ld + c];
+  }
   red[slice][lane] = s;
   __syncthreads();
   if (slice == 0 && c < cols) {
@@ -182,6 +192,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x_
   int r1 = r0 + chunk;
   if (r1 > rows) r1 = rows;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
   for (int r = r0; r < r1; ++r) {
     if (PLANES) {
       const bf16_t* p = (const bf16_t*)x_ + (size_t)r * ld + c;

@@ -157,7 +157,7 @@ def linear_wgrad(ws, dy, x, dw, db, M, N_in, N_out):
     ops.gemm(dy, x, dw, N_out, N_in, M, trans_a=True, trans_b=True, lda=N_out, ldb=N_in, splitk_ws=skw, splits=sp,
              block_m=bm)
     if db is not None:
-        nb = min(128, M)
+        nb = min(512 if N_out <= 1024 else 256, M)     # row chunks: enough workgroups to fill 256 CUs at 1024 columns each
         ops.colsum(dy, db, ws.vec("colsum_partials", nb * N_out), rows=M, cols=N_out, nblocks=nb)
 
 

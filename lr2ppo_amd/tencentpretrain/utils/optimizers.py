@@ -75,6 +75,10 @@ class AdamW(Optimizer):
         if cached is not None and cached[0] == sig:
             return cached[1], cached[2], ps, cached[3]
         rows = []
+        # one workgroup per chunk: keep >= ~2000 workgroups in flight even when the group is small (the 20 M parameters
+        # left after out_layer.fc1.weight is updated inside its GEMM would otherwise run on 90 workgroups)
+        total = sum(p.numel() for p in ps)
+        chunk_elems = min(CHUNK_ELEMS, max(1 << 13, (-(-total // 2048) + 1023) // 1024 * 1024))
         for p in ps:
             if p.grad.is_sparse:
                 raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
@@ -83,7 +87,7 @@ class AdamW(Optimizer):
             st = self._ensure_state(p)
             n, off = p.numel(), 0
             while off < n:
-                c = min(CHUNK_ELEMS, n - off)
+                c = min(chunk_elems, n - off)
                 rows.append((p.data_ptr() + 4 * off, p.grad.data_ptr() + 4 * off, st["exp_avg"].data_ptr() + 4 * off,
                              st["exp_avg_sq"].data_ptr() + 4 * off, c, group["weight_decay"]))
                 off += c
