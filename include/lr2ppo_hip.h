@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 3
+#define LR2_ABI_VERSION 4
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -180,6 +180,11 @@ int lr2_ppo_loss(const void* scores, const void* old_scores, const void* rewards
 
 /* SmoothL1(beta) mean loss + gradient (dpred may be NULL).  replaces: nn.SmoothL1Loss(beta=0.3) (finetune/ppo.py:236). */
 int lr2_smooth_l1(const void* pred, const void* target, int n, float beta, void* loss, void* dpred, void* stream);
+
+/* Pairwise hinge of the stage-2 reward training: scores = [chosen(bs) ; reject(bs)];
+ * loss_acc[0] = mean relu(margin - (chosen - reject)), loss_acc[1] = mean (chosen > reject); dscores (may be NULL) = d loss / d scores.
+ * replaces: finetune/reward_pair_dataloader.py:356-359 (+ the autograd of that expression). */
+int lr2_pair_hinge(const void* scores, int bs, float margin, void* loss_acc, void* dscores, void* stream);
 
 /* One chunk of the multi-tensor AdamW: `count` fp32 elements starting at p/g/m/v. */
 typedef struct lr2_adamw_chunk {

@@ -101,6 +101,7 @@ SIGNATURES = {
     "lr2_period_rows_grad": [_P, _P, _I, _I, _I, _P],
     "lr2_ppo_loss": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P],
     "lr2_smooth_l1": [_P, _P, _I, _F, _P, _P, _P],
+    "lr2_pair_hinge": [_P, _I, _F, _P, _P, _P],
     "lr2_adamw_multi": [_P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _P],
     "lr2_text_embed": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "lr2_patchify": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -135,7 +136,7 @@ def lib() -> C.CDLL:
                 raise RuntimeError(f"lr2ppo_amd: {LIB_PATH} does not export {name}") from e
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        if handle.lr2_abi_version() != 3:
+        if handle.lr2_abi_version() != 4:
             raise RuntimeError("lr2ppo_amd: ABI version mismatch between python package and native library")
         _lib = handle
         return _lib

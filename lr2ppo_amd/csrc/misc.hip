@@ -294,6 +294,32 @@ __global__ __launch_bounds__(1024) void smooth_l1_kernel(const float* __restrict
   if (threadIdx.x == 0) loss[0] = s / (float)n;
 }
 
+// Pairwise hinge of the stage-2 reward training (finetune/reward_pair_dataloader.py:356-359):
+// loss = mean relu(margin - (chosen - reject)), acc = mean (chosen > reject); scores = [chosen(bs) ; reject(bs)].
+__global__ __launch_bounds__(1024) void pair_hinge_kernel(const float* __restrict__ scores, int bs, float margin,
+                                                          float* __restrict__ out2, float* __restrict__ dscores) {
+  __shared__ float red[16];
+  float loss = 0.f, acc = 0.f;
+  for (int i = threadIdx.x; i < bs; i += blockDim.x) {
+    const float c = scores[i], r = scores[bs + i];
+    const float h = margin - (c - r);
+    loss += h > 0.f ? h : 0.f;
+    acc += c > r ? 1.f : 0.f;
+    if (dscores) {
+      const float g = h > 0.f ? 1.0f / (float)bs : 0.f;
+      dscores[i] = -g;
+      dscores[bs + i] = g;
+    }
+  }
+  const float ls = block_sum_1024(loss, red);
+  __syncthreads();
+  const float as = block_sum_1024(acc, red);
+  if (threadIdx.x == 0) {
+    out2[0] = ls / (float)bs;
+    out2[1] = as / (float)bs;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // AdamW, correct_bias=False, decay applied after the Adam update with the same lr
 // (tencentpretrain/utils/optimizers.py:381-400).  28 B of HBM traffic per parameter.
@@ -508,6 +534,13 @@ extern "C" int lr2_smooth_l1(const void* pred, const void* target, int n, float 
   if (!pred || !target || !loss || n <= 0 || beta <= 0.f) return LR2_ERR_ARG;
   LR2_LAUNCH(smooth_l1_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)pred,
                      (const float*)target, n, beta, (float*)loss, (float*)dpred);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_pair_hinge(const void* scores, int bs, float margin, void* loss_acc, void* dscores, void* stream) {
+  if (!scores || !loss_acc || bs <= 0) return LR2_ERR_ARG;
+  LR2_LAUNCH(pair_hinge_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)scores, bs, margin,
+             (float*)loss_acc, (float*)dscores);
   CHECK_LAUNCH();
 }
 

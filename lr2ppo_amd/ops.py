@@ -387,6 +387,16 @@ def smooth_l1(pred, target, loss, dpred=None, *, n, beta=0.3):
     return loss
 
 
+def pair_hinge(scores, loss_acc, dscores=None, *, bs, margin=1.0):
+    """scores: [2*bs] = chosen then reject; loss_acc: [2] (loss, accuracy); dscores: [2*bs] or None."""
+    _chk_f32(scores, loss_acc, dscores)
+    if scores.numel() != 2 * bs or loss_acc.numel() < 2 or (dscores is not None and dscores.numel() != 2 * bs):
+        raise ValueError("pair_hinge: scores/dscores must hold 2*bs elements, loss_acc 2")
+    _nat.check(_nat.lib().lr2_pair_hinge(scores.data_ptr(), bs, margin, loss_acc.data_ptr(), _ptr(dscores), _stream()),
+               "lr2_pair_hinge")
+    return loss_acc
+
+
 def adamw_multi(table_dev: torch.Tensor, n_chunks: int, lr: float, beta1: float, beta2: float, eps: float,
                 n_params: int = 0):
     with _Timed(f"adamw_{n_params}", 0.0, 28.0 * n_params):

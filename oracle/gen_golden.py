@@ -25,6 +25,18 @@ os.chdir(REF)
 sys.path.insert(0, REF)
 sys.path.insert(0, os.path.join(REF, "finetune"))
 sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+if "torchvision" not in sys.modules:
+    try:
+        import torchvision  # noqa: F401
+    except ImportError:
+        # finetune/pointwise.py and reward_pair_dataloader.py import torchvision at module level for an image-file path
+        # their MovieNet readers never take (features come from clean_feat.h5); absent in this image -> empty stand-ins
+        tv, tvt, tvio, tvimg = (types.ModuleType(n) for n in ("torchvision", "torchvision.transforms", "torchvision.io",
+                                                             "torchvision.io.image"))
+        tvio.read_image, tvimg.ImageReadMode = None, None
+        tv.transforms, tv.io, tvio.image = tvt, tvio, tvimg
+        sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.io": tvio,
+                            "torchvision.io.image": tvimg})
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -317,6 +329,86 @@ def gen_train_step():
     _save("train_step.npz", **arrays)
 
 
+def _sampled(named, names, seed):
+    gi = torch.Generator().manual_seed(seed)
+    return {n: torch.randint(0, named[n].numel(), (64,), generator=gi) for n in names}
+
+
+def gen_stage1():
+    """Three stage-1 train_model calls (finetune/pointwise.py:300-313) on the imported reference, dropout off:
+    losses, the schedule's lr before each step and sampled weights after each step."""
+    import pointwise
+    bs, tags, steps = 2, 3, 3
+    args = _ns(**HEAD_ARGS, is_master=False, optimizer="adamw", scheduler="linear", learning_rate=1e-3, train_steps=21,
+               warmup=0.1, device=torch.device("cpu"))
+    model = pointwise.Classifier(args, None)
+    assert _spec_of(model) == [[n, list(sh)] for n, sh in O.head_param_spec("actor")]
+    _load(model, O.seeded_params(O.head_param_spec("actor"), seed=17))
+    opt, sch = pointwise.build_optimizer(args, model)
+    model.eval()
+    named = dict(model.named_parameters())
+    names = ["text_proj.fc1.weight", "img_proj.fc2.bias", "xit.0.0.0.fn.1.keys.weight", "xit.1.0.weight",
+             "out_layer.fc1.weight", "out_layer.fc1.bias", "out_layer.fc2.weight", "head.weight", "head.bias"]
+    idx = _sampled(named, names, 177)
+    arrays = {"bs": np.array(bs), "tags": np.array(tags), "steps": np.array(steps)}
+    for n in names:
+        arrays["idx." + n] = idx[n]
+    for step in range(steps):
+        text, img, tgts = O.seeded_head_inputs(2000 + step, bs, tags)
+        arrays[f"lr_{step}"] = np.array(opt.param_groups[0]["lr"])
+        loss = pointwise.train_model(args, model, opt, sch, text, img, tgts)
+        arrays[f"loss_{step}"] = loss.detach().clone()
+        for n in names:
+            arrays[f"w{step}." + n] = named[n].detach().flatten()[idx[n]].clone()
+    with torch.no_grad():
+        text, img, _ = O.seeded_head_inputs(2100, bs, tags)
+        arrays["eval_logits"] = model(text, img, None).clone()
+    _save("stage1_step.npz", **arrays)
+
+
+def gen_stage2():
+    """Three stage-2 train_model calls (finetune/reward_pair_dataloader.py:347-365), dropout off: loss, acc, lr and
+    sampled weights per step, plus the index pairs get_index produces for fixed target lists."""
+    import random
+    import reward_pair_dataloader as rp
+    bs, tags, steps = 2, 2, 3
+    args = _ns(**HEAD_ARGS, is_master=False, optimizer="adamw", scheduler="linear", learning_rate=1e-3, train_steps=21,
+               warmup=0.1, device=torch.device("cpu"))
+    model = rp.Classifier(args, None)
+    assert _spec_of(model) == [[n, list(sh)] for n, sh in O.head_param_spec("reward")]
+    _load(model, O.seeded_params(O.head_param_spec("reward"), seed=19))
+    opt, sch = rp.build_optimizer(args, model)
+    model.eval()
+    named = dict(model.named_parameters())
+    names = ["text_proj.fc2.weight", "img_proj.fc1.weight", "pos_emb.weight", "xit.0.0.1.fn.1.0.weight",
+             "xitt.0.0.0.fn.1.values.weight", "xitt.1.0.bias", "out_layer.fc1.weight", "out_layer.fc2.bias", "head.weight"]
+    idx = _sampled(named, names, 199)
+    arrays = {"bs": np.array(bs), "tags": np.array(tags), "steps": np.array(steps)}
+    for n in names:
+        arrays["idx." + n] = idx[n]
+    orders = [([0, 1, 0, 1], [0, 1, 1, 0]), ([1, 0, 0, 1], [1, 0, 1, 0])]       # the two training layouts (:126-139)
+    for step in range(steps):
+        text, img, tgts = O.seeded_head_inputs(3000 + step, bs, tags)
+        chosen = torch.tensor([orders[(step + i) % 2][0] for i in range(bs)])
+        reject = torch.tensor([orders[(step + i) % 2][1] for i in range(bs)])
+        arrays[f"chosen_{step}"], arrays[f"reject_{step}"] = chosen, reject
+        arrays[f"lr_{step}"] = np.array(opt.param_groups[0]["lr"])
+        loss, acc = rp.train_model(args, model, opt, sch, text, img, tgts.long(), chosen, reject)
+        arrays[f"loss_{step}"], arrays[f"acc_{step}"] = loss.detach().clone(), acc.detach().clone()
+        for n in names:
+            arrays[f"w{step}." + n] = named[n].detach().flatten()[idx[n]].clone()
+    # get_index on fixed inputs: python's `random` is seeded, so the shuffles are reproducible here; the fixture stores
+    # the shuffled order next to the result so that the restatement is checked without replaying the RNG
+    cases = []
+    for seed, targets in ((1, [2, 0, 1]), (2, [0, 0, 2]), (3, [1, 2, 2]), (4, [2, 1, 0]), (5, [0, 1, 1])):
+        random.seed(seed)
+        ch, rj = rp.get_index([{"target": t} for t in targets])
+        cases.append({"targets": targets, "order": ch[:2], "chosen": ch, "reject": rj})
+    with open(os.path.join(GOLD, "stage2_get_index.json"), "w") as f:
+        json.dump(cases, f)
+    _save("stage2_step.npz", **arrays)
+
+
 def gen_encoder_small():
     from tencentpretrain.encoders import str2encoder
     arrays = {}
@@ -445,7 +537,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -476,3 +476,59 @@ def seeded_head_inputs(seed: int, bs: int, tags: int, n_img: int = 16, n_cls: in
 def pooling_first(hidden: torch.Tensor, seg: torch.Tensor) -> torch.Tensor:
     """utils/misc.py:23-35 default branch: multiply by seg then take token 0."""
     return (hidden * seg.unsqueeze(-1).type_as(hidden))[:, 0, :]
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY 8(f) rows 1-2: the stage-1 (pointwise) and stage-2 (pairwise reward) training steps
+# ---------------------------------------------------------------------------------------------
+def pair_hinge(chosen: torch.Tensor, reject: torch.Tensor, margin: float = 1.0):
+    """finetune/reward_pair_dataloader.py:356-359: loss = relu(m_R - (chosen - reject)).mean(), acc = (chosen > reject).mean()."""
+    return torch.relu(margin - (chosen - reject)).mean(), (chosen > reject).float().mean()
+
+
+def pair_index(tag_targets, order):
+    """get_index (reward_pair_dataloader.py:77-84) for an already shuffled two-element `order`:
+    -> (chosen_index, reject_index), each 4 long; the first two entries are the shown order, the last two the
+    candidate next order (kept when the first tag's target >= the second's, swapped otherwise)."""
+    a, b = order
+    keep, swap = [a, b, a, b], [a, b, b, a]
+    return (keep, swap) if tag_targets[a] >= tag_targets[b] else (swap, keep)
+
+
+def sgd_free_train_steps(P: Params, loss_fn, batches, base_lr: float, warmup_steps: float, train_steps: float):
+    """The reference's per-batch recipe shared by pointwise.py:300-313 and reward_pair_dataloader.py:347-365:
+    zero_grad -> loss -> backward -> AdamW.step (lr of the CURRENT schedule position, decay groups by the
+    bias|gamma|beta substring rule) -> scheduler.step.  P is updated in place; returns the per-step outputs of loss_fn.
+    (LambdaLR applies lambda(0) at construction, so the first step runs at lr = base_lr * lambda(0) = 0.)"""
+    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in P.items()}
+    outs = []
+    for step, batch in enumerate(batches):
+        Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        out = loss_fn(Pg, batch)
+        loss = out[0] if isinstance(out, tuple) else out
+        loss.backward()
+        lr = base_lr * linear_schedule_lambda(step, warmup_steps, train_steps)
+        for k in P:
+            m, v = state[k]
+            p_new, m_new, v_new = adamw_step(P[k], Pg[k].grad, m, v, lr, 0.0 if no_decay(k) else 0.01)
+            P[k], state[k] = p_new, (m_new, v_new)
+        outs.append(tuple(o.detach() for o in out) if isinstance(out, tuple) else out.detach())
+    return outs
+
+
+def stage1_loss(P: Params, batch, drop=None):
+    """pointwise.py:300-303 + Classifier.forward mode 'reg' (:203-232) == Actor.forward with targets."""
+    text, img, tgts = batch
+    loss, logits = actor_forward(P, text, img, tgts, drop=drop)
+    return loss, logits
+
+
+def stage2_loss(P: Params, batch, drop=None):
+    """reward_pair_dataloader.py:347-359: two Classifier forwards (chosen / reject orderings) + hinge.
+    Evaluated as ONE forward over the batch [chosen ; reject] (items are independent), which is also how the HIP path
+    runs it; `drop` therefore indexes its masks over the concatenated batch."""
+    text, img, chosen, reject = batch
+    bs = text.shape[0]
+    scores = critic_forward(P, torch.cat([text, text]), torch.cat([img, img]), torch.cat([chosen, reject]), n_pos=4, drop=drop)
+    loss, acc = pair_hinge(scores[:bs], scores[bs:])
+    return loss, acc, scores

@@ -118,7 +118,7 @@ def test_header_symbols_are_declared_bound_and_exported(native):
     exported = set(re.findall(r" T (lr2_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
     lib = native.lib()
-    assert lib.lr2_abi_version() == int(re.search(r"#define LR2_ABI_VERSION (\d+)", hdr).group(1)) == 3
+    assert lib.lr2_abi_version() == int(re.search(r"#define LR2_ABI_VERSION (\d+)", hdr).group(1)) == 4
 
 
 def test_ctypes_structs_have_the_layout_the_c_compiler_gives_the_header(native, tmp_path):
@@ -175,3 +175,50 @@ def test_synthetic_dataset_shapes_and_determinism():
     assert t.shape == (2, 196, 768) and i.shape == (16, 768) and y.shape == (2,) and int(y.max()) <= 2
     t2, _, _ = SyntheticMovieNet(4, 2, 16, seed=7)[1]
     assert torch.equal(t, t2)
+
+
+def test_stage1_stage2_modules_mirror_the_reference_surface():
+    """finetune/pointwise.py and finetune/reward_pair_dataloader.py: same public names; host-side helpers checked
+    against fixtures generated from the imported reference (get_index) or worked out from pointwise.py:96-119."""
+    import random
+    from lr2ppo_amd.finetune import pointwise as pw, reward_pair_dataloader as rp
+    for n in ("get_scores", "log_sig", "get_def_cls", "MovieNet", "Mlp", "Classifier", "load_or_initialize_parameters",
+              "build_optimizer", "train_model", "evaluate", "get_dataloader", "main"):
+        assert hasattr(pw, n), n
+    for n in ("log_sig", "get_def_cls", "get_index", "MovieNet", "Mlp", "Classifier", "load_or_initialize_parameters",
+              "build_optimizer", "train_model", "evaluate", "get_dataloader", "main"):
+        assert hasattr(rp, n), n
+    with open(os.path.join(GOLD, "stage2_get_index.json")) as f:
+        cases = json.load(f)
+    for seed, c in zip((1, 2, 3, 4, 5), cases):
+        random.seed(seed)
+        ch, rj = rp.get_index([{"target": t} for t in c["targets"]])
+        assert ch == c["chosen"] and rj == c["reject"], c
+    # training reader of stage 1: cut to max_tags, else pad by cycling through the non-zero-label tags (or all tags)
+    assert pw.train_tag_index([0, 1, 0], 7) == [0, 1, 2, 1, 1, 1, 1]
+    assert pw.train_tag_index([0, 2, 1, 0], 7) == [0, 1, 2, 3, 1, 2, 1]     # add_list = [1, 2]; i % 2 for i = 4, 5, 6
+    assert pw.train_tag_index([0, 0], 5) == [0, 1, 0, 1, 0]
+    assert pw.train_tag_index([1, 2, 0, 1], 3) == [0, 1, 2]
+    # synthetic pairs follow the reader's layouts
+    ds = rp.SyntheticPairs(6, True)
+    for i in range(6):
+        t, im, lab, ch, rj = ds[i]
+        assert t.shape == (2, 196, 768) and (ch.tolist(), rj.tolist()) in [tuple(map(list, x)) for x in rp.TRAIN_LAYOUTS]
+    t, im, lab, ch, rj = rp.SyntheticPairs(3, False)[1]
+    assert t.shape == (3, 196, 768) and ch[:2].tolist() == rj[:2].tolist() and ch[2:].tolist() == rj[2:].tolist()[::-1]
+    assert lab[ch[2]] >= lab[ch[3]]
+
+
+def test_stage_launcher_arguments_parse():
+    """Argument lists of pointwise.sh and reward_pair_dataloader.sh (paths shortened)."""
+    from lr2ppo_amd.finetune import pointwise as pw, reward_pair_dataloader as rp
+    common = ["--train_path", "t.json", "--dev_path", "d.json", "--test_path", "x.json", "--epochs_num", "10",
+              "--learning_rate", "1e-5", "--mask", "fully_visible", "--output_model_path", "o.bin", "--log_path", "l.txt",
+              "--exp_name", "e", "--seq_length", "196", "--visual_feat_dim", "768", "--max_imgs", "16", "--max_tags", "20",
+              "--pretrained_model_path", "r.bin", "--vocab_path", "v.txt", "--merges_path", "m.txt", "--tokenizer", "bpe",
+              "--config_path", "c.json", "--encoder", "transformer", "--vit_pretrained_model_path", "vit.bin",
+              "--vit_tokenizer", "virtual", "--vit_config_path", "vc.json", "--vit_encoder", "transformer"]
+    a = pw.build_parser().parse_args(common + ["--batch_size", "2", "--report_steps", "150", "--mode", "reg"])
+    assert a.batch_size == 2 and a.max_tags == 20 and a.mode == "reg"
+    b = rp.build_parser().parse_args(common + ["--batch_size", "64", "--report_steps", "100", "--mode", "cls"])
+    assert b.batch_size == 64 and b.mode == "cls"

@@ -175,3 +175,55 @@ def test_head_forward_full_size():
         pr = O.seeded_params(O.head_param_spec("reward"), seed=9)
         r = O.reward_forward(pr, text, img, nxt)
         assert torch.allclose(r, g["reward"], atol=2e-5, rtol=1e-4)
+
+
+def _check_train_steps(gold_name, kind, seed, make_batch, loss_fn, n_out):
+    g = load_golden(gold_name)
+    bs, tags, steps = int(g["bs"]), int(g["tags"]), int(g["steps"])
+    P = O.seeded_params(O.head_param_spec(kind), seed=seed)
+    batches = [make_batch(g, step, bs, tags) for step in range(steps)]
+    for step in range(steps):
+        assert abs(float(g[f"lr_{step}"]) - 1e-3 * O.linear_schedule_lambda(step, 2.1, 21)) < 1e-12
+    outs = O.sgd_free_train_steps(P, loss_fn, batches, 1e-3, 2.1, 21)
+    for step in range(steps):
+        ref = float(g[f"loss_{step}"])
+        assert abs(float(outs[step][0]) - ref) < 2e-5 * max(1.0, abs(ref)), step
+        if n_out > 1:
+            assert float(outs[step][1]) == float(g[f"acc_{step}"]), step
+    last = steps - 1
+    for key in [k for k in g if k.startswith(f"w{last}.")]:
+        n = key[len(f"w{last}."):]
+        got = P[n].flatten()[g["idx." + n]]
+        assert (got - g[key]).abs().max() < 2e-6, n
+    return g, P
+
+
+@pytest.mark.slow
+def test_stage1_pointwise_train_steps_match_reference():
+    """three pointwise.train_model steps (Actor architecture + SmoothL1 + per-batch scheduler)."""
+    g, P = _check_train_steps("stage1_step.npz", "actor", 17,
+                              lambda g, step, bs, tags: O.seeded_head_inputs(2000 + step, bs, tags), O.stage1_loss, 1)
+    text, img, _ = O.seeded_head_inputs(2100, int(g["bs"]), int(g["tags"]))
+    with torch.no_grad():
+        logits = O.actor_forward(P, text, img, None)
+    ref = g["eval_logits"].view(-1)
+    assert (logits.view(-1) - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.slow
+def test_stage2_pair_reward_train_steps_match_reference():
+    """three reward_pair_dataloader.train_model steps (two forwards + hinge + AdamW)."""
+    def batch(g, step, bs, tags):
+        text, img, _ = O.seeded_head_inputs(3000 + step, bs, tags)
+        return text, img, g[f"chosen_{step}"], g[f"reject_{step}"]
+    _check_train_steps("stage2_step.npz", "reward", 19, batch, O.stage2_loss, 2)
+
+
+def test_stage2_get_index_restatement():
+    import json
+    with open(os.path.join(GOLD, "stage2_get_index.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 5
+    for c in cases:
+        ch, rj = O.pair_index(c["targets"], c["order"])
+        assert ch == c["chosen"] and rj == c["reject"], c

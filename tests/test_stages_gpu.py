@@ -1,0 +1,131 @@
+"""SURVEY 8(f) rows 1-2 on the GPU: the stage-1 (pointwise) and stage-2 (pairwise reward) training steps of the HIP
+path against fixtures frozen from the imported reference (tests/golden/stage{1,2}_step.npz) and against the oracle
+with the dropout mask stream pinned."""
+import argparse
+
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import lr2ppo_oracle as O
+
+pytestmark = pytest.mark.gpu
+ARGS = dict(mode="reg", labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768)
+
+
+def _args(dev, **kw):
+    return argparse.Namespace(**ARGS, is_master=False, optimizer="adamw", scheduler="linear", learning_rate=1e-3,
+                              train_steps=21, warmup=0.1, device=dev, **kw)
+
+
+def _check_weights(g, named, step, tag):
+    for key in [k for k in g if k.startswith(f"w{step}.")]:
+        n = key[len(f"w{step}."):]
+        got = named[n].detach().flatten()[g["idx." + n].to(named[n].device)].cpu()
+        assert (got - g[key]).abs().max() < 2e-6, f"{tag}: {n} after step {step}"
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_stage1_train_model_matches_reference_golden(dev, fuse):
+    from lr2ppo_amd.finetune import pointwise as pw
+    g = load_golden("stage1_step.npz")
+    bs, tags, steps = int(g["bs"]), int(g["tags"]), int(g["steps"])
+    args = _args(dev, fuse_fc1_update=fuse)
+    model = pw.Classifier(args, None)
+    model.load_state_dict(O.seeded_params(O.head_param_spec("actor"), seed=17), strict=True)
+    model = model.to(dev).eval()                                   # dropout off, as in the golden run
+    opt, sch = pw.build_optimizer(args, model)
+    named = dict(model.named_parameters())
+    for step in range(steps):
+        text, img, tgts = O.seeded_head_inputs(2000 + step, bs, tags)
+        assert abs(opt.param_groups[0]["lr"] - float(g[f"lr_{step}"])) < 1e-12
+        loss = pw.train_model(args, model, opt, sch, text.to(dev), img.to(dev), tgts.to(dev))
+        ref = float(g[f"loss_{step}"])       # the third step's loss is O(100): lr 4.8e-4 on 519 M parameters
+        assert loss.dim() == 0 and abs(float(loss) - ref) < 2e-5 * max(1.0, abs(ref)), step
+        _check_weights(g, named, step, "stage1")
+    text, img, _ = O.seeded_head_inputs(2100, bs, tags)
+    with torch.no_grad():
+        logits = model(text.to(dev), img.to(dev), None).cpu()
+    ref = g["eval_logits"].view(-1)
+    assert (logits.view(-1) - ref).abs().max() < 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_stage2_train_model_matches_reference_golden(dev, fuse):
+    from lr2ppo_amd.finetune import reward_pair_dataloader as rp
+    g = load_golden("stage2_step.npz")
+    bs, tags, steps = int(g["bs"]), int(g["tags"]), int(g["steps"])
+    args = _args(dev, fuse_fc1_update=fuse)
+    args.mode = "cls"                                              # what reward_pair_dataloader.sh passes; never read
+    model = rp.Classifier(args, None)
+    model.load_state_dict(O.seeded_params(O.head_param_spec("reward"), seed=19), strict=True)
+    model = model.to(dev).eval()
+    opt, sch = rp.build_optimizer(args, model)
+    named = dict(model.named_parameters())
+    for step in range(steps):
+        text, img, tgts = O.seeded_head_inputs(3000 + step, bs, tags)
+        chosen, reject = g[f"chosen_{step}"].to(dev), g[f"reject_{step}"].to(dev)
+        assert abs(opt.param_groups[0]["lr"] - float(g[f"lr_{step}"])) < 1e-12
+        loss, acc = rp.train_model(args, model, opt, sch, text.to(dev), img.to(dev), tgts.to(dev), chosen, reject)
+        ref = float(g[f"loss_{step}"])
+        assert abs(float(loss) - ref) < 2e-5 * max(1.0, abs(ref)), step
+        assert float(acc) == float(g[f"acc_{step}"]), step
+        _check_weights(g, named, step, "stage2")
+    # the two-forward API of the reference gives the same scores as the fused [chosen ; reject] batch
+    text, img, tgts = O.seeded_head_inputs(3100, bs, tags)
+    chosen, reject = g["chosen_0"].to(dev), g["reject_0"].to(dev)
+    with torch.no_grad():
+        c = model(text.to(dev), img.to(dev), tgts.to(dev), chosen)
+        r = model(text.to(dev), img.to(dev), tgts.to(dev), reject)
+        both = model.engine_forward(torch.cat([text, text]).to(dev), torch.cat([img, img]).to(dev),
+                                    torch.cat([chosen, reject]), save=False)
+    assert torch.allclose(torch.cat([c, r]), both.view(-1), atol=2e-5)
+
+
+def test_stage2_train_step_with_dropout_matches_oracle(dev):
+    """Train mode (dropout 0.1 at every XiT site, trunk and tail) with the mask stream pinned: loss, accuracy and
+    parameter gradients of one step against the oracle's autograd over the same [chosen ; reject] batch."""
+    from lr2ppo_amd import runtime
+    from lr2ppo_amd.finetune import reward_pair_dataloader as rp
+    bs, tags = 2, 2
+    text, img, _ = O.seeded_head_inputs(77, bs, tags)
+    chosen = torch.tensor([[0, 1, 0, 1], [1, 0, 0, 1]])
+    reject = torch.tensor([[0, 1, 1, 0], [1, 0, 1, 0]])
+    P = O.seeded_params(O.head_param_spec("reward"), seed=23)
+    with torch.no_grad():                       # spread the scores so that some hinges are active and some are not
+        P["head.weight"] *= 40.0
+    args = _args(dev, fuse_fc1_update=False)
+    model = rp.Classifier(args, None)
+    model.load_state_dict(P, strict=True)
+    model = model.to(dev).train()
+    opt, sch = rp.build_optimizer(args, model)  # lr 0 at the first step: weights stay, gradients are what we read
+    runtime.set_dropout_seed(4242, calls=3)
+    seed = runtime.peek_drop_seed()
+    loss, acc = rp.train_model(args, model, opt, sch, text.to(dev), img.to(dev), torch.zeros(bs, tags), chosen.to(dev),
+                               reject.to(dev))
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref_loss, ref_acc, _ = O.stage2_loss(Pg, (text, img, chosen, reject), drop={"p": 0.1, "seed": seed, "site_base": 0})
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss.detach())) < 1e-3 * max(1.0, abs(float(ref_loss.detach())))
+    assert float(acc) == float(ref_acc)
+    G = model.grad_buffers()
+    for n in ["text_proj.fc1.weight", "img_proj.fc2.bias", "xit.0.0.0.fn.1.queries.weight", "xit.1.0.weight",
+              "out_layer.fc1.weight", "out_layer.fc2.weight", "pos_emb.weight", "xitt.0.0.0.fn.1.keys.weight",
+              "xitt.0.0.1.fn.1.3.weight", "xitt.1.0.bias", "head.weight", "head.bias"]:
+        ref_g = Pg[n].grad
+        err = (G[n].cpu().view_as(ref_g) - ref_g).abs().max().item()
+        assert err < 1e-6 + 2e-3 * ref_g.abs().max().item(), f"grad {n}: {err} vs scale {ref_g.abs().max().item()}"
+
+
+def test_pair_hinge_kernel(dev):
+    from lr2ppo_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for bs in (1, 7, 64, 1500):
+        s = (torch.randn(2 * bs, generator=g) * 2).to(dev)
+        out, ds = torch.empty(2, device=dev), torch.empty(2 * bs, device=dev)
+        ops.pair_hinge(s, out, ds, bs=bs, margin=1.0)
+        sc = s.cpu().double().requires_grad_(True)
+        loss, acc = O.pair_hinge(sc[:bs], sc[bs:])
+        loss.backward()
+        assert abs(float(out[0]) - float(loss)) < 1e-5 and abs(float(out[1]) - float(acc)) < 1e-6
+        assert torch.allclose(ds.cpu().double(), sc.grad, atol=1e-7)

@@ -36,10 +36,15 @@ def main():
         A = torch.randn((K, M) if ta else (M, K), device=dev, generator=g)
         B = torch.randn((K, N) if tb else (N, K), device=dev, generator=g)
         out = torch.empty(M, N, device=dev)
-        if a.planes and not (M == 64 and K > 100000) and not (N > 100000 and form == "NN"):
-            Ap, Bp = ops.Planes.empty(*A.shape, dev), ops.Planes.empty(*B.shape, dev)
-            ops.split_planes(A, Ap), ops.split_planes(B, Bp)
-            A, B = Ap, Bp
+        if a.planes:
+            big_b = (M == 64 and K > 100000) or (N > 100000 and form == "NN")   # out_layer.fc1 weight: stays fp32
+            Ap = ops.Planes.empty(*A.shape, dev)
+            ops.split_planes(A, Ap)
+            A = Ap
+            if not big_b:
+                Bp = ops.Planes.empty(*B.shape, dev)
+                ops.split_planes(B, Bp)
+                B = Bp
         bm, sp = ops.choose_tiling(M, N, K, ta, tb)
         bm = a.bm or bm
         sp = a.splits or sp
