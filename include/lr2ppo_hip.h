@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 4
+#define LR2_ABI_VERSION 5
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -147,10 +147,14 @@ int lr2_xattn_bwd(const void* Q, const void* K, const void* V, const void* dO, v
                   float post_scale, void* stream);
 
 /* TencentPretrain self-attention core, per (sequence, head): S = Q K^T * scale + (seg[key]>0 ? 0 : -10000),
- * P = softmax(S), O = P V.  Q,K,V,O [batch*L, heads*hd]; seg int64 [batch*L]; L <= 256, hd == 64.
+ * P = softmax(S), O = P V -- both products on the matrix cores (split-bf16 x3), softmax in fp32.
+ * q_hi / k_hi / v_hi: bf16 hi planes of Q, K, V, element (row, h*64 + d) at ptr[row*ld + h*64 + d], the lo plane lo_off
+ * ELEMENTS behind each (one fused QKV matrix [batch*L, 3*heads*64] with ld = 3*heads*64 is the intended producer);
+ * seg int64 [batch*L]; o fp32 [batch*L, ld_o] and/or o_hi planes (lo plane o_lo_off elements behind); L <= 256, hd == 64.
  * replaces: tencentpretrain/layers/multi_headed_attn.py:61-74 and the mask of encoders/transformer_encoder.py:62-68. */
-int lr2_self_attn_fwd(const void* Q, const void* K, const void* V, const int64_t* seg, void* O, int batch, int heads,
-                      int L, int head_dim, float scale, void* stream);
+int lr2_self_attn_fwd(const void* q_hi, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld, const int64_t* seg,
+                      void* o, void* o_hi, uint64_t o_lo_off, int ld_o, int batch, int heads, int L, int head_dim,
+                      float scale, void* stream);
 
 /* y[r] = dot(x[row(r)], w) + b for r < rows, row(r) = r*row_step + row_off.
  * replaces: self.head = nn.Linear(768, 1) and the last-position select (finetune/ppo.py:228-232,293-295). */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "liblr2ppo_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "misc.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
 
 _lock = threading.Lock()
@@ -94,7 +94,7 @@ SIGNATURES = {
     "lr2_colsum": [_P, _I, _U64, _I, _I, _I, _P, _I, _P, _P],
     "lr2_xattn_fwd": [_P, _P, _P, _P, _I, _U64, _I, _I, _I, _I, _I, _F, _P],
     "lr2_xattn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _U64, _U64, _I, _I, _I, _I, _I, _F, _P],
-    "lr2_self_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "lr2_self_attn_fwd": [_P, _P, _P, _U64, _I, _P, _P, _P, _U64, _I, _I, _I, _I, _I, _F, _P],
     "lr2_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lr2_head_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lr2_add_period_rows": [_P, _P, _P, _I, _I, _I, _P],
@@ -136,7 +136,7 @@ def lib() -> C.CDLL:
                 raise RuntimeError(f"lr2ppo_amd: {LIB_PATH} does not export {name}") from e
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        if handle.lr2_abi_version() != 4:
+        if handle.lr2_abi_version() != 5:
             raise RuntimeError("lr2ppo_amd: ABI version mismatch between python package and native library")
         _lib = handle
         return _lib

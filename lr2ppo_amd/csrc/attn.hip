@@ -206,66 +206,6 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
   }
 }
 
-// ----------------------------------------------------------------------------------------------
-// Encoder self-attention, head_dim 64.  One workgroup per (sequence, head); K and V of the head in LDS
-// (2 x L x 64 fp32 <= 128 KiB of the CU's 160 KiB); one lane owns one query row and runs an online softmax.
-constexpr int SA_HD = 64;
-__global__ __launch_bounds__(256) void self_attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                            const float* __restrict__ V, const int64_t* __restrict__ seg,
-                                                            float* __restrict__ O, int heads, int L, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sK = smem;                 // [L][64]
-  float* sV = smem + (size_t)L * SA_HD;
-  float* sM = sV + (size_t)L * SA_HD;  // [L] additive mask
-  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-  const int E = heads * SA_HD;
-  const int t = threadIdx.x;
-  for (int idx = t; idx < L * (SA_HD / 4); idx += 256) {
-    const int j = idx / (SA_HD / 4), d4 = idx % (SA_HD / 4);
-    const size_t o = ((size_t)b * L + j) * E + (size_t)h * SA_HD + d4 * 4;
-    *reinterpret_cast<float4*>(sK + j * SA_HD + d4 * 4) = *reinterpret_cast<const float4*>(K + o);
-    *reinterpret_cast<float4*>(sV + j * SA_HD + d4 * 4) = *reinterpret_cast<const float4*>(V + o);
-  }
-  for (int j = t; j < L; j += 256) sM[j] = (seg[(size_t)b * L + j] > 0) ? 0.f : -10000.0f;
-  __syncthreads();
-  if (t >= L) return;
-  const size_t ro = ((size_t)b * L + t) * E + (size_t)h * SA_HD;
-  float4 q[SA_HD / 4], acc[SA_HD / 4];
-#pragma unroll
-  for (int i = 0; i < SA_HD / 4; ++i) {
-    q[i] = *reinterpret_cast<const float4*>(Q + ro + i * 4);
-    acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  float m = -INFINITY, l = 0.f;
-  for (int j = 0; j < L; ++j) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < SA_HD / 4; ++i) {
-      const float4 k4 = *reinterpret_cast<const float4*>(sK + j * SA_HD + i * 4);
-      s += q[i].x * k4.x + q[i].y * k4.y + q[i].z * k4.z + q[i].w * k4.w;
-    }
-    s = s * scale + sM[j];
-    const float mn = fmaxf(m, s);
-    const float alpha = expf(m - mn), p = expf(s - mn);
-    l = l * alpha + p;
-    m = mn;
-#pragma unroll
-    for (int i = 0; i < SA_HD / 4; ++i) {
-      const float4 v4 = *reinterpret_cast<const float4*>(sV + j * SA_HD + i * 4);
-      acc[i].x = acc[i].x * alpha + p * v4.x;
-      acc[i].y = acc[i].y * alpha + p * v4.y;
-      acc[i].z = acc[i].z * alpha + p * v4.z;
-      acc[i].w = acc[i].w * alpha + p * v4.w;
-    }
-  }
-  const float inv = 1.0f / l;
-#pragma unroll
-  for (int i = 0; i < SA_HD / 4; ++i) {
-    float4 o4 = make_float4(acc[i].x * inv, acc[i].y * inv, acc[i].z * inv, acc[i].w * inv);
-    *reinterpret_cast<float4*>(O + ro + i * 4) = o4;
-  }
-}
-
 }  // namespace
 
 extern "C" int lr2_xattn_fwd(const void* Q, const void* K, const void* V, void* O, int o_planes, uint64_t o_lo_off, int batch,
@@ -291,20 +231,5 @@ extern "C" int lr2_xattn_bwd(const void* Q, const void* K, const void* V, const 
   LR2_LAUNCH(xattn_bwd_kernel, dim3(batch * heads), dim3(256), lds, (hipStream_t)stream, (const float*)Q,
                      (const float*)K, (const float*)V, (const float*)dO, (float*)dQ, (float*)dK, (float*)dV, planes,
                      (size_t)q_lo_off, (size_t)kv_lo_off, heads, Lq, Lk, head_dim, post_scale);
-  return lr2_launch_status(__func__);
-}
-
-extern "C" int lr2_self_attn_fwd(const void* Q, const void* K, const void* V, const int64_t* seg, void* O, int batch,
-                                 int heads, int L, int head_dim, float scale, void* stream) {
-  if (!Q || !K || !V || !seg || !O || batch <= 0 || heads <= 0) return LR2_ERR_ARG;
-  if (head_dim != SA_HD || L < 1 || L > 256) return LR2_ERR_SHAPE;
-  const size_t lds = ((size_t)2 * L * SA_HD + L) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (lr2_allow_dynamic_lds(self_attn_fwd_kernel, 160 * 1024, "self_attn_fwd")) return LR2_ERR_LAUNCH;
-    attr_set = true;
-  }
-  LR2_LAUNCH(self_attn_fwd_kernel, dim3(batch * heads), dim3(256), lds, (hipStream_t)stream, (const float*)Q,
-                     (const float*)K, (const float*)V, seg, (float*)O, heads, L, scale);
   return lr2_launch_status(__func__);
 }

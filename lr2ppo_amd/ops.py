@@ -160,9 +160,10 @@ def choose_tiling(M: int, N: int, K: int, trans_a: bool, trans_b: bool = False):
     that skinny GEMMs fill the chip without wave-quantisation tails (576 workgroups on 512 slots = 2 rounds)."""
     bm = 64 if (M <= 64 and not trans_a) else 128
     tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
-    if bm == 128 and not trans_a and not trans_b and 512 < tiles < 1024:
-        # NT with between one and two rounds of 128-row tiles (M=12544, N=768: 588 tiles on 512 slots): the half-empty
-        # second round costs more than the lower intensity of 64-row tiles (measured +9..11 %)
+    if bm == 128 and not trans_a and not trans_b and (512 < tiles < 1536 or (256 < tiles <= 512 and K < 1536)):
+        # NT with fewer than three rounds of 128-row tiles (512 resident workgroups): the part-empty last round costs more
+        # than the lower intensity of 64-row tiles.  Measured with tools/gemm_bench.py: M=12544 N=768 (588 tiles) +9..11 %,
+        # M=6304 N=768 K=768 (300) +17 %, M=6304 N=3072 (1200) +17 %; M=12544 N=3072 (2352 tiles) is 10 % faster at 128.
         return 64, 1
     k_tiles = (K + 63) // 64
     slots = 768 if bm == 64 else 512
@@ -244,10 +245,11 @@ def layernorm_fwd(x, gamma, beta, out, mean=None, rstd=None, *, rows, D, eps=1e-
                   out_planes: Optional[Planes] = None):
     """out (fp32) and/or out_planes receive LN(x); both use the (group, group_stride) row mapping."""
     _chk_f32(x, gamma, beta, out, mean, rstd)
-    rc = _nat.lib().lr2_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(out),
-                                      out_planes.data_ptr() if out_planes is not None else None,
-                                      out_planes.lo_off if out_planes is not None else 0, _ptr(mean), _ptr(rstd), rows, D, eps,
-                                      mode, group, group_stride, _stream())
+    with _Timed(f"lnfwd_R{rows}_D{D}", 0.0, 8.0 * rows * D):
+        rc = _nat.lib().lr2_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(out),
+                                          out_planes.data_ptr() if out_planes is not None else None,
+                                          out_planes.lo_off if out_planes is not None else 0, _ptr(mean), _ptr(rstd), rows, D,
+                                          eps, mode, group, group_stride, _stream())
     _nat.check(rc, "lr2_layernorm_fwd")
     return out if out is not None else out_planes
 
@@ -306,12 +308,22 @@ def xattn_bwd(q, k, v, do, dq, dk, dv, *, batch, heads, Lq, Lk, head_dim, post_s
                                         heads, Lq, Lk, head_dim, post_scale, _stream()), "lr2_xattn_bwd")
 
 
-def self_attn_fwd(q, k, v, seg, o, *, batch, heads, L, head_dim, scale):
-    _chk_f32(q, k, v, o)
+def self_attn_fwd(qkv: "Planes", seg, o, *, batch, heads, L, head_dim, scale):
+    """Encoder self-attention on the matrix cores.  qkv: Planes [batch*L, 3*heads*head_dim] = [Q | K | V] (what one fused
+    QKV GEMM writes); seg: int64 [batch*L]; o: fp32 tensor or Planes [batch*L, heads*head_dim]."""
+    E = heads * head_dim
+    if not isinstance(qkv, Planes) or qkv.cols != 3 * E or qkv.rows != batch * L:
+        raise TypeError("self_attn_fwd: qkv must be a Planes matrix [batch*L, 3*heads*head_dim]")
     if seg.dtype != torch.int64:
         raise TypeError("seg must be int64")
-    _nat.check(_nat.lib().lr2_self_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), seg.data_ptr(), o.data_ptr(), batch, heads,
-                                      L, head_dim, scale, _stream()), "lr2_self_attn_fwd")
+    o_pl = isinstance(o, Planes)
+    _chk_f32(None if o_pl else o)
+    base = qkv.data_ptr()
+    with _Timed(f"selfattn_B{batch}_H{heads}_L{L}", 4.0 * batch * heads * L * L * head_dim, 16.0 * batch * L * E):
+        _nat.check(_nat.lib().lr2_self_attn_fwd(base, base + 2 * E, base + 4 * E, qkv.lo_off, qkv.cols, seg.data_ptr(),
+                                                None if o_pl else o.data_ptr(), o.data_ptr() if o_pl else None,
+                                                o.lo_off if o_pl else 0, E, batch, heads, L, head_dim, scale, _stream()),
+                   "lr2_self_attn_fwd")
     return o
 
 

@@ -228,21 +228,23 @@ def test_xattn_fwd_bwd(ops, dev, batch, heads, Lq, Lk, hd):
     _close(dv, vt.grad.view(-1, E), 1e-5, 1e-4, "dv")
 
 
-@pytest.mark.parametrize("batch,heads,L", [(3, 12, 197), (2, 4, 9), (2, 12, 196)])
-def test_self_attn_fwd_with_key_mask(ops, dev, batch, heads, L):
+@pytest.mark.parametrize("batch,heads,L", [(3, 12, 197), (2, 4, 9), (2, 12, 196), (2, 2, 64), (1, 3, 130), (2, 1, 256)])
+@pytest.mark.parametrize("planes_out", [False, True])
+def test_self_attn_fwd_with_key_mask(ops, dev, batch, heads, L, planes_out):
+    """MFMA self-attention (S^T = K Q^T, P fragments reused from the accumulators) from a fused QKV planes matrix."""
     g = torch.Generator().manual_seed(L)
     E = heads * 64
     q, k, v = _rand(g, batch, L, E, scale=0.3), _rand(g, batch, L, E, scale=0.3), _rand(g, batch, L, E)
     seg = torch.ones(batch, L, dtype=torch.long)
-    seg[1, L // 3:] = 0
+    seg[-1, L // 3:] = 0
     mask = (1.0 - (seg > 0).double()).view(batch, 1, 1, L) * -10000.0
     qh, kh, vh = (t.double().view(batch, L, heads, 64).transpose(1, 2) for t in (q, k, v))
     p = torch.softmax(qh @ kh.transpose(-2, -1) / 8.0 + mask, dim=-1)
     ref = (p @ vh).transpose(1, 2).reshape(batch * L, E)
-    o = torch.empty(batch * L, E, device=dev)
-    ops.self_attn_fwd(q.to(dev).view(-1, E), k.to(dev).view(-1, E), v.to(dev).view(-1, E), seg.to(dev).view(-1), o,
-                      batch=batch, heads=heads, L=L, head_dim=64, scale=1.0 / 8.0)
-    _close(o, ref, 1e-5, 1e-5, "self-attn")
+    qkv = _planes(ops, torch.cat([q, k, v], dim=-1).view(batch * L, 3 * E), dev)
+    o = ops.Planes.empty(batch * L, E, dev) if planes_out else torch.full((batch * L, E), float("nan"), device=dev)
+    ops.self_attn_fwd(qkv, seg.to(dev).view(-1), o, batch=batch, heads=heads, L=L, head_dim=64, scale=1.0 / 8.0)
+    _close(o.to_float() if planes_out else o, ref, 2e-5, 2e-5, "self-attn")
 
 
 # ------------------------------------------------------------------------------------- small ops

@@ -15,6 +15,8 @@ SHAPES = [  # (form, M, N, K) as ops.gemm sees them
     ("NN", 12544, 3072, 768), ("TN", 3072, 768, 12544), ("TN", 768, 3072, 12544), ("TN", 768, 768, 12544),
     ("NT", 64, 3072, 162816), ("NN", 64, 162816, 3072), ("TN", 3072, 162816, 64), ("NT", 1024, 3072, 768),
     ("NT", 4096, 4096, 4096),
+    # dual-encoder forward at batch 32 (M = 32 * 197)
+    ("NT", 6304, 2304, 768), ("NT", 6304, 768, 768), ("NT", 6304, 3072, 768), ("NT", 6304, 768, 3072),
 ]
 
 
