@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 5
+#define LR2_ABI_VERSION 6
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -153,8 +153,21 @@ int lr2_xattn_bwd(const void* Q, const void* K, const void* V, const void* dO, v
  * seg int64 [batch*L]; o fp32 [batch*L, ld_o] and/or o_hi planes (lo plane o_lo_off elements behind); L <= 256, hd == 64.
  * replaces: tencentpretrain/layers/multi_headed_attn.py:61-74 and the mask of encoders/transformer_encoder.py:62-68. */
 int lr2_self_attn_fwd(const void* q_hi, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld, const int64_t* seg,
-                      void* o, void* o_hi, uint64_t o_lo_off, int ld_o, int batch, int heads, int L, int head_dim,
-                      float scale, void* stream);
+                      void* o, void* o_hi, uint64_t o_lo_off, int ld_o, void* lse, float drop_p, uint64_t drop_seed,
+                      uint32_t drop_site, int batch, int heads, int L, int head_dim, float scale, void* stream);
+/* (above) lse: optional fp32 [batch, heads, L] log-sum-exp of the masked scores; drop_p > 0 applies the counter-based
+ * dropout to the probabilities (element index ((b*heads + h)*L + q)*L + key, multi_headed_attn.py:72). */
+
+/* Backward of lr2_self_attn_fwd: from Q, K, V planes and dO planes (same layout rules) to dQ, dK, dV planes
+ * (dq_hi / dk_hi / dv_hi: hi planes, element (row, h*64 + d) at ptr[row*ld_d + h*64 + d], lo plane d_lo_off elements behind --
+ * three column blocks of one dQKV matrix are the intended target).  Two kernels: dQ per 64 queries (also writes the
+ * per-query log-sum-exp and sum_k dP*P into lse_ws / dsum_ws, fp32 [batch*heads*L] each), then dK, dV per 64 keys.
+ * Probabilities are recomputed; pass the forward's drop_p / seed / site to replay its mask.
+ * replaces: autograd of tencentpretrain/layers/multi_headed_attn.py:61-74. */
+int lr2_self_attn_bwd(const void* q_hi, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld, const void* do_hi,
+                      uint64_t do_lo_off, int ld_do, const int64_t* seg, void* dq_hi, void* dk_hi, void* dv_hi,
+                      uint64_t d_lo_off, int ld_d, void* lse_ws, void* dsum_ws, float drop_p, uint64_t drop_seed,
+                      uint32_t drop_site, int batch, int heads, int L, int head_dim, float scale, void* stream);
 
 /* y[r] = dot(x[row(r)], w) + b for r < rows, row(r) = r*row_step + row_off.
  * replaces: self.head = nn.Linear(768, 1) and the last-position select (finetune/ppo.py:228-232,293-295). */

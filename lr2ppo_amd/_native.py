@@ -94,7 +94,9 @@ SIGNATURES = {
     "lr2_colsum": [_P, _I, _U64, _I, _I, _I, _P, _I, _P, _P],
     "lr2_xattn_fwd": [_P, _P, _P, _P, _I, _U64, _I, _I, _I, _I, _I, _F, _P],
     "lr2_xattn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _U64, _U64, _I, _I, _I, _I, _I, _F, _P],
-    "lr2_self_attn_fwd": [_P, _P, _P, _U64, _I, _P, _P, _P, _U64, _I, _I, _I, _I, _I, _F, _P],
+    "lr2_self_attn_fwd": [_P, _P, _P, _U64, _I, _P, _P, _P, _U64, _I, _P, _F, _U64, _U32, _I, _I, _I, _I, _F, _P],
+    "lr2_self_attn_bwd": [_P, _P, _P, _U64, _I, _P, _U64, _I, _P, _P, _P, _P, _U64, _I, _P, _P, _F, _U64, _U32, _I, _I, _I,
+                          _I, _F, _P],
     "lr2_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lr2_head_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lr2_add_period_rows": [_P, _P, _P, _I, _I, _I, _P],
@@ -136,7 +138,7 @@ def lib() -> C.CDLL:
                 raise RuntimeError(f"lr2ppo_amd: {LIB_PATH} does not export {name}") from e
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        if handle.lr2_abi_version() != 5:
+        if handle.lr2_abi_version() != 6:
             raise RuntimeError("lr2ppo_amd: ABI version mismatch between python package and native library")
         _lib = handle
         return _lib

@@ -21,6 +21,17 @@ namespace {
 constexpr int HD = 64;          // head dim
 constexpr int ROW_B = HD * 2;   // bytes of one K / V row in one LDS plane
 
+// Dropout on the attention probabilities (multi_headed_attn.py:72): element (b, h, q, key) of the [B, H, L, L] tensor
+// is kept iff dropout_keep(key, flat index, thr); thr == 0 switches it off.
+struct DropP {
+  uint64_t key;
+  uint32_t thr;
+  float inv_keep;   // 1 / (1 - p)
+};
+__device__ __forceinline__ float drop_mul(const DropP& d, uint64_t idx) {
+  return dropout_keep(d.key, idx, d.thr) ? d.inv_keep : 0.0f;
+}
+
 // K plane: 16-B unit u of row r at u ^ ((r >> 1) & 7): conflict-free ds_read_b128 fragment reads (as in gemm.hip).
 __device__ __forceinline__ int k_off(int r, int u) { return r * ROW_B + ((u ^ ((r >> 1) & 7)) << 4); }
 // V plane: 32-B chunk c of row r at c ^ ((r >> 1) & 3): the 8 rows one half-wave touches in a transposed read land on
@@ -40,7 +51,7 @@ __global__ __launch_bounds__(256) void self_attn_mfma_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ Vh, size_t lo_off, int ld,
                                                              const int64_t* __restrict__ seg, float* __restrict__ O,
                                                              bf16_t* __restrict__ Oh, size_t o_lo_off, int ld_o, int heads,
-                                                             int L, float scale) {
+                                                             int L, float scale, float* __restrict__ lse, DropP dr) {
   constexpr int LP = 16 * NT;
   constexpr int PLANE = LP * ROW_B;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -133,6 +144,8 @@ __global__ __launch_bounds__(256) void self_attn_mfma_kernel(const bf16_t* __res
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
+  if (lse && g == 0 && q_row < L) lse[((size_t)b * heads + h) * L + q_row] = mx + logf(sum);
+  const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_row < L ? q_row : 0)) * (uint64_t)L;
 
   // ---- O = P V over 32-key blocks; P fragments straight from the accumulators (permuted contraction index) ----
   f32x4_t o[4];
@@ -146,6 +159,13 @@ __global__ __launch_bounds__(256) void self_attn_mfma_kernel(const bf16_t* __res
     for (int r = 0; r < 4; ++r) {
       p[r] = s[2 * u][r] * inv;
       p[4 + r] = s[2 * u + 1][r] * inv;
+    }
+    if (dr.thr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r] *= drop_mul(dr, drow + 32 * u + 4 * g + r);
+        p[4 + r] *= drop_mul(dr, drow + 32 * u + 16 + 4 * g + r);
+      }
     }
     const uint32_t h01 = cvt_pk_bf16(p[0], p[1]), h23 = cvt_pk_bf16(p[2], p[3]);
     const uint32_t h45 = cvt_pk_bf16(p[4], p[5]), h67 = cvt_pk_bf16(p[6], p[7]);
@@ -188,42 +208,416 @@ __global__ __launch_bounds__(256) void self_attn_mfma_kernel(const bf16_t* __res
   }
 }
 
+// fp32 x 8 -> A fragment pair (hi, lo) of the split product
+__device__ __forceinline__ void split8(const float (&p)[8], bf16x8_t& hi, bf16x8_t& lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = cvt_pk_bf16(p[2 * i], p[2 * i + 1]);
+    l[i] = cvt_pk_bf16(p[2 * i] - __uint_as_float(h[i] << 16), p[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+  }
+  hi = __builtin_bit_cast(bf16x8_t, (u32x4_t{h[0], h[1], h[2], h[3]}));
+  lo = __builtin_bit_cast(bf16x8_t, (u32x4_t{l[0], l[1], l[2], l[3]}));
+}
+
+__device__ __forceinline__ bf16x8_t tr_pair_k(const char* plane, int row_a, int row_b, int u, int half8) {
+  // transposed read from a plane kept in the K layout (k_off): correct, 2-4 way bank conflicts accepted
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(plane + k_off(row_a, u) + half8));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(plane + k_off(row_b, u) + half8));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// 16 rows x 64 columns of one planes matrix as MFMA fragments (lane: row l & 15, columns 8*(l >> 4) + 32*ks ..)
+__device__ __forceinline__ void load_frags(const bf16_t* hi_plane, size_t lo_off, size_t elem_off, bool ok, bf16x8_t (&fh)[2],
+                                           bf16x8_t (&fl)[2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    u32x4_t a = {0, 0, 0, 0}, c = a;
+    if (ok) {
+      a = *reinterpret_cast<const u32x4_t*>(hi_plane + elem_off + 32 * ks);
+      c = *reinterpret_cast<const u32x4_t*>(hi_plane + elem_off + 32 * ks + lo_off);
+    }
+    fh[ks] = __builtin_bit_cast(bf16x8_t, a);
+    fl[ks] = __builtin_bit_cast(bf16x8_t, c);
+  }
+}
+
+__device__ __forceinline__ f32x4_t mfma3(bf16x8_t ah, bf16x8_t al, bf16x8_t bh, bf16x8_t bl, f32x4_t acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+// 16 x 64 accumulator tile (o[n][r] = X[row 4g + r][col 16n + (l & 15)]) -> planes rows via the wave's LDS slab
+__device__ __forceinline__ void store_tile_planes(const f32x4_t (&o)[4], float* slab, int lane, int row_first, int rows_valid,
+                                                  bf16_t* dst_hi, size_t lo_off, size_t row_stride, size_t base) {
+  const int qn = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slab[(4 * g + r) * (HD + 4) + 16 * n + qn] = o[n][r];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = pass * 4 + (lane >> 4), c = (lane & 15) * 4;
+    if (row_first + r < rows_valid) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + r * (HD + 4) + c);
+      store_planes4(dst_hi + base + (size_t)(row_first + r) * row_stride + c, lo_off, v);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---- backward, part 1: dQ (+ the per-query statistics part 2 needs) -------------------------------------------------
+// Same decomposition as the forward: workgroup = (sequence, head, 64 queries), K and V of the head in LDS, everything
+// in the transposed layout (lane = one query, 4 keys per 16-key tile):
+//   S^T = K Q^T, P = softmax;  dPd^T = V dO^T;  dP = dPd o M;  D = sum_k dP P;  dS = P (dP - D) * scale;  dQ = dS K
+// (M = dropout keep / (1 - p)).  dQ goes to columns [h*64, h*64+64) of the dQKV planes matrix.
 template <int NT>
-int launch_self_attn(const bf16_t* q, const bf16_t* k, const bf16_t* v, size_t lo_off, int ld, const int64_t* seg, float* o,
-                     bf16_t* oh, size_t o_lo_off, int ld_o, int batch, int heads, int L, float scale, hipStream_t stream) {
+__global__ __launch_bounds__(256) void self_attn_bwd_dq_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
+                                                               const bf16_t* __restrict__ Vh, size_t lo_off, int ld,
+                                                               const bf16_t* __restrict__ dOh, size_t do_lo_off, int ld_do,
+                                                               const int64_t* __restrict__ seg, bf16_t* __restrict__ dQh,
+                                                               size_t dq_lo_off, int ld_dq, float* __restrict__ lse,
+                                                               float* __restrict__ dsum, int heads, int L, float scale,
+                                                               DropP dr) {
+  constexpr int LP = 16 * NT;
+  constexpr int PLANE = LP * ROW_B;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + 2 * PLANE;        // K layout too: V is an A operand here (rows = keys, contraction over hd)
+  float* sMask = reinterpret_cast<float*>(smem + 4 * PLANE);
+  float* sOut = sMask + LP;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row0 = (size_t)b * L;
+  const int col0 = h * HD;
+  for (int i = tid; i < LP * 8; i += 256) {
+    const int r = i >> 3, u = i & 7;
+    u32x4_t kh = {0, 0, 0, 0}, kl = kh, vh = kh, vl = kh;
+    if (r < L) {
+      const size_t o = (row0 + r) * (size_t)ld + col0 + u * 8;
+      kh = *reinterpret_cast<const u32x4_t*>(Kh + o);
+      kl = *reinterpret_cast<const u32x4_t*>(Kh + o + lo_off);
+      vh = *reinterpret_cast<const u32x4_t*>(Vh + o);
+      vl = *reinterpret_cast<const u32x4_t*>(Vh + o + lo_off);
+    }
+    *reinterpret_cast<u32x4_t*>(sK + k_off(r, u)) = kh;
+    *reinterpret_cast<u32x4_t*>(sK + PLANE + k_off(r, u)) = kl;
+    *reinterpret_cast<u32x4_t*>(sV + k_off(r, u)) = vh;
+    *reinterpret_cast<u32x4_t*>(sV + PLANE + k_off(r, u)) = vl;
+  }
+  for (int j = tid; j < LP; j += 256) sMask[j] = j < L ? ((seg[row0 + j] > 0) ? 0.f : -10000.0f) : -INFINITY;
+  const int qn = lane & 15, g = lane >> 4;
+  const int q_row = qt * 64 + wave * 16 + qn;
+  const bool q_ok = q_row < L;
+  bf16x8_t qh[2], ql[2], gh[2], gl[2];
+  load_frags(Qh, lo_off, (row0 + (q_ok ? q_row : 0)) * (size_t)ld + col0 + 8 * g, q_ok, qh, ql);
+  load_frags(dOh, do_lo_off, (row0 + (q_ok ? q_row : 0)) * (size_t)ld_do + col0 + 8 * g, q_ok, gh, gl);
+  __syncthreads();
+
+  f32x4_t s[NT], dp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f}, d = a;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r = 16 * t + qn;
+      const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(sK + k_off(r, g + 4 * ks));
+      const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(sK + PLANE + k_off(r, g + 4 * ks));
+      const bf16x8_t vh = *reinterpret_cast<const bf16x8_t*>(sV + k_off(r, g + 4 * ks));
+      const bf16x8_t vl = *reinterpret_cast<const bf16x8_t*>(sV + PLANE + k_off(r, g + 4 * ks));
+      a = mfma3(kh, kl, qh[ks], ql[ks], a);
+      d = mfma3(vh, vl, gh[ks], gl[ks], d);
+    }
+    s[t] = a;
+    dp[t] = d;
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float4 mk = *reinterpret_cast<const float4*>(sMask + 16 * t + 4 * g);
+    s[t][0] = s[t][0] * scale + mk.x;
+    s[t][1] = s[t][1] * scale + mk.y;
+    s[t][2] = s[t][2] * scale + mk.z;
+    s[t][3] = s[t][3] * scale + mk.w;
+    mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[t][r] = expf(s[t][r] - mx);
+      sum += s[t][r];
+    }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_ok ? q_row : 0)) * (uint64_t)L;
+  float dd = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[t][r] *= inv;                                                     // P
+      if (dr.thr) dp[t][r] *= drop_mul(dr, drow + 16 * t + 4 * g + r);    // dP = dPd o M
+      dd += dp[t][r] * s[t][r];
+    }
+  dd += __shfl_xor(dd, 16, 64);
+  dd += __shfl_xor(dd, 32, 64);
+  if (g == 0 && q_ok) {
+    const size_t si = ((size_t)b * heads + h) * L + q_row;
+    lse[si] = mx + logf(sum);
+    dsum[si] = dd;
+  }
+  f32x4_t o[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+#pragma unroll
+  for (int u = 0; u < NT / 2; ++u) {
+    float e[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      e[r] = s[2 * u][r] * (dp[2 * u][r] - dd) * scale;
+      e[4 + r] = s[2 * u + 1][r] * (dp[2 * u + 1][r] - dd) * scale;
+    }
+    bf16x8_t eh, el;
+    split8(e, eh, el);
+    const int ra = 32 * u + 4 * g + tq, rb = ra + 16;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int unit = 2 * n + (tp >> 1), half8 = 8 * (tp & 1);
+      o[n] = mfma3(eh, el, tr_pair_k(sK, ra, rb, unit, half8), tr_pair_k(sK + PLANE, ra, rb, unit, half8), o[n]);
+    }
+  }
+  store_tile_planes(o, sOut + wave * 16 * (HD + 4), lane, qt * 64 + wave * 16, L, dQh, dq_lo_off, (size_t)ld_dq,
+                    row0 * (size_t)ld_dq + col0);
+}
+
+// ---- backward, part 2: dK, dV ------------------------------------------------------------------------------------------
+// Workgroup = (sequence, head, 64 keys); Q and dO of the head in LDS; each wave owns 16 keys (K, V fragments in
+// registers) and walks over the queries in the NON-transposed layout (lane = one key, 4 queries per 16-query tile):
+//   S = Q K^T, P = exp(S - lse[q]);  dPd = dO V^T;  Pd = P o M, dP = dPd o M, dS = P (dP - D[q]) * scale
+//   dV = Pd^T dO,  dK = dS^T Q       (contraction over queries: P / dS tiles reused as A fragments, Q / dO transposed reads)
+template <int NT>
+__global__ __launch_bounds__(256) void self_attn_bwd_dkv_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
+                                                                const bf16_t* __restrict__ Vh, size_t lo_off, int ld,
+                                                                const bf16_t* __restrict__ dOh, size_t do_lo_off, int ld_do,
+                                                                const int64_t* __restrict__ seg, bf16_t* __restrict__ dKh,
+                                                                bf16_t* __restrict__ dVh, size_t dkv_lo_off, int ld_dkv,
+                                                                const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                                int heads, int L, float scale, DropP dr) {
+  constexpr int LP = 16 * NT;
+  constexpr int PLANE = LP * ROW_B;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQ = smem;                    // K layout: fragment reads (rows = queries) + transposed reads
+  char* sG = smem + 2 * PLANE;        // dO
+  float* sLse = reinterpret_cast<float*>(smem + 4 * PLANE);   // [LP]
+  float* sD = sLse + LP;                                      // [LP]
+  float* sOut = sD + LP;
+  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row0 = (size_t)b * L;
+  const int col0 = h * HD;
+  for (int i = tid; i < LP * 8; i += 256) {
+    const int r = i >> 3, u = i & 7;
+    u32x4_t a = {0, 0, 0, 0}, c = a, d = a, e = a;
+    if (r < L) {
+      const size_t o = (row0 + r) * (size_t)ld + col0 + u * 8;
+      const size_t og = (row0 + r) * (size_t)ld_do + col0 + u * 8;
+      a = *reinterpret_cast<const u32x4_t*>(Qh + o);
+      c = *reinterpret_cast<const u32x4_t*>(Qh + o + lo_off);
+      d = *reinterpret_cast<const u32x4_t*>(dOh + og);
+      e = *reinterpret_cast<const u32x4_t*>(dOh + og + do_lo_off);
+    }
+    *reinterpret_cast<u32x4_t*>(sQ + k_off(r, u)) = a;
+    *reinterpret_cast<u32x4_t*>(sQ + PLANE + k_off(r, u)) = c;
+    *reinterpret_cast<u32x4_t*>(sG + k_off(r, u)) = d;
+    *reinterpret_cast<u32x4_t*>(sG + PLANE + k_off(r, u)) = e;
+  }
+  for (int j = tid; j < LP; j += 256) {
+    const size_t si = ((size_t)b * heads + h) * L + j;
+    sLse[j] = j < L ? lse[si] : INFINITY;     // padded queries: P = exp(-inf) = 0
+    sD[j] = j < L ? dsum[si] : 0.f;
+  }
+  const int kn = lane & 15, g = lane >> 4;
+  const int key = kt * 64 + wave * 16 + kn;
+  const bool k_ok = key < L;
+  bf16x8_t kh[2], kl[2], vh[2], vl[2];
+  load_frags(Kh, lo_off, (row0 + (k_ok ? key : 0)) * (size_t)ld + col0 + 8 * g, k_ok, kh, kl);
+  load_frags(Vh, lo_off, (row0 + (k_ok ? key : 0)) * (size_t)ld + col0 + 8 * g, k_ok, vh, vl);
+  const float kmask = k_ok ? ((seg[row0 + key] > 0) ? 0.f : -10000.0f) : -INFINITY;
+  __syncthreads();
+
+  f32x4_t dv[4], dk[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) dv[n] = dk[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+  const uint64_t dbase = ((uint64_t)b * heads + h) * (uint64_t)L;
+#pragma unroll 1
+  for (int u = 0; u < NT / 2; ++u) {
+    float pd[8], ds[8];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int t = 2 * u + half;
+      f32x4_t a = {0.f, 0.f, 0.f, 0.f}, d = a;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int r = 16 * t + kn;         // A fragments: query row 16t + (l & 15)
+        const bf16x8_t qh = *reinterpret_cast<const bf16x8_t*>(sQ + k_off(r, g + 4 * ks));
+        const bf16x8_t ql = *reinterpret_cast<const bf16x8_t*>(sQ + PLANE + k_off(r, g + 4 * ks));
+        const bf16x8_t gh = *reinterpret_cast<const bf16x8_t*>(sG + k_off(r, g + 4 * ks));
+        const bf16x8_t gl = *reinterpret_cast<const bf16x8_t*>(sG + PLANE + k_off(r, g + 4 * ks));
+        a = mfma3(qh, ql, kh[ks], kl[ks], a);      // S[query 16t + 4g + r][key kn]
+        d = mfma3(gh, gl, vh[ks], vl[ks], d);      // dPd
+      }
+      const float4 ls = *reinterpret_cast<const float4*>(sLse + 16 * t + 4 * g);
+      const float4 dd = *reinterpret_cast<const float4*>(sD + 16 * t + 4 * g);
+      const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, ddv[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = expf(a[r] * scale + kmask - lsv[r]);
+        float m = 1.0f;
+        if (dr.thr) {
+          const int q = 16 * t + 4 * g + r;
+          m = drop_mul(dr, (dbase + (uint64_t)(q < L ? q : 0)) * (uint64_t)L + (uint64_t)(k_ok ? key : 0));
+        }
+        pd[4 * half + r] = p * m;
+        ds[4 * half + r] = p * (d[r] * m - ddv[r]) * scale;
+      }
+    }
+    bf16x8_t ph, pl, eh, el;
+    split8(pd, ph, pl);
+    split8(ds, eh, el);
+    const int ra = 32 * u + 4 * g + tq, rb = ra + 16;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int unit = 2 * n + (tp >> 1), half8 = 8 * (tp & 1);
+      dv[n] = mfma3(ph, pl, tr_pair_k(sG, ra, rb, unit, half8), tr_pair_k(sG + PLANE, ra, rb, unit, half8), dv[n]);
+      dk[n] = mfma3(eh, el, tr_pair_k(sQ, ra, rb, unit, half8), tr_pair_k(sQ + PLANE, ra, rb, unit, half8), dk[n]);
+    }
+  }
+  float* slab = sOut + wave * 16 * (HD + 4);
+  store_tile_planes(dk, slab, lane, kt * 64 + wave * 16, L, dKh, dkv_lo_off, (size_t)ld_dkv, row0 * (size_t)ld_dkv + col0);
+  store_tile_planes(dv, slab, lane, kt * 64 + wave * 16, L, dVh, dkv_lo_off, (size_t)ld_dkv, row0 * (size_t)ld_dkv + col0);
+}
+
+static DropP make_drop(float p, uint64_t seed, uint32_t site) {
+  DropP d{0, 0, 1.0f};
+  if (p > 0.f) {
+    d.thr = dropout_threshold(p);
+    d.inv_keep = 1.0f / (1.0f - p);
+    d.key = (((uint64_t)site) << 40) ^ (seed * 0x9E3779B97F4A7C15ull);
+  }
+  return d;
+}
+
+template <typename Kern>
+int allow_lds_once(Kern kern, size_t lds, bool& done, const char* what) {
+  if (!done) {
+    if (lr2_allow_dynamic_lds(kern, lds, what)) return LR2_ERR_LAUNCH;
+    done = true;
+  }
+  return 0;
+}
+
+struct AttnArgs {
+  const bf16_t *q, *k, *v;
+  size_t lo_off;
+  int ld;
+  const int64_t* seg;
+  int batch, heads, L;
+  float scale;
+  DropP dr;
+  hipStream_t stream;
+};
+
+template <int NT>
+int launch_fwd(const AttnArgs& a, float* o, bf16_t* oh, size_t o_lo_off, int ld_o, float* lse) {
   constexpr int LP = 16 * NT;
   const size_t lds = (size_t)4 * LP * ROW_B + (size_t)LP * 4 + (size_t)4 * 16 * (HD + 4) * 4;
-  auto kern = self_attn_mfma_kernel<NT>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (lr2_allow_dynamic_lds(kern, lds, "self_attn_fwd")) return LR2_ERR_LAUNCH;
-    attr_set = true;
-  }
-  LR2_LAUNCH(kern, dim3((L + 63) / 64, heads, batch), dim3(256), lds, stream, q, k, v, lo_off, ld, seg, o, oh, o_lo_off, ld_o,
-             heads, L, scale);
+  static bool done = false;
+  if (allow_lds_once(self_attn_mfma_kernel<NT>, lds, done, "self_attn_fwd")) return LR2_ERR_LAUNCH;
+  LR2_LAUNCH(self_attn_mfma_kernel<NT>, dim3((a.L + 63) / 64, a.heads, a.batch), dim3(256), lds, a.stream, a.q, a.k, a.v,
+             a.lo_off, a.ld, a.seg, o, oh, o_lo_off, ld_o, a.heads, a.L, a.scale, lse, a.dr);
   return lr2_launch_status("lr2_self_attn_fwd");
 }
 
-template __global__ void self_attn_mfma_kernel<4>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int, const int64_t*,
-                                                  float*, bf16_t*, size_t, int, int, int, float);
-template __global__ void self_attn_mfma_kernel<8>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int, const int64_t*,
-                                                  float*, bf16_t*, size_t, int, int, int, float);
-template __global__ void self_attn_mfma_kernel<14>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int, const int64_t*,
-                                                   float*, bf16_t*, size_t, int, int, int, float);
-template __global__ void self_attn_mfma_kernel<16>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int, const int64_t*,
-                                                   float*, bf16_t*, size_t, int, int, int, float);
+template <int NT>
+int launch_bwd(const AttnArgs& a, const bf16_t* go, size_t do_lo_off, int ld_do, bf16_t* dq, bf16_t* dk, bf16_t* dv,
+               size_t d_lo_off, int ld_d, float* lse, float* dsum) {
+  constexpr int LP = 16 * NT;
+  const size_t lds1 = (size_t)4 * LP * ROW_B + (size_t)LP * 4 + (size_t)4 * 16 * (HD + 4) * 4;
+  const size_t lds2 = (size_t)4 * LP * ROW_B + (size_t)LP * 8 + (size_t)4 * 16 * (HD + 4) * 4;
+  static bool done1 = false, done2 = false;
+  if (allow_lds_once(self_attn_bwd_dq_kernel<NT>, lds1, done1, "self_attn_bwd_dq")) return LR2_ERR_LAUNCH;
+  if (allow_lds_once(self_attn_bwd_dkv_kernel<NT>, lds2, done2, "self_attn_bwd_dkv")) return LR2_ERR_LAUNCH;
+  const dim3 grid((a.L + 63) / 64, a.heads, a.batch);
+  LR2_LAUNCH(self_attn_bwd_dq_kernel<NT>, grid, dim3(256), lds1, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, go, do_lo_off, ld_do,
+             a.seg, dq, d_lo_off, ld_d, lse, dsum, a.heads, a.L, a.scale, a.dr);
+  if (lr2_launch_status("lr2_self_attn_bwd(dq)")) return LR2_ERR_LAUNCH;
+  LR2_LAUNCH(self_attn_bwd_dkv_kernel<NT>, grid, dim3(256), lds2, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, go, do_lo_off, ld_do,
+             a.seg, dk, dv, d_lo_off, ld_d, (const float*)lse, (const float*)dsum, a.heads, a.L, a.scale, a.dr);
+  return lr2_launch_status("lr2_self_attn_bwd(dkv)");
+}
+
+#define LR2_SA_INST(NT)                                                                                                        \
+  template __global__ void self_attn_mfma_kernel<NT>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int, const int64_t*, \
+                                                     float*, bf16_t*, size_t, int, int, int, float, float*, DropP);            \
+  template __global__ void self_attn_bwd_dq_kernel<NT>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int, const bf16_t*, \
+                                                       size_t, int, const int64_t*, bf16_t*, size_t, int, float*, float*, int,  \
+                                                       int, float, DropP);                                                     \
+  template __global__ void self_attn_bwd_dkv_kernel<NT>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int,               \
+                                                        const bf16_t*, size_t, int, const int64_t*, bf16_t*, bf16_t*, size_t,   \
+                                                        int, const float*, const float*, int, int, float, DropP);
+LR2_SA_INST(4)
+LR2_SA_INST(8)
+LR2_SA_INST(14)
+LR2_SA_INST(16)
 
 }  // namespace
 
+#define LR2_SA_DISPATCH(L, CALL)  \
+  if ((L) <= 64) return CALL(4);  \
+  if ((L) <= 128) return CALL(8); \
+  if ((L) <= 224) return CALL(14); \
+  return CALL(16);
+
 extern "C" int lr2_self_attn_fwd(const void* q_hi, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld,
-                                 const int64_t* seg, void* o, void* o_hi, uint64_t o_lo_off, int ld_o, int batch, int heads,
-                                 int L, int head_dim, float scale, void* stream) {
+                                 const int64_t* seg, void* o, void* o_hi, uint64_t o_lo_off, int ld_o, void* lse, float drop_p,
+                                 uint64_t drop_seed, uint32_t drop_site, int batch, int heads, int L, int head_dim, float scale,
+                                 void* stream) {
   if (!q_hi || !k_hi || !v_hi || !seg || (!o && !o_hi) || batch <= 0 || heads <= 0) return LR2_ERR_ARG;
-  if (head_dim != HD || L < 1 || L > 256 || ld % 8 || ld_o % 4 || lo_off % 8) return LR2_ERR_SHAPE;
-  const bf16_t *q = (const bf16_t*)q_hi, *k = (const bf16_t*)k_hi, *v = (const bf16_t*)v_hi;
-  hipStream_t s = (hipStream_t)stream;
-  if (L <= 64) return launch_self_attn<4>(q, k, v, lo_off, ld, seg, (float*)o, (bf16_t*)o_hi, o_lo_off, ld_o, batch, heads, L, scale, s);
-  if (L <= 128) return launch_self_attn<8>(q, k, v, lo_off, ld, seg, (float*)o, (bf16_t*)o_hi, o_lo_off, ld_o, batch, heads, L, scale, s);
-  if (L <= 224) return launch_self_attn<14>(q, k, v, lo_off, ld, seg, (float*)o, (bf16_t*)o_hi, o_lo_off, ld_o, batch, heads, L, scale, s);
-  return launch_self_attn<16>(q, k, v, lo_off, ld, seg, (float*)o, (bf16_t*)o_hi, o_lo_off, ld_o, batch, heads, L, scale, s);
+  if (head_dim != HD || L < 1 || L > 256 || ld % 8 || ld_o % 4 || lo_off % 8 || o_lo_off % 4) return LR2_ERR_SHAPE;
+  if (drop_p < 0.f || drop_p >= 1.f) return LR2_ERR_ARG;
+  const AttnArgs a{(const bf16_t*)q_hi, (const bf16_t*)k_hi, (const bf16_t*)v_hi, (size_t)lo_off, ld, seg, batch, heads, L,
+                   scale, make_drop(drop_p, drop_seed, drop_site), (hipStream_t)stream};
+#define CALL(NT) launch_fwd<NT>(a, (float*)o, (bf16_t*)o_hi, (size_t)o_lo_off, ld_o, (float*)lse)
+  LR2_SA_DISPATCH(L, CALL)
+#undef CALL
+}
+
+extern "C" int lr2_self_attn_bwd(const void* q_hi, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld,
+                                 const void* do_hi, uint64_t do_lo_off, int ld_do, const int64_t* seg, void* dq_hi, void* dk_hi,
+                                 void* dv_hi, uint64_t d_lo_off, int ld_d, void* lse_ws, void* dsum_ws, float drop_p,
+                                 uint64_t drop_seed, uint32_t drop_site, int batch, int heads, int L, int head_dim, float scale,
+                                 void* stream) {
+  if (!q_hi || !k_hi || !v_hi || !do_hi || !seg || !dq_hi || !dk_hi || !dv_hi || !lse_ws || !dsum_ws || batch <= 0 || heads <= 0)
+    return LR2_ERR_ARG;
+  if (head_dim != HD || L < 1 || L > 256 || ld % 8 || ld_do % 8 || ld_d % 8 || lo_off % 8 || do_lo_off % 8 || d_lo_off % 8)
+    return LR2_ERR_SHAPE;
+  if (drop_p < 0.f || drop_p >= 1.f) return LR2_ERR_ARG;
+  const AttnArgs a{(const bf16_t*)q_hi, (const bf16_t*)k_hi, (const bf16_t*)v_hi, (size_t)lo_off, ld, seg, batch, heads, L,
+                   scale, make_drop(drop_p, drop_seed, drop_site), (hipStream_t)stream};
+#define CALL(NT)                                                                                                           \
+  launch_bwd<NT>(a, (const bf16_t*)do_hi, (size_t)do_lo_off, ld_do, (bf16_t*)dq_hi, (bf16_t*)dk_hi, (bf16_t*)dv_hi,        \
+                 (size_t)d_lo_off, ld_d, (float*)lse_ws, (float*)dsum_ws)
+  LR2_SA_DISPATCH(L, CALL)
+#undef CALL
 }

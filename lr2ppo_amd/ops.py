@@ -308,23 +308,52 @@ def xattn_bwd(q, k, v, do, dq, dk, dv, *, batch, heads, Lq, Lk, head_dim, post_s
                                         heads, Lq, Lk, head_dim, post_scale, _stream()), "lr2_xattn_bwd")
 
 
-def self_attn_fwd(qkv: "Planes", seg, o, *, batch, heads, L, head_dim, scale):
+def _qkv_ptrs(qkv, E):
+    base = qkv.data_ptr()
+    return base, base + 2 * E, base + 4 * E
+
+
+def self_attn_fwd(qkv: "Planes", seg, o, *, batch, heads, L, head_dim, scale, lse=None, drop: Optional[Drop] = None):
     """Encoder self-attention on the matrix cores.  qkv: Planes [batch*L, 3*heads*head_dim] = [Q | K | V] (what one fused
-    QKV GEMM writes); seg: int64 [batch*L]; o: fp32 tensor or Planes [batch*L, heads*head_dim]."""
+    QKV GEMM writes); seg: int64 [batch*L]; o: fp32 tensor or Planes [batch*L, heads*head_dim]; lse: optional fp32
+    [batch*heads*L]; drop: dropout on the probabilities."""
     E = heads * head_dim
     if not isinstance(qkv, Planes) or qkv.cols != 3 * E or qkv.rows != batch * L:
         raise TypeError("self_attn_fwd: qkv must be a Planes matrix [batch*L, 3*heads*head_dim]")
     if seg.dtype != torch.int64:
         raise TypeError("seg must be int64")
     o_pl = isinstance(o, Planes)
-    _chk_f32(None if o_pl else o)
-    base = qkv.data_ptr()
+    _chk_f32(None if o_pl else o, lse)
+    q, k, v = _qkv_ptrs(qkv, E)
+    p, seed, site = (drop.p, drop.seed, drop.site) if drop is not None else (0.0, 0, 0)
     with _Timed(f"selfattn_B{batch}_H{heads}_L{L}", 4.0 * batch * heads * L * L * head_dim, 16.0 * batch * L * E):
-        _nat.check(_nat.lib().lr2_self_attn_fwd(base, base + 2 * E, base + 4 * E, qkv.lo_off, qkv.cols, seg.data_ptr(),
+        _nat.check(_nat.lib().lr2_self_attn_fwd(q, k, v, qkv.lo_off, qkv.cols, seg.data_ptr(),
                                                 None if o_pl else o.data_ptr(), o.data_ptr() if o_pl else None,
-                                                o.lo_off if o_pl else 0, E, batch, heads, L, head_dim, scale, _stream()),
-                   "lr2_self_attn_fwd")
+                                                o.lo_off if o_pl else 0, E, _ptr(lse), p, seed, site, batch, heads, L, head_dim,
+                                                scale, _stream()), "lr2_self_attn_fwd")
     return o
+
+
+def self_attn_bwd(qkv: "Planes", do: "Planes", seg, dqkv: "Planes", lse_ws, dsum_ws, *, batch, heads, L, head_dim, scale,
+                  drop: Optional[Drop] = None):
+    """dQKV (Planes [batch*L, 3E]) from QKV and dO (Planes [batch*L, E]); lse_ws / dsum_ws: fp32 [batch*heads*L] scratch."""
+    E = heads * head_dim
+    for name, t, cols in (("qkv", qkv, 3 * E), ("do", do, E), ("dqkv", dqkv, 3 * E)):
+        if not isinstance(t, Planes) or t.cols != cols or t.rows != batch * L:
+            raise TypeError(f"self_attn_bwd: {name} must be a Planes matrix [batch*L, {cols}]")
+    if seg.dtype != torch.int64:
+        raise TypeError("seg must be int64")
+    _chk_f32(lse_ws, dsum_ws)
+    if lse_ws.numel() < batch * heads * L or dsum_ws.numel() < batch * heads * L:
+        raise ValueError("self_attn_bwd: statistics workspaces too small")
+    q, k, v = _qkv_ptrs(qkv, E)
+    dq, dk, dv = _qkv_ptrs(dqkv, E)
+    p, seed, site = (drop.p, drop.seed, drop.site) if drop is not None else (0.0, 0, 0)
+    with _Timed(f"selfattnbwd_B{batch}_H{heads}_L{L}", 14.0 * batch * heads * L * L * head_dim, 32.0 * batch * L * E):
+        _nat.check(_nat.lib().lr2_self_attn_bwd(q, k, v, qkv.lo_off, qkv.cols, do.data_ptr(), do.lo_off, do.cols, seg.data_ptr(),
+                                                dq, dk, dv, dqkv.lo_off, dqkv.cols, lse_ws.data_ptr(), dsum_ws.data_ptr(), p,
+                                                seed, site, batch, heads, L, head_dim, scale, _stream()), "lr2_self_attn_bwd")
+    return dqkv
 
 
 def gather_rows(src, index, dst, *, B, t_in, t_out, row_elems, src_bstride=None, src_tstride=None):

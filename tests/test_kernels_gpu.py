@@ -247,6 +247,49 @@ def test_self_attn_fwd_with_key_mask(ops, dev, batch, heads, L, planes_out):
     _close(o.to_float() if planes_out else o, ref, 2e-5, 2e-5, "self-attn")
 
 
+@pytest.mark.parametrize("batch,heads,L,drop_p", [(2, 3, 197, 0.0), (1, 2, 64, 0.0), (2, 1, 130, 0.1), (1, 2, 256, 0.0),
+                                                    (2, 2, 196, 0.1)])
+def test_self_attn_bwd_matches_autograd(ops, dev, batch, heads, L, drop_p):
+    """dQ / dK / dV of the MFMA self-attention (two kernels, probabilities recomputed, dropout mask replayed) against
+    fp64 autograd of the reference formula; the forward with dropout and its log-sum-exp output are checked on the way."""
+    import numpy as np
+    from oracle import lr2ppo_oracle as O
+    g = torch.Generator().manual_seed(L + heads)
+    E = heads * 64
+    qkv = torch.cat([_rand(g, batch * L, E, scale=0.3), _rand(g, batch * L, E, scale=0.3), _rand(g, batch * L, E)], dim=1)
+    do = _rand(g, batch * L, E)
+    seg = torch.ones(batch, L, dtype=torch.long)
+    seg[-1, (2 * L) // 3:] = 0
+    mask = (1.0 - (seg > 0).double()).view(batch, 1, 1, L) * -10000.0
+    seed, site = 99, 5
+    mult = torch.ones(batch, heads, L, L, dtype=torch.float64)
+    if drop_p > 0:
+        keep = O.dropout_keep_mask(seed, site, batch * heads * L * L, drop_p)
+        mult = torch.from_numpy(np.asarray(keep, dtype=np.float64)).view(batch, heads, L, L) / (1.0 - drop_p)
+    x = qkv.double().requires_grad_(True)
+    qh, kh, vh = (t.reshape(batch, L, heads, 64).transpose(1, 2) for t in x.split(E, dim=1))
+    sc = qh @ kh.transpose(-2, -1) / 8.0 + mask
+    ref_o = ((torch.softmax(sc, dim=-1) * mult) @ vh).transpose(1, 2).reshape(batch * L, E)
+    (ref_o * do.double()).sum().backward()
+    drop = ops.Drop(drop_p, seed, site) if drop_p > 0 else None
+    qkv_p, do_p = _planes(ops, qkv, dev), _planes(ops, do, dev)
+    o = torch.empty(batch * L, E, device=dev)
+    lse = torch.empty(batch * heads * L, device=dev)
+    ops.self_attn_fwd(qkv_p, seg.to(dev).view(-1), o, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, lse=lse, drop=drop)
+    _close(o, ref_o.detach(), 3e-5, 3e-5, "self-attn fwd (dropout)")
+    _close(lse.view(batch, heads, L), torch.logsumexp(sc.detach(), dim=-1), 1e-5, 1e-5, "lse")
+    dqkv = ops.Planes.empty(batch * L, 3 * E, dev)
+    dqkv.buf.fill_(0x7FC0)       # bf16 NaN pattern: every element must be written
+    ws1, ws2 = torch.empty(batch * heads * L, device=dev), torch.empty(batch * heads * L, device=dev)
+    ops.self_attn_bwd(qkv_p, do_p, seg.to(dev).view(-1), dqkv, ws1, ws2, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125,
+                      drop=drop)
+    got = dqkv.to_float()
+    for name, lo in (("dQ", 0), ("dK", E), ("dV", 2 * E)):
+        ref = x.grad[:, lo:lo + E]
+        _close(got[:, lo:lo + E], ref, 3e-5 * max(1.0, float(ref.abs().max())), 5e-5, name)
+    assert torch.equal(ws1, lse)
+
+
 # ------------------------------------------------------------------------------------- small ops
 def test_gather_copy_head_period(ops, dev):
     g = torch.Generator().manual_seed(2)
