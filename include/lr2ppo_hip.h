@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 6
+#define LR2_ABI_VERSION 7
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -96,6 +96,10 @@ int lr2_copy_rows(const void* src, void* dst, int dst_planes, uint64_t dst_lo_of
                   uint64_t dst_gstride, uint64_t dst_off, void* stream);
 /* fp32 -> bf16 planes: dst_hi[i] = bf16(src[i]), dst_hi[lo_off + i] = bf16(src[i] - hi) for i < n (n % 4 == 0). */
 int lr2_split_planes(const void* src, void* dst_hi, uint64_t lo_off, uint64_t n, void* stream);
+/* planes of dropout_mask(src) / (1 - p), mask element index = flat element index (the gradient entering a dropped branch).
+ * replaces: autograd of nn.Dropout at tencentpretrain/layers/transformer.py:55,58,65,72 on the pre-LN residual paths. */
+int lr2_dropout_planes(const void* src, void* dst_hi, uint64_t lo_off, uint64_t n, float drop_p, uint64_t drop_seed,
+                       uint32_t drop_site, void* stream);
 /* The same for many tensors in one launch (weights after an optimizer step). table: DEVICE array of chunks. */
 typedef struct lr2_split_chunk {
   const void* src;
@@ -116,15 +120,16 @@ int lr2_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* 
                       void* mean, void* rstd, int rows, int D, float eps, int mode, int group, uint64_t group_stride,
                       void* stream);
 
-/* LayerNorm backward (mode 0).  dy uses the same (group, stride) row mapping as the forward output.
+/* LayerNorm backward, both semantics (mode / eps as in the forward).  dy uses the same (group, stride) row mapping as the forward output.
  * dx = LN'(dy) (+ resid_grad) -> dx (fp32); optional dxm_hi = bf16 planes of dropout_mask(dx)/(1-p) (the gradient of
  * y = dropout(a) + res with respect to a, finetune/xit.py:34,40; p = 0: planes of dx), the next GEMMs' operand.  dgamma/dbeta are accumulated per block
  * into partials [nblocks][2][D]; finish with lr2_colsum_partials_finish.
- * replaces: autograd of nn.LayerNorm + the in-place residual adds of finetune/xit.py:45-55,77-86. */
+ * replaces: autograd of nn.LayerNorm + the in-place residual adds of finetune/xit.py:45-55,77-86, and of the
+ * TencentPretrain LayerNorm (tencentpretrain/layers/layer_norm.py:16-21) in the encoder layers. */
 int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_stride, const void* x, const void* gamma,
                       const void* mean, const void* rstd, const void* resid_grad, void* dx, void* dxm_hi,
                       uint64_t dxm_lo_off, float drop_p, uint64_t drop_seed, uint32_t drop_site, void* partials,
-                      int nblocks, int rows, int D, void* stream);
+                      int nblocks, int rows, int D, int mode, float eps, void* stream);
 /* out[c] = sum_b partials[b*ld + c] for c < cols (deterministic second stage of column reductions). */
 int lr2_colsum_partials_finish(const void* partials, int nblocks, int cols, int ld, void* out, int accumulate,
                                void* stream);

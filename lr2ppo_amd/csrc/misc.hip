@@ -62,6 +62,20 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     store_planes4(dst + i * 4, lo_off, reinterpret_cast<const float4*>(src)[i]);
 }
 
+// planes of dropout_mask(src) / (1 - p): the gradient entering a dropped branch (pre-LN encoder layers)
+__global__ __launch_bounds__(256) void dropout_planes_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             size_t lo_off, size_t n4, float scale, uint32_t thr, uint64_t key) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 v = reinterpret_cast<const float4*>(src)[i];
+    const uint64_t e = (uint64_t)i * 4;
+    v.x = dropout_keep(key, e + 0, thr) ? v.x * scale : 0.f;
+    v.y = dropout_keep(key, e + 1, thr) ? v.y * scale : 0.f;
+    v.z = dropout_keep(key, e + 2, thr) ? v.z * scale : 0.f;
+    v.w = dropout_keep(key, e + 3, thr) ? v.w * scale : 0.f;
+    store_planes4(dst + i * 4, lo_off, v);
+  }
+}
+
 struct SplitChunk {
   const float* src;
   bf16_t* dst_hi;
@@ -461,6 +475,17 @@ extern "C" int lr2_split_planes(const void* src, void* dst_hi, uint64_t lo_off, 
   if (n % 4 || lo_off % 4) return LR2_ERR_SHAPE;
   LR2_LAUNCH(split_planes_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)src,
              (bf16_t*)dst_hi, (size_t)lo_off, (size_t)(n / 4));
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_dropout_planes(const void* src, void* dst_hi, uint64_t lo_off, uint64_t n, float drop_p, uint64_t drop_seed,
+                                  uint32_t drop_site, void* stream) {
+  if (!src || !dst_hi || n == 0 || drop_p < 0.f || drop_p >= 1.f) return LR2_ERR_ARG;
+  if (n % 4 || lo_off % 4) return LR2_ERR_SHAPE;
+  if (drop_p == 0.f) return lr2_split_planes(src, dst_hi, lo_off, n, stream);
+  LR2_LAUNCH(dropout_planes_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)src,
+             (bf16_t*)dst_hi, (size_t)lo_off, (size_t)(n / 4), 1.0f / (1.0f - drop_p), dropout_threshold(drop_p),
+             (((uint64_t)drop_site) << 40) ^ (drop_seed * 0x9E3779B97F4A7C15ull));
   CHECK_LAUNCH();
 }
 

@@ -69,13 +69,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)), g = dy*gamma     (nn.LayerNorm backward)
+// dx = rstd * (g - mean(g) - xhat * c2), g = dy*gamma
+//   mode 0 (nn.LayerNorm, biased variance, eps inside the sqrt):      c2 = sum(g*xhat) / D
+//   mode 1 (TencentPretrain LayerNorm, y = gamma (x - mean) / (std + eps) + beta with the UNBIASED std, layer_norm.py:16-21):
+//           c2 = sum(g*xhat) / ((D - 1) * (1 - eps * rstd)),  rstd = 1 / (std + eps)      [std * rstd = 1 - eps * rstd]
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int group, uint64_t group_stride,
                                                             const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const float* __restrict__ resid_grad, float* __restrict__ dx_f32,
                                                             bf16_t* __restrict__ dxm_hi, size_t dxm_lo_off, float drop_scale, uint32_t drop_thr,
-                                                            uint64_t drop_key, float* __restrict__ partials, int rows, int D) {
+                                                            uint64_t drop_key, float* __restrict__ partials, int rows, int D,
+                                                            int mode, float eps) {
   __shared__ float red[4][2][MAXV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 dg[MAXV], db[MAXV], gam[MAXV];
@@ -105,7 +109,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         db[i].x += dyv.x; db[i].y += dyv.y; db[i].z += dyv.z; db[i].w += dyv.w;
       }
     }
-    const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+    const float c1 = wave_sum(s1) / (float)D;
+    const float c2 = wave_sum(s2) / (mode == 0 ? (float)D : (float)(D - 1) * (1.0f - eps * rstd));
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int e = (i * 64 + lane) * 4;
@@ -226,9 +231,10 @@ extern "C" int lr2_layernorm_fwd(const void* x, const void* gamma, const void* b
 extern "C" int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_stride, const void* x, const void* gamma,
                                  const void* mean, const void* rstd, const void* resid_grad, void* dx, void* dxm_hi,
                                  uint64_t dxm_lo_off, float drop_p, uint64_t drop_seed, uint32_t drop_site, void* partials,
-                                 int nblocks, int rows, int D, void* stream) {
+                                 int nblocks, int rows, int D, int mode, float eps, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !partials || (!dx && !dxm_hi) || rows <= 0 || nblocks <= 0)
     return LR2_ERR_ARG;
+  if (mode != 0 && mode != 1) return LR2_ERR_ARG;
   if (D % 4 != 0 || D > MAXV * 256 || D < 4) return LR2_ERR_SHAPE;
   if (group <= 0) { group = rows; group_stride = 0; }
   float scale = 0.f;
@@ -241,7 +247,7 @@ extern "C" int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_strid
   }
   LR2_LAUNCH(layernorm_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, group, group_stride,
              (const float*)x, (const float*)gamma, (const float*)mean, (const float*)rstd, (const float*)resid_grad,
-             (float*)dx, (bf16_t*)dxm_hi, (size_t)dxm_lo_off, scale, thr, key, (float*)partials, rows, D);
+             (float*)dx, (bf16_t*)dxm_hi, (size_t)dxm_lo_off, scale, thr, key, (float*)partials, rows, D, mode, eps);
   return lr2_launch_status(__func__);
 }
 

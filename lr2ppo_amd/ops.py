@@ -31,6 +31,15 @@ def get_gemm_passes() -> int:
 _PROF = None
 _PROF_ONLY = None
 
+# Bumped whenever a kernel of this package writes parameters through raw pointers (the optimizer): caches of derived
+# data (weight planes) compare it next to torch's own tensor version counters, which such writes do not advance.
+PARAM_EPOCH = 0
+
+
+def bump_param_epoch():
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
+
 
 def profile_start(only=None):
     """Start collecting (start, end) HIP events per kernel signature; see profile_stop().  `only`: a collection of
@@ -134,6 +143,15 @@ def split_planes(src: torch.Tensor, dst: Planes):
     _chk_f32(src)
     n = src.numel()
     _nat.check(_nat.lib().lr2_split_planes(src.data_ptr(), dst.data_ptr(), dst.lo_off, n, _stream()), "lr2_split_planes")
+    return dst
+
+
+def dropout_planes(src: torch.Tensor, dst: Planes, drop: Optional[Drop]):
+    """dst = planes of dropout_mask(src) / (1 - p) (drop None / p = 0: plain split)."""
+    _chk_f32(src)
+    p, seed, site = (drop.p, drop.seed, drop.site) if drop is not None else (0.0, 0, 0)
+    _nat.check(_nat.lib().lr2_dropout_planes(src.data_ptr(), dst.data_ptr(), dst.lo_off, src.numel(), p, seed, site, _stream()),
+               "lr2_dropout_planes")
     return dst
 
 
@@ -255,8 +273,10 @@ def layernorm_fwd(x, gamma, beta, out, mean=None, rstd=None, *, rows, D, eps=1e-
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partials, dgamma, dbeta, *, rows, D, group=0, group_stride=0,
-                  resid_grad=None, dx_planes: Optional[Planes] = None, drop: Optional[Drop] = None, nblocks=256):
-    """dx (fp32) = LN'(dy) + resid_grad; dx_planes = planes of dropout_mask(dx)/(1-p) (p = 0: of dx)."""
+                  resid_grad=None, dx_planes: Optional[Planes] = None, drop: Optional[Drop] = None, nblocks=256, mode=0,
+                  eps=1e-5):
+    """dx (fp32) = LN'(dy) + resid_grad; dx_planes = planes of dropout_mask(dx)/(1-p) (p = 0: of dx).
+    mode / eps: the forward's (0 = nn.LayerNorm, 1 = TencentPretrain LayerNorm)."""
     _chk_f32(dy, x, gamma, mean, rstd, dx, partials, dgamma, dbeta, resid_grad)
     nb = min(nblocks, (rows + 3) // 4)
     if partials.numel() < nb * 2 * D:
@@ -267,7 +287,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partials, dgamma, dbeta, *, rows
                              rstd.data_ptr(), _ptr(resid_grad), _ptr(dx),
                              dx_planes.data_ptr() if dx_planes is not None else None,
                              dx_planes.lo_off if dx_planes is not None else 0, p, seed, site,
-                             partials.data_ptr(), nb, rows, D, _stream())
+                             partials.data_ptr(), nb, rows, D, mode, eps, _stream())
     _nat.check(rc, "lr2_layernorm_bwd")
     _nat.check(L.lr2_colsum_partials_finish(partials.data_ptr(), nb, D, 2 * D, dgamma.data_ptr(), 0, _stream()), "finish")
     _nat.check(L.lr2_colsum_partials_finish(partials.data_ptr() + 4 * D, nb, D, 2 * D, dbeta.data_ptr(), 0, _stream()),

@@ -8,14 +8,16 @@ Per layer: ONE fused QKV GEMM (N = 3*hidden, weights concatenated once), the MFM
 projection (+residual), FFN1 (+GELU), FFN2 (+residual) and 2 wavefront LayerNorms.  Everything a GEMM consumes travels as
 bf16 hi/lo planes written by the producing kernel (LayerNorm, attention, GEMM epilogue) and is streamed by LDS-DMA; the
 residual stream stays fp32.  Weight planes are split once and re-split only when a parameter changes.
-Training through the encoders (dropout + backward) is not part of this round: the reference never trains them either
-(features are pre-extracted)."""
+With autograd enabled (train mode or parameters that require grad) the same kernels run a saving schedule and a
+hand-written backward (`_EncoderFn`): MFMA attention backward with recomputed probabilities, TencentPretrain-LayerNorm
+backward, dgrad / wgrad GEMMs with fused GELU' and residual epilogues, dropout at the reference's three sites per layer
+(attention probabilities, dropout_1, dropout_2) from the counter-based mask stream of lr2ppo_amd.runtime."""
 import math
 
 import torch
 import torch.nn as nn
 
-from ... import engine, ops
+from ... import engine, ops, runtime
 from ..layers.layer_norm import LayerNorm
 from ..layers.transformer import TransformerLayer
 
@@ -37,10 +39,12 @@ class TransformerEncoder(nn.Module):
         self._ws = None
         self._wplanes = None
 
-    def _weight_planes(self, dev):
-        """Per layer: (Wqkv planes [3E, E], bqkv [3E], Wo, W1, W2 planes); rebuilt when any parameter was written."""
-        sig = tuple(p._version for p in self.parameters()) + (str(dev),)
-        if self._wplanes is not None and self._wplanes[0] == sig:
+    def _weight_planes(self, dev, cache=True):
+        """Per layer: (Wqkv planes [3E, E], bqkv [3E], Wo, W1, W2 planes); rebuilt when any parameter was written
+        (torch's version counters + ops.PARAM_EPOCH, which the HIP optimizer bumps: its kernels write through raw
+        pointers).  cache=False (training): always re-split."""
+        sig = tuple(p._version for p in self.parameters()) + (str(dev), ops.PARAM_EPOCH)
+        if cache and self._wplanes is not None and self._wplanes[0] == sig:
             return self._wplanes[1]
         out = []
         for layer in self.transformer:
@@ -57,12 +61,19 @@ class TransformerEncoder(nn.Module):
         self._wplanes = (sig, out)
         return out
 
-    @torch.no_grad()
     def forward(self, emb, seg):
-        if self.training and any(l.dropout_1.p > 0 for l in self.transformer):
-            raise NotImplementedError("encoder training (dropout/backward) is outside this round's scope; call .eval()")
         if emb.dtype != torch.float32 or not emb.is_cuda:
             raise TypeError("lr2ppo_amd: emb must be a float32 tensor on the HIP device (no CPU path)")
+        needs_grad = torch.is_grad_enabled() and (emb.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            return _EncoderFn.apply(self, emb, seg, *list(self.parameters()))
+        if self.training and any(l.dropout_1.p > 0 for l in self.transformer):
+            out, _ = self._forward_train(emb, seg)       # dropout without a graph (torch.no_grad() in train mode)
+            return out
+        return self._forward_infer(emb, seg)
+
+    @torch.no_grad()
+    def _forward_infer(self, emb, seg):
         B, L, E = emb.shape
         H, hd = self.heads_num, E // self.heads_num
         M = B * L
@@ -104,3 +115,171 @@ class TransformerEncoder(nn.Module):
         else:
             out.view(M, E).copy_(h)
         return out
+
+    # ---- training schedule: same kernels, activations kept for the backward -------------------------------------
+    def _dims(self, emb):
+        B, L, E = emb.shape
+        return B, L, E, self.heads_num, E // self.heads_num, B * L, self.transformer[0].feed_forward.linear_1.out_features
+
+    @torch.no_grad()
+    def _forward_train(self, emb, seg):
+        B, L, E, H, hd, M, F = self._dims(emb)
+        dev = emb.device
+        if self._ws is None or self._ws.device != dev:
+            self._ws = engine.Workspace(dev)
+        ws = self._ws                                                   # split-K / reduction scratch only
+        seg = seg.to(device=dev, dtype=torch.int64).contiguous().view(-1)
+        W = self._weight_planes(dev, cache=False)
+        p = float(self.transformer[0].dropout_1.p) if self.training else 0.0
+        seed = runtime.next_drop(p, 0).seed if p > 0 else 0
+        drop = (lambda site: ops.Drop(p, seed, site)) if p > 0 else (lambda site: None)
+        mat = lambda r, c: torch.empty(r, c, device=dev)                # noqa: E731
+        vec = lambda n: torch.empty(n, device=dev)                      # noqa: E731
+        pl = lambda r, c: ops.Planes.empty(r, c, dev)                   # noqa: E731
+        pre = self.layernorm_positioning == "pre"
+        scale = 1.0 / math.sqrt(float(hd))
+        h = emb.detach().contiguous().view(M, E)
+        h_p = None
+        if not pre:
+            h_p = ops.split_planes(h, pl(M, E))
+        saved = {"layers": [], "seg": seg, "dims": (B, L, E, H, hd, M, F), "drop": (p, seed), "W": W}
+        for i, (layer, w) in enumerate(zip(self.transformer, W)):
+            att, ffn = layer.self_attn, layer.feed_forward
+            ln1, ln2 = layer.layer_norm_1, layer.layer_norm_2
+            s0 = 4 * i
+            S = {}
+            if pre:
+                x_p, S["m1"], S["r1"], S["h_in"] = pl(M, E), vec(M), vec(M), h
+                ops.layernorm_fwd(h, ln1.gamma.data, ln1.beta.data, None, S["m1"], S["r1"], rows=M, D=E, eps=ln1.eps, mode=1,
+                                  out_planes=x_p)
+            else:
+                x_p = h_p
+            qkv_p, o_p, t1 = pl(M, 3 * E), pl(M, E), mat(M, E)
+            engine.linear_fwd(ws, x_p, w["wqkv"], w["bqkv"], None, M, 3 * E, E, out_planes=qkv_p)
+            ops.self_attn_fwd(qkv_p, seg, o_p, batch=B, heads=H, L=L, head_dim=hd, scale=scale, drop=drop(s0))
+            engine.linear_fwd(ws, o_p, w["wo"], att.final_linear.bias.data, t1, M, E, E, resid=h, drop=drop(s0 + 1))
+            z, ff_p = mat(M, F), pl(M, F)
+            S.update(x_p=x_p, qkv_p=qkv_p, o_p=o_p, t1=t1, z=z, ff_p=ff_p)
+            if pre:
+                x2_p, S["m2"], S["r2"] = pl(M, E), vec(M), vec(M)
+                ops.layernorm_fwd(t1, ln2.gamma.data, ln2.beta.data, None, S["m2"], S["r2"], rows=M, D=E, eps=ln2.eps, mode=1,
+                                  out_planes=x2_p)
+                engine.linear_fwd(ws, x2_p, w["w1"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_z=z, out_planes=ff_p)
+                hn = mat(M, E)
+                engine.linear_fwd(ws, ff_p, w["w2"], ffn.linear_2.bias.data, hn, M, E, F, resid=t1, drop=drop(s0 + 2))
+                S["x2_p"] = x2_p
+                h = hn
+            else:
+                inter, inter_p, S["m1"], S["r1"] = mat(M, E), pl(M, E), vec(M), vec(M)
+                ops.layernorm_fwd(t1, ln1.gamma.data, ln1.beta.data, inter, S["m1"], S["r1"], rows=M, D=E, eps=ln1.eps, mode=1,
+                                  out_planes=inter_p)
+                engine.linear_fwd(ws, inter_p, w["w1"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_z=z, out_planes=ff_p)
+                t2 = mat(M, E)
+                engine.linear_fwd(ws, ff_p, w["w2"], ffn.linear_2.bias.data, t2, M, E, F, resid=inter, drop=drop(s0 + 2))
+                hn, hn_p, S["m2"], S["r2"] = mat(M, E), pl(M, E), vec(M), vec(M)
+                ops.layernorm_fwd(t2, ln2.gamma.data, ln2.beta.data, hn, S["m2"], S["r2"], rows=M, D=E, eps=ln2.eps, mode=1,
+                                  out_planes=hn_p)
+                S.update(inter_p=inter_p, t2=t2)
+                h, h_p = hn, hn_p
+            saved["layers"].append(S)
+        if pre:
+            out = torch.empty(B, L, E, device=dev)
+            saved["h_final"], saved["mf"], saved["rf"] = h, vec(M), vec(M)
+            ops.layernorm_fwd(h, self.layer_norm.gamma.data, self.layer_norm.beta.data, out.view(M, E), saved["mf"], saved["rf"],
+                              rows=M, D=E, eps=self.layer_norm.eps, mode=1)
+        else:
+            out = h.view(B, L, E)
+        return out, saved
+
+    @torch.no_grad()
+    def _backward_train(self, saved, dout):
+        """-> (d emb [B, L, E], {parameter: gradient}) for the forward that produced `saved`."""
+        B, L, E, H, hd, M, F = saved["dims"]
+        dev, seg, W = dout.device, saved["seg"], saved["W"]
+        ws = self._ws
+        p, seed = saved["drop"]
+        drop = (lambda site: ops.Drop(p, seed, site)) if p > 0 else (lambda site: None)
+        mat = lambda r, c: torch.empty(r, c, device=dev)                # noqa: E731
+        pl = lambda r, c: ops.Planes.empty(r, c, dev)                   # noqa: E731
+        params = list(self.parameters())
+        flat = torch.empty(sum(q.numel() for q in params), device=dev)
+        G, off = {}, 0
+        for q in params:
+            G[q] = flat[off:off + q.numel()].view_as(q)
+            off += q.numel()
+        partials = ws.vec("ln_partials", 256 * 2 * E)
+        lse_ws, dsum_ws = ws.vec("attn_lse", B * H * L), ws.vec("attn_dsum", B * H * L)
+        dwqkv, dbqkv = ws.mat("dwqkv", 3 * E, E), ws.vec("dbqkv", 3 * E)
+        pre = self.layernorm_positioning == "pre"
+        scale = 1.0 / math.sqrt(float(hd))
+        dh = dout.contiguous().view(M, E)
+        if pre:
+            ln = self.layer_norm
+            dnew = mat(M, E)
+            ops.layernorm_bwd(dh, saved["h_final"], ln.gamma.data, saved["mf"], saved["rf"], dnew, partials, G[ln.gamma],
+                              G[ln.beta], rows=M, D=E, mode=1, eps=ln.eps)
+            dh = dnew
+        for i in reversed(range(self.layers_num)):
+            layer, w, S = self.transformer[i], W[i], saved["layers"][i]
+            att, ffn = layer.self_attn, layer.feed_forward
+            ln1, ln2 = layer.layer_norm_1, layer.layer_norm_2
+            s0 = 4 * i
+            dff_p, dz_p = pl(M, E), pl(M, F)
+            if pre:
+                ops.dropout_planes(dh, dff_p, drop(s0 + 2))
+                ffn_in_p = S["x2_p"]
+            else:
+                d_t2 = mat(M, E)
+                ops.layernorm_bwd(dh, S["t2"], ln2.gamma.data, S["m2"], S["r2"], d_t2, partials, G[ln2.gamma], G[ln2.beta],
+                                  rows=M, D=E, dx_planes=dff_p, drop=drop(s0 + 2), mode=1, eps=ln2.eps)
+                ffn_in_p = S["inter_p"]
+            engine.linear_wgrad(ws, dff_p, S["ff_p"], G[ffn.linear_2.weight], G[ffn.linear_2.bias], M, F, E)
+            engine.linear_dgrad(ws, dff_p, w["w2"], None, M, F, E, act=2, aux_z=S["z"], out_planes=dz_p)
+            engine.linear_wgrad(ws, dz_p, ffn_in_p, G[ffn.linear_1.weight], G[ffn.linear_1.bias], M, E, F)
+            d_t1, dao_p = mat(M, E), pl(M, E)
+            if pre:
+                d_x2 = mat(M, E)
+                engine.linear_dgrad(ws, dz_p, w["w1"], d_x2, M, E, F)
+                ops.layernorm_bwd(d_x2, S["t1"], ln2.gamma.data, S["m2"], S["r2"], d_t1, partials, G[ln2.gamma], G[ln2.beta],
+                                  rows=M, D=E, resid_grad=dh, dx_planes=dao_p, drop=drop(s0 + 1), mode=1, eps=ln2.eps)
+            else:
+                d_inter = mat(M, E)
+                engine.linear_dgrad(ws, dz_p, w["w1"], d_inter, M, E, F, resid=d_t2)
+                ops.layernorm_bwd(d_inter, S["t1"], ln1.gamma.data, S["m1"], S["r1"], d_t1, partials, G[ln1.gamma], G[ln1.beta],
+                                  rows=M, D=E, dx_planes=dao_p, drop=drop(s0 + 1), mode=1, eps=ln1.eps)
+            engine.linear_wgrad(ws, dao_p, S["o_p"], G[att.final_linear.weight], G[att.final_linear.bias], M, E, E)
+            do_p, dqkv_p = pl(M, E), pl(M, 3 * E)
+            engine.linear_dgrad(ws, dao_p, w["wo"], None, M, E, E, out_planes=do_p)
+            ops.self_attn_bwd(S["qkv_p"], do_p, seg, dqkv_p, lse_ws, dsum_ws, batch=B, heads=H, L=L, head_dim=hd, scale=scale,
+                              drop=drop(s0))
+            engine.linear_wgrad(ws, dqkv_p, S["x_p"], dwqkv, dbqkv, M, E, 3 * E)
+            for j in range(3):
+                G[att.linear_layers[j].weight].copy_(dwqkv[j * E:(j + 1) * E])
+                G[att.linear_layers[j].bias].copy_(dbqkv[j * E:(j + 1) * E])
+            dprev = mat(M, E)
+            if pre:
+                d_x1 = mat(M, E)
+                engine.linear_dgrad(ws, dqkv_p, w["wqkv"], d_x1, M, E, 3 * E)
+                ops.layernorm_bwd(d_x1, S["h_in"], ln1.gamma.data, S["m1"], S["r1"], dprev, partials, G[ln1.gamma], G[ln1.beta],
+                                  rows=M, D=E, resid_grad=d_t1, mode=1, eps=ln1.eps)
+            else:
+                engine.linear_dgrad(ws, dqkv_p, w["wqkv"], dprev, M, E, 3 * E, resid=d_t1)
+            dh = dprev
+            saved["layers"][i] = None                                   # release this layer's activations
+        return dh.view(B, L, E), G
+
+
+class _EncoderFn(torch.autograd.Function):
+    """Coarse autograd node: the whole encoder stack forward / backward on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, enc, emb, seg, *params):
+        out, saved = enc._forward_train(emb, seg)
+        ctx.enc, ctx.saved = enc, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        demb, G = ctx.enc._backward_train(ctx.saved, dout.contiguous())
+        ctx.saved = None
+        return (None, demb, None) + tuple(G[q] if q.requires_grad else None for q in ctx.enc.parameters())

@@ -121,6 +121,7 @@ class AdamW(Optimizer):
                     raise NotImplementedError("correct_bias=True with weight decay is not used by LR2PPO")
             ops.adamw_multi(table, n, step_size, beta1, beta2, group["eps"], n_params=n_params)
         self._external.clear()
+        ops.bump_param_epoch()
         return loss
 
 

@@ -443,6 +443,34 @@ def gen_encoder_small():
     _save("encoder_small.npz", **arrays)
 
 
+def gen_encoder_bwd():
+    """Backward of the reference TransformerEncoder (autograd, eval mode = dropout off) on a 2-layer stack with heads of
+    64 (the head size of ViT-B/16 and RoBERTa-base): output, input gradient and every parameter gradient of
+    sum(out * wout), both LayerNorm placements, padded `seg`."""
+    from tencentpretrain.encoders import str2encoder
+    arrays = {}
+    for tag in ("post", "pre"):
+        a = _encoder_args("models/xlm-roberta/base_config.json", hidden_size=128, emb_size=128, feedforward_size=256,
+                          heads_num=2, layers_num=2, layernorm_positioning=tag, dropout=0.1)
+        enc = str2encoder["transformer"](a).eval()
+        spec = [(n, tuple(p.shape)) for n, p in enc.named_parameters()]
+        assert spec == O.encoder_param_spec(2, 128, 256, tag == "pre"), tag
+        params = O.seeded_params(spec, seed=51, std=0.15, skip_gamma_beta=False)
+        enc.load_state_dict(params, strict=True)
+        g = torch.Generator().manual_seed(52)
+        emb = torch.randn(3, 50, 128, generator=g).requires_grad_(True)
+        wout = torch.randn(3, 50, 128, generator=g)
+        seg = torch.ones(3, 50, dtype=torch.long)
+        seg[1, 33:] = 0
+        seg[2, 7:] = 0
+        out = enc(emb, seg)
+        (out * wout).sum().backward()
+        arrays[f"{tag}_out"], arrays[f"{tag}_demb"] = out.detach(), emb.grad.detach()
+        for n, p_ in enc.named_parameters():
+            arrays[f"{tag}_grad.{n}"] = p_.grad.detach()
+    _save("encoder_bwd_small.npz", **arrays)
+
+
 def gen_embeddings_small():
     from tencentpretrain.embeddings import Embedding, str2embedding
     arrays = {}
@@ -537,7 +565,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -384,24 +384,28 @@ def encoder_param_spec(layers: int, hidden: int, ff: int, pre_ln: bool, prefix: 
     return spec
 
 
-def tp_attention(P: Params, prefix: str, h: torch.Tensor, mask: torch.Tensor, heads: int):
+def tp_attention(P: Params, prefix: str, h: torch.Tensor, mask: torch.Tensor, heads: int, drop=None, site: int = 0):
     """MultiHeadedAttention.forward (layers/multi_headed_attn.py:27-76): linear_layers[0,1,2] =
-    Q,K,V; scores / sqrt(d) THEN + mask(-10000)."""
+    Q,K,V; scores / sqrt(d) THEN + mask(-10000); dropout on the probabilities (:72), mask indexed over [b, heads, L, L]."""
     b, L, e = h.shape
     d = e // heads
     q = linear(P, prefix + ".linear_layers.0", h).view(b, L, heads, d).transpose(1, 2)
     k = linear(P, prefix + ".linear_layers.1", h).view(b, L, heads, d).transpose(1, 2)
     v = linear(P, prefix + ".linear_layers.2", h).view(b, L, heads, d).transpose(1, 2)
     s = (q @ k.transpose(-2, -1)) / math.sqrt(float(d)) + mask
-    p = torch.softmax(s, dim=-1)
+    p = _apply_dropout(torch.softmax(s, dim=-1), drop, site)
     o = (p @ v).transpose(1, 2).contiguous().view(b, L, e)
     return linear(P, prefix + ".final_linear", o)
 
 
+ENC_SITES_PER_LAYER = 4    # dropout sites of layer i: 4i (attention probabilities), 4i+1 (dropout_1), 4i+2 (dropout_2)
+
+
 def transformer_encoder(P: Params, emb: torch.Tensor, seg: torch.Tensor, layers: int, heads: int,
-                        pre_ln: bool, prefix: str = "") -> torch.Tensor:
+                        pre_ln: bool, prefix: str = "", drop=None) -> torch.Tensor:
     """TransformerEncoder.forward with mask='fully_visible' (encoders/transformer_encoder.py:48-138,
-    layers/transformer.py:50-73), dropout off."""
+    layers/transformer.py:50-73).  drop = {"p", "seed", "site_base"}: train-mode dropout with the counter-based masks of
+    the HIP path (three sites per layer, see ENC_SITES_PER_LAYER); None = dropout off."""
     b, L, _ = emb.shape
     mask = (seg > 0).unsqueeze(1).repeat(1, L, 1).unsqueeze(1).float()
     mask = (1.0 - mask) * -10000.0
@@ -410,15 +414,18 @@ def transformer_encoder(P: Params, emb: torch.Tensor, seg: torch.Tensor, layers:
         t = f"{prefix}transformer.{i}"
         g1, b1 = P[f"{t}.layer_norm_1.gamma"], P[f"{t}.layer_norm_1.beta"]
         g2, b2 = P[f"{t}.layer_norm_2.gamma"], P[f"{t}.layer_norm_2.beta"]
+        s0 = ENC_SITES_PER_LAYER * i
         if not pre_ln:
-            inter = layernorm_tp(tp_attention(P, f"{t}.self_attn", h, mask, heads) + h, g1, b1)
+            att = _apply_dropout(tp_attention(P, f"{t}.self_attn", h, mask, heads, drop, s0), drop, s0 + 1)
+            inter = layernorm_tp(att + h, g1, b1)
             ffn = linear(P, f"{t}.feed_forward.linear_2", gelu_erf(linear(P, f"{t}.feed_forward.linear_1", inter)))
-            h = layernorm_tp(ffn + inter, g2, b2)
+            h = layernorm_tp(_apply_dropout(ffn, drop, s0 + 2) + inter, g2, b2)
         else:
             inter = layernorm_tp(h, g1, b1)
-            h = h + tp_attention(P, f"{t}.self_attn", inter, mask, heads)
+            h = h + _apply_dropout(tp_attention(P, f"{t}.self_attn", inter, mask, heads, drop, s0), drop, s0 + 1)
             o = layernorm_tp(h, g2, b2)
-            h = linear(P, f"{t}.feed_forward.linear_2", gelu_erf(linear(P, f"{t}.feed_forward.linear_1", o))) + h
+            ffn = linear(P, f"{t}.feed_forward.linear_2", gelu_erf(linear(P, f"{t}.feed_forward.linear_1", o)))
+            h = _apply_dropout(ffn, drop, s0 + 2) + h
     if pre_ln:
         h = layernorm_tp(h, P[f"{prefix}layer_norm.gamma"], P[f"{prefix}layer_norm.beta"])
     return h

@@ -110,3 +110,73 @@ def test_oracle_encoder_small_on_device_gemm_path(dev):
     emb = emb.to(dev).eval()
     out = emb(g["txt_src"].to(dev), g["txt_seg"].to(dev))
     assert _err(out, g["txt_out"]) < 2e-5
+
+
+def _small64(tag, dropout):
+    return _args(**{**ROBERTA, "hidden_size": 128, "emb_size": 128, "feedforward_size": 256, "heads_num": 2, "layers_num": 2,
+                    "layernorm_positioning": tag, "dropout": dropout})
+
+
+def _bwd_case():
+    g = torch.Generator().manual_seed(52)
+    emb = torch.randn(3, 50, 128, generator=g)
+    wout = torch.randn(3, 50, 128, generator=g)
+    seg = torch.ones(3, 50, dtype=torch.long)
+    seg[1, 33:] = 0
+    seg[2, 7:] = 0
+    return emb, wout, seg
+
+
+def _cmp(got, ref, what, rel=1e-3):
+    err = _err(got, ref)
+    assert err < 1e-5 + rel * float(ref.abs().max()), f"{what}: {err} vs scale {float(ref.abs().max())}"
+
+
+@pytest.mark.parametrize("tag", ["post", "pre"])
+def test_encoder_backward_matches_reference_golden(dev, tag):
+    """A14 backward (eval mode, dropout off): output, input gradient and every parameter gradient of the 2-layer stack
+    with 64-wide heads against the reference's own autograd (tests/golden/encoder_bwd_small.npz)."""
+    from lr2ppo_amd.tencentpretrain.encoders import str2encoder
+    g = load_golden("encoder_bwd_small.npz")
+    enc = str2encoder["transformer"](_small64(tag, 0.1))
+    P = O.seeded_params(O.encoder_param_spec(2, 128, 256, tag == "pre"), seed=51, std=0.15, skip_gamma_beta=False)
+    enc.load_state_dict(P, strict=True)
+    enc = enc.to(dev).eval()
+    emb, wout, seg = _bwd_case()
+    e = emb.to(dev).requires_grad_(True)
+    out = enc(e, seg.to(dev))
+    (out * wout.to(dev)).sum().backward()
+    _cmp(out, g[f"{tag}_out"], "out", rel=1e-4)
+    _cmp(e.grad, g[f"{tag}_demb"], "d emb")
+    for n, p in enc.named_parameters():
+        _cmp(p.grad, g[f"{tag}_grad.{n}"], n)
+    with torch.no_grad():                                  # the inference schedule gives the same output
+        _cmp(enc(emb.to(dev), seg.to(dev)), g[f"{tag}_out"], "inference out", rel=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["post", "pre"])
+def test_encoder_train_mode_dropout_matches_oracle(dev, tag):
+    """Train mode: dropout 0.1 on attention probabilities, dropout_1 and dropout_2 of every layer from the pinned
+    counter-based mask stream -- forward and all gradients against the oracle's autograd with the same masks."""
+    from lr2ppo_amd import runtime
+    from lr2ppo_amd.tencentpretrain.encoders import str2encoder
+    enc = str2encoder["transformer"](_small64(tag, 0.1))
+    P = O.seeded_params(O.encoder_param_spec(2, 128, 256, tag == "pre"), seed=51, std=0.15, skip_gamma_beta=False)
+    enc.load_state_dict(P, strict=True)
+    enc = enc.to(dev).train()
+    emb, wout, seg = _bwd_case()
+    runtime.set_dropout_seed(777, calls=2)
+    seed = runtime.peek_drop_seed()
+    e = emb.to(dev).requires_grad_(True)
+    out = enc(e, seg.to(dev))
+    (out * wout.to(dev)).sum().backward()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    eo = emb.clone().requires_grad_(True)
+    ref = O.transformer_encoder(Pg, eo, seg, 2, 2, tag == "pre", drop={"p": 0.1, "seed": seed, "site_base": 0})
+    (ref * wout).sum().backward()
+    _cmp(out, ref.detach(), "out", rel=1e-4)
+    _cmp(e.grad, eo.grad, "d emb")
+    for n, p in enc.named_parameters():
+        _cmp(p.grad, Pg[n].grad, n)
+    out2 = enc(e, seg.to(dev))                             # the mask stream advances: a second forward differs
+    assert not torch.equal(out2, out)

@@ -227,3 +227,31 @@ def test_stage2_get_index_restatement():
     for c in cases:
         ch, rj = O.pair_index(c["targets"], c["order"])
         assert ch == c["chosen"] and rj == c["reject"], c
+
+
+def _enc_bwd_case(tag):
+    spec = O.encoder_param_spec(2, 128, 256, tag == "pre")
+    P = O.seeded_params(spec, seed=51, std=0.15, skip_gamma_beta=False)
+    g = torch.Generator().manual_seed(52)
+    emb = torch.randn(3, 50, 128, generator=g)
+    wout = torch.randn(3, 50, 128, generator=g)
+    seg = torch.ones(3, 50, dtype=torch.long)
+    seg[1, 33:] = 0
+    seg[2, 7:] = 0
+    return P, emb, wout, seg
+
+
+@pytest.mark.parametrize("tag", ["post", "pre"])
+def test_encoder_backward_oracle_matches_reference_autograd(tag):
+    """A14 backward: the oracle's encoder under torch autograd against gradients frozen from the reference's own modules."""
+    g = load_golden("encoder_bwd_small.npz")
+    P, emb, wout, seg = _enc_bwd_case(tag)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    e = emb.clone().requires_grad_(True)
+    out = O.transformer_encoder(Pg, e, seg, 2, 2, tag == "pre")
+    (out * wout).sum().backward()
+    assert (out - g[f"{tag}_out"]).abs().max() < 2e-5
+    assert (e.grad - g[f"{tag}_demb"]).abs().max() < 2e-5 * max(1.0, float(g[f"{tag}_demb"].abs().max()))
+    for k in P:
+        ref = g[f"{tag}_grad.{k}"]
+        assert (Pg[k].grad - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max())), k
