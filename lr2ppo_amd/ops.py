@@ -178,11 +178,14 @@ def choose_tiling(M: int, N: int, K: int, trans_a: bool, trans_b: bool = False):
     that skinny GEMMs fill the chip without wave-quantisation tails (576 workgroups on 512 slots = 2 rounds)."""
     bm = 64 if (M <= 64 and not trans_a) else 128
     tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
-    if bm == 128 and not trans_a and not trans_b and (512 < tiles < 1536 or (256 < tiles <= 512 and K < 1536)):
-        # NT with fewer than three rounds of 128-row tiles (512 resident workgroups): the part-empty last round costs more
-        # than the lower intensity of 64-row tiles.  Measured with tools/gemm_bench.py: M=12544 N=768 (588 tiles) +9..11 %,
-        # M=6304 N=768 K=768 (300) +17 %, M=6304 N=3072 (1200) +17 %; M=12544 N=3072 (2352 tiles) is 10 % faster at 128.
-        return 64, 1
+    if bm == 128 and not trans_a and not trans_b and tiles < 1536:
+        # NT with fewer than three rounds of 128-row tiles (512 resident workgroups): when the last round is poorly filled
+        # it costs more than the lower intensity of 64-row tiles.  Measured with tools/gemm_bench.py: M=12544 N=768
+        # (588 tiles) +9..15 %, M=6304 N=768 K=768 (300) +17 %, M=6304 N=3072 (1200) +17 %; full rounds (4096^3: 1024
+        # tiles) and M=12544 N=3072 (2352) are 10-25 % faster with 128-row tiles.
+        last = tiles % 512
+        if (tiles > 512 and 0 < last <= 400) or (256 < tiles <= 512 and K < 1536):
+            return 64, 1
     k_tiles = (K + 63) // 64
     slots = 768 if bm == 64 else 512
     if tiles >= slots or k_tiles < 8:
