@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--fuse-fc1", type=int, default=1, choices=[0, 1],
                     help="1: AdamW step of out_layer.fc1.weight inside its weight-gradient GEMM (default); 0: separate passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-encoder", action="store_true",
+                    help="skip the dual-encoder forward measurement reported under config.dual_encoder_forward")
     ap.add_argument("--cpu-batch", type=int, default=4, help="batch of the CPU-baseline sample")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     return ap.parse_args()
@@ -194,6 +196,14 @@ def main():
         out["roofline"]["top_ms_per_step"] = top
         out["roofline"]["timed_kernels_ms_per_step"] = round(timed_all, 3)
         out["roofline"]["host_enqueue_ms_per_step"] = round(t_host / a.steps * 1e3, 3)
+    # ---- dual-encoder forward at this step's feature-extraction shapes (north_star's MFMA-utilisation figure) ----
+    # Not part of `value`: the reference's PPO loop reads pre-extracted features (finetune/ppo.py:115-148); reported so
+    # that the encoder number travels with the bench line.  ViT-B/16 over batch*16 frames, RoBERTa-base over batch*tags.
+    if world == 1 and not a.no_encoder:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import encoder_bench
+        torch.cuda.empty_cache()
+        out["config"]["dual_encoder_forward"] = encoder_bench.measure_forward(a.batch, a.tags, 16, iters=3, passes=a.passes, dev=dev)
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
     if world == 1 and not a.no_cpu_baseline:
         del model, reward, opt, copt, data

@@ -46,8 +46,8 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* plane, int row_a, int ro
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int NT>   // NT = key tiles of 16 (even); LP = 16 * NT padded keys
-__global__ __launch_bounds__(256) void self_attn_mfma_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
+template <int NT, int NW>   // NT = key tiles of 16 (even), LP = 16 * NT padded keys; NW = waves per workgroup
+__global__ __launch_bounds__(64 * NW) void self_attn_mfma_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
                                                              const bf16_t* __restrict__ Vh, size_t lo_off, int ld,
                                                              const int64_t* __restrict__ seg, float* __restrict__ O,
                                                              bf16_t* __restrict__ Oh, size_t o_lo_off, int ld_o, int heads,
@@ -58,14 +58,14 @@ __global__ __launch_bounds__(256) void self_attn_mfma_kernel(const bf16_t* __res
   char* sK = smem;                    // [hi | lo]
   char* sV = smem + 2 * PLANE;        // [hi | lo]
   float* sMask = reinterpret_cast<float*>(smem + 4 * PLANE);          // [LP]
-  float* sOut = sMask + LP;                                          // [4 waves][16][HD + 4]
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  float* sOut = sMask + LP;                                          // [NW waves][16][HD + 4]
+  const int h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t row0 = (size_t)b * L;
   const int col0 = h * HD;
 
   // ---- stage K, V (both planes) and the additive key mask ----
-  for (int i = tid; i < LP * 8; i += 256) {
+  for (int i = tid; i < LP * 8; i += 64 * NW) {
     const int r = i >> 3, u = i & 7;
     u32x4_t kh = {0, 0, 0, 0}, kl = kh, vh = kh, vl = kh;
     if (r < L) {
@@ -80,11 +80,15 @@ __global__ __launch_bounds__(256) void self_attn_mfma_kernel(const bf16_t* __res
     *reinterpret_cast<u32x4_t*>(sV + v_off(r, u)) = vh;
     *reinterpret_cast<u32x4_t*>(sV + PLANE + v_off(r, u)) = vl;
   }
-  for (int j = tid; j < LP; j += 256) sMask[j] = j < L ? ((seg[row0 + j] > 0) ? 0.f : -10000.0f) : -INFINITY;
+  for (int j = tid; j < LP; j += 64 * NW) sMask[j] = j < L ? ((seg[row0 + j] > 0) ? 0.f : -10000.0f) : -INFINITY;
 
-  // ---- this wave's 16 query rows as B fragments of S^T = K Q^T (lane: query l & 15, hd 8*(l >> 4) + 32*ks ..) ----
+  __syncthreads();
+  // K / V stay resident; each wave walks over 16-query sub-tiles (blockIdx.x strides them when the grid splits the queries)
   const int qn = lane & 15, g = lane >> 4;
-  const int q_row = qt * 64 + wave * 16 + qn;
+  const int n_sub = (L + 15) >> 4;
+  for (int sub = blockIdx.x * NW + wave; sub < n_sub; sub += gridDim.x * NW) {
+  // ---- this sub-tile's 16 query rows as B fragments of S^T = K Q^T (lane: query l & 15, hd 8*(l >> 4) + 32*ks ..) ----
+  const int q_row = sub * 16 + qn;
   bf16x8_t qh[2], ql[2];
   {
     const bool ok = q_row < L;
@@ -100,7 +104,6 @@ __global__ __launch_bounds__(256) void self_attn_mfma_kernel(const bf16_t* __res
       ql[ks] = __builtin_bit_cast(bf16x8_t, c);
     }
   }
-  __syncthreads();
 
   // ---- S^T tiles: acc[t][r] = S[query qn][key 16t + 4g + r] ----
   f32x4_t s[NT];
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256) void self_attn_mfma_kernel(const bf16_t* __res
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int r = pass * 4 + (lane >> 4), c = (lane & 15) * 4;
-    const int qr = qt * 64 + wave * 16 + r;
+    const int qr = sub * 16 + r;
     if (qr < L) {
       const float4 v = *reinterpret_cast<const float4*>(slab + r * (HD + 4) + c);
       const size_t off = (row0 + qr) * (size_t)ld_o + col0 + c;
@@ -206,6 +209,8 @@ __global__ __launch_bounds__(256) void self_attn_mfma_kernel(const bf16_t* __res
       if (Oh) store_planes4(Oh + off, o_lo_off, v);
     }
   }
+  __builtin_amdgcn_wave_barrier();
+  }  // sub-tile loop
 }
 
 // fp32 x 8 -> A fragment pair (hi, lo) of the split product
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dq_kernel(const bf16_t* __r
   char* sV = smem + 2 * PLANE;        // K layout too: V is an A operand here (rows = keys, contraction over hd)
   float* sMask = reinterpret_cast<float*>(smem + 4 * PLANE);
   float* sOut = sMask + LP;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t row0 = (size_t)b * L;
   const int col0 = h * HD;
@@ -311,12 +316,14 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dq_kernel(const bf16_t* __r
   }
   for (int j = tid; j < LP; j += 256) sMask[j] = j < L ? ((seg[row0 + j] > 0) ? 0.f : -10000.0f) : -INFINITY;
   const int qn = lane & 15, g = lane >> 4;
-  const int q_row = qt * 64 + wave * 16 + qn;
+  __syncthreads();
+  const int n_sub = (L + 15) >> 4;
+  for (int sub = blockIdx.x * 4 + wave; sub < n_sub; sub += gridDim.x * 4) {
+  const int q_row = sub * 16 + qn;
   const bool q_ok = q_row < L;
   bf16x8_t qh[2], ql[2], gh[2], gl[2];
   load_frags(Qh, lo_off, (row0 + (q_ok ? q_row : 0)) * (size_t)ld + col0 + 8 * g, q_ok, qh, ql);
   load_frags(dOh, do_lo_off, (row0 + (q_ok ? q_row : 0)) * (size_t)ld_do + col0 + 8 * g, q_ok, gh, gl);
-  __syncthreads();
 
   f32x4_t s[NT], dp[NT];
 #pragma unroll
@@ -396,8 +403,9 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dq_kernel(const bf16_t* __r
       o[n] = mfma3(eh, el, tr_pair_k(sK, ra, rb, unit, half8), tr_pair_k(sK + PLANE, ra, rb, unit, half8), o[n]);
     }
   }
-  store_tile_planes(o, sOut + wave * 16 * (HD + 4), lane, qt * 64 + wave * 16, L, dQh, dq_lo_off, (size_t)ld_dq,
+  store_tile_planes(o, sOut + wave * 16 * (HD + 4), lane, sub * 16, L, dQh, dq_lo_off, (size_t)ld_dq,
                     row0 * (size_t)ld_dq + col0);
+  }  // sub-tile loop
 }
 
 // ---- backward, part 2: dK, dV ------------------------------------------------------------------------------------------
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dkv_kernel(const bf16_t* __
   float* sLse = reinterpret_cast<float*>(smem + 4 * PLANE);   // [LP]
   float* sD = sLse + LP;                                      // [LP]
   float* sOut = sD + LP;
-  const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t row0 = (size_t)b * L;
   const int col0 = h * HD;
@@ -447,13 +455,15 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dkv_kernel(const bf16_t* __
     sD[j] = j < L ? dsum[si] : 0.f;
   }
   const int kn = lane & 15, g = lane >> 4;
-  const int key = kt * 64 + wave * 16 + kn;
+  __syncthreads();
+  const int n_sub = (L + 15) >> 4;
+  for (int sub = blockIdx.x * 4 + wave; sub < n_sub; sub += gridDim.x * 4) {
+  const int key = sub * 16 + kn;
   const bool k_ok = key < L;
   bf16x8_t kh[2], kl[2], vh[2], vl[2];
   load_frags(Kh, lo_off, (row0 + (k_ok ? key : 0)) * (size_t)ld + col0 + 8 * g, k_ok, kh, kl);
   load_frags(Vh, lo_off, (row0 + (k_ok ? key : 0)) * (size_t)ld + col0 + 8 * g, k_ok, vh, vl);
   const float kmask = k_ok ? ((seg[row0 + key] > 0) ? 0.f : -10000.0f) : -INFINITY;
-  __syncthreads();
 
   f32x4_t dv[4], dk[4];
 #pragma unroll
@@ -504,8 +514,9 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dkv_kernel(const bf16_t* __
     }
   }
   float* slab = sOut + wave * 16 * (HD + 4);
-  store_tile_planes(dk, slab, lane, kt * 64 + wave * 16, L, dKh, dkv_lo_off, (size_t)ld_dkv, row0 * (size_t)ld_dkv + col0);
-  store_tile_planes(dv, slab, lane, kt * 64 + wave * 16, L, dVh, dkv_lo_off, (size_t)ld_dkv, row0 * (size_t)ld_dkv + col0);
+  store_tile_planes(dk, slab, lane, sub * 16, L, dKh, dkv_lo_off, (size_t)ld_dkv, row0 * (size_t)ld_dkv + col0);
+  store_tile_planes(dv, slab, lane, sub * 16, L, dVh, dkv_lo_off, (size_t)ld_dkv, row0 * (size_t)ld_dkv + col0);
+  }  // sub-tile loop
 }
 
 static DropP make_drop(float p, uint64_t seed, uint32_t site) {
@@ -527,6 +538,15 @@ int allow_lds_once(Kern kern, size_t lds, bool& done, const char* what) {
   return 0;
 }
 
+// grid.x: how many workgroups share one (sequence, head).  One is best (K/V or Q/dO are staged once) as long as the grid
+// still fills the chip; small batches split the sub-tiles over up to 4 workgroups.
+static int attn_chunks(int batch, int heads, int L) {
+  const int n_sub = (L + 15) / 16, max_chunks = (n_sub + 3) / 4;
+  int c = (512 + batch * heads - 1) / (batch * heads);
+  if (c < 1) c = 1;
+  return c > max_chunks ? max_chunks : c;
+}
+
 struct AttnArgs {
   const bf16_t *q, *k, *v;
   size_t lo_off;
@@ -538,13 +558,19 @@ struct AttnArgs {
   hipStream_t stream;
 };
 
+// Forward: 8 waves per workgroup (2 per SIMD) hide the LDS-read latency of the dependent tile chains; the 256-key
+// variant keeps 4 (its K/V planes + 8 output slabs would not fit the 160 KiB of LDS).
 template <int NT>
 int launch_fwd(const AttnArgs& a, float* o, bf16_t* oh, size_t o_lo_off, int ld_o, float* lse) {
   constexpr int LP = 16 * NT;
-  const size_t lds = (size_t)4 * LP * ROW_B + (size_t)LP * 4 + (size_t)4 * 16 * (HD + 4) * 4;
+  constexpr int NW = NT <= 14 ? 8 : 4;
+  const size_t lds = (size_t)4 * LP * ROW_B + (size_t)LP * 4 + (size_t)NW * 16 * (HD + 4) * 4;
   static bool done = false;
-  if (allow_lds_once(self_attn_mfma_kernel<NT>, lds, done, "self_attn_fwd")) return LR2_ERR_LAUNCH;
-  LR2_LAUNCH(self_attn_mfma_kernel<NT>, dim3((a.L + 63) / 64, a.heads, a.batch), dim3(256), lds, a.stream, a.q, a.k, a.v,
+  if (allow_lds_once(self_attn_mfma_kernel<NT, NW>, lds, done, "self_attn_fwd")) return LR2_ERR_LAUNCH;
+  const int n_sub = (a.L + 15) / 16, max_chunks = (n_sub + NW - 1) / NW;
+  int chunks = attn_chunks(a.batch, a.heads, a.L);
+  if (chunks > max_chunks) chunks = max_chunks;
+  LR2_LAUNCH((self_attn_mfma_kernel<NT, NW>), dim3(chunks, a.heads, a.batch), dim3(64 * NW), lds, a.stream, a.q, a.k, a.v,
              a.lo_off, a.ld, a.seg, o, oh, o_lo_off, ld_o, a.heads, a.L, a.scale, lse, a.dr);
   return lr2_launch_status("lr2_self_attn_fwd");
 }
@@ -558,7 +584,7 @@ int launch_bwd(const AttnArgs& a, const bf16_t* go, size_t do_lo_off, int ld_do,
   static bool done1 = false, done2 = false;
   if (allow_lds_once(self_attn_bwd_dq_kernel<NT>, lds1, done1, "self_attn_bwd_dq")) return LR2_ERR_LAUNCH;
   if (allow_lds_once(self_attn_bwd_dkv_kernel<NT>, lds2, done2, "self_attn_bwd_dkv")) return LR2_ERR_LAUNCH;
-  const dim3 grid((a.L + 63) / 64, a.heads, a.batch);
+  const dim3 grid(attn_chunks(a.batch, a.heads, a.L), a.heads, a.batch);
   LR2_LAUNCH(self_attn_bwd_dq_kernel<NT>, grid, dim3(256), lds1, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, go, do_lo_off, ld_do,
              a.seg, dq, d_lo_off, ld_d, lse, dsum, a.heads, a.L, a.scale, a.dr);
   if (lr2_launch_status("lr2_self_attn_bwd(dq)")) return LR2_ERR_LAUNCH;
@@ -568,8 +594,9 @@ int launch_bwd(const AttnArgs& a, const bf16_t* go, size_t do_lo_off, int ld_do,
 }
 
 #define LR2_SA_INST(NT)                                                                                                        \
-  template __global__ void self_attn_mfma_kernel<NT>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int, const int64_t*, \
-                                                     float*, bf16_t*, size_t, int, int, int, float, float*, DropP);            \
+  template __global__ void self_attn_mfma_kernel<NT, (NT <= 14 ? 8 : 4)>(const bf16_t*, const bf16_t*, const bf16_t*, size_t,  \
+                                                                         int, const int64_t*, float*, bf16_t*, size_t, int,   \
+                                                                         int, int, float, float*, DropP);                      \
   template __global__ void self_attn_bwd_dq_kernel<NT>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int, const bf16_t*, \
                                                        size_t, int, const int64_t*, bf16_t*, size_t, int, float*, float*, int,  \
                                                        int, float, DropP);                                                     \
