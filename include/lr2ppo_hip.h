@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 7
+#define LR2_ABI_VERSION 8
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -228,6 +228,15 @@ int lr2_adamw_multi(const lr2_adamw_chunk* table_dev, int n_chunks, double lr, d
  * replaces: tencentpretrain/embeddings/{word,pos,seg}_embedding.py forward sums (embedding.py:19-30). */
 int lr2_text_embed(const int64_t* src, const int64_t* seg, const void* word, const void* pos, const void* seg_table,
                    void* out, int rows, int L, int D, void* stream);
+/* Backward of lr2_text_embed's word / segment gathers (the position table's gradient is lr2_period_rows_grad):
+ * dword[src[r], :] += dx[r, :], dseg[seg[r], :] += dx[r, :]; both tables must be zeroed by the caller; float atomics.
+ * replaces: autograd of nn.Embedding in tencentpretrain/embeddings/{word,seg}_embedding.py. */
+int lr2_text_embed_bwd(const void* dx, const int64_t* src, const int64_t* seg, void* dword, void* dseg, int rows, int D,
+                       void* stream);
+/* dst = dropout_mask(src) / (1 - p), fp32, mask element index = flat element index (src == dst allowed).
+ * replaces: self.dropout of tencentpretrain/embeddings/embedding.py:33 and its autograd. */
+int lr2_dropout_apply(const void* src, void* dst, uint64_t n, float drop_p, uint64_t drop_seed, uint32_t drop_site,
+                      void* stream);
 /* Image -> patch rows: out[(b*P + p), c*ps*ps + i*ps + j] = img[b, c, py*ps+i, px*ps+j].
  * replaces: the unfold implied by nn.Conv2d(k=s=patch) in tencentpretrain/embeddings/patch_embedding.py:18,27. */
 int lr2_patchify(const void* img, void* out, int B, int C, int H, int W, int ps, void* stream);

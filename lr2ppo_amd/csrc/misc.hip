@@ -76,6 +76,44 @@ __global__ __launch_bounds__(256) void dropout_planes_kernel(const float* __rest
   }
 }
 
+// dst = dropout_mask(src) / (1 - p) in fp32 (embedding dropout forward, and its backward on the incoming gradient)
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n4,
+                                                            float scale, uint32_t thr, uint64_t key) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 v = reinterpret_cast<const float4*>(src)[i];
+    const uint64_t e = (uint64_t)i * 4;
+    v.x = dropout_keep(key, e + 0, thr) ? v.x * scale : 0.f;
+    v.y = dropout_keep(key, e + 1, thr) ? v.y * scale : 0.f;
+    v.z = dropout_keep(key, e + 2, thr) ? v.z * scale : 0.f;
+    v.w = dropout_keep(key, e + 3, thr) ? v.w * scale : 0.f;
+    reinterpret_cast<float4*>(dst)[i] = v;
+  }
+}
+
+// Backward of the word / segment embedding gathers: dword[src[r]] += dx[r], dseg[seg[r]] += dx[r] (tables pre-zeroed).
+// Word rows by float atomics (token ids collide rarely); the 3 segment rows are first reduced per workgroup in LDS.
+__global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ src,
+                                                             const int64_t* __restrict__ seg, float* __restrict__ dword,
+                                                             float* __restrict__ dseg, int rows, int D, int rows_per_block) {
+  extern __shared__ float sseg[];   // [3][D]
+  for (int i = threadIdx.x; i < 3 * D; i += 256) sseg[i] = 0.f;
+  __syncthreads();
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  for (int r = r0; r < r1; ++r) {
+    const int64_t tok = src[r];
+    const int sg = (int)seg[r];
+    for (int c = threadIdx.x; c < D; c += 256) {
+      const float v = dx[(size_t)r * D + c];
+      atomicAdd(dword + (size_t)tok * D + c, v);
+      sseg[sg * D + c] += v;        // column c is owned by one thread: no race inside the block
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * D; i += 256)
+    if (sseg[i] != 0.f) atomicAdd(dseg + i, sseg[i]);
+}
+
 struct SplitChunk {
   const float* src;
   bf16_t* dst_hi;
@@ -486,6 +524,25 @@ extern "C" int lr2_dropout_planes(const void* src, void* dst_hi, uint64_t lo_off
   LR2_LAUNCH(dropout_planes_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)src,
              (bf16_t*)dst_hi, (size_t)lo_off, (size_t)(n / 4), 1.0f / (1.0f - drop_p), dropout_threshold(drop_p),
              (((uint64_t)drop_site) << 40) ^ (drop_seed * 0x9E3779B97F4A7C15ull));
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_dropout_apply(const void* src, void* dst, uint64_t n, float drop_p, uint64_t drop_seed, uint32_t drop_site,
+                                 void* stream) {
+  if (!src || !dst || n == 0 || drop_p <= 0.f || drop_p >= 1.f) return LR2_ERR_ARG;
+  if (n % 4) return LR2_ERR_SHAPE;
+  LR2_LAUNCH(dropout_apply_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst,
+             (size_t)(n / 4), 1.0f / (1.0f - drop_p), dropout_threshold(drop_p),
+             (((uint64_t)drop_site) << 40) ^ (drop_seed * 0x9E3779B97F4A7C15ull));
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_text_embed_bwd(const void* dx, const int64_t* src, const int64_t* seg, void* dword, void* dseg, int rows,
+                                  int D, void* stream) {
+  if (!dx || !src || !seg || !dword || !dseg || rows <= 0 || D <= 0) return LR2_ERR_ARG;
+  const int rows_per_block = 16;
+  LR2_LAUNCH(text_embed_bwd_kernel, dim3((rows + rows_per_block - 1) / rows_per_block), dim3(256), (size_t)3 * D * sizeof(float),
+             (hipStream_t)stream, (const float*)dx, src, seg, (float*)dword, (float*)dseg, rows, D, rows_per_block);
   CHECK_LAUNCH();
 }
 

@@ -155,6 +155,27 @@ def dropout_planes(src: torch.Tensor, dst: Planes, drop: Optional[Drop]):
     return dst
 
 
+def dropout_apply(src: torch.Tensor, dst: torch.Tensor, drop: Optional[Drop]):
+    """dst = dropout_mask(src) / (1 - p) (fp32; drop None / p = 0: copy)."""
+    _chk_f32(src, dst)
+    if drop is None or drop.p <= 0.0:
+        if dst.data_ptr() != src.data_ptr():
+            dst.copy_(src)
+        return dst
+    _nat.check(_nat.lib().lr2_dropout_apply(src.data_ptr(), dst.data_ptr(), src.numel(), drop.p, drop.seed, drop.site, _stream()),
+               "lr2_dropout_apply")
+    return dst
+
+
+def text_embed_bwd(dx, src, seg, dword, dseg, *, rows, D):
+    """dword[src[r]] += dx[r]; dseg[seg[r]] += dx[r] (tables zeroed by the caller)."""
+    _chk_f32(dx, dword, dseg)
+    if src.dtype != torch.int64 or seg.dtype != torch.int64:
+        raise TypeError("src / seg must be int64")
+    _nat.check(_nat.lib().lr2_text_embed_bwd(dx.data_ptr(), src.data_ptr(), seg.data_ptr(), dword.data_ptr(), dseg.data_ptr(),
+                                             rows, D, _stream()), "lr2_text_embed_bwd")
+
+
 def split_planes_multi(table_dev: torch.Tensor, n_chunks: int):
     _nat.check(_nat.lib().lr2_split_planes_multi(table_dev.data_ptr(), n_chunks, _stream()), "lr2_split_planes_multi")
 

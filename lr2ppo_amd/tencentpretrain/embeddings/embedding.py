@@ -2,7 +2,10 @@
 
 Reference: tencentpretrain/embeddings/{embedding,word_embedding,pos_embedding,seg_embedding,patch_embedding,
 dual_embedding}.py.  `Embedding.update(sub, name)` registers sub-embeddings; `forward(src, seg)` sums them,
-applies the TencentPretrain LayerNorm unless `remove_embedding_layernorm`, then dropout (inference: identity).
+applies the TencentPretrain LayerNorm unless `remove_embedding_layernorm`, then dropout (inference: identity; train
+mode: counter-based masks of lr2ppo_amd.runtime).  With autograd enabled the forward keeps what the hand-written backward
+needs (`_EmbeddingFn`): LayerNorm backward, position-table column sums, word / segment scatter-adds, and for the patch
+embedding the weight gradient of the Conv2d(k = s = patch) as one TN GEMM over the patch rows.
 Two compositions are recognised and run as fused kernels:
   ["patch", "pos"]        image -> patch rows (lr2_patchify) -> split-bf16 GEMM with the conv weight viewed as
                           [E, C*p*p] (Conv2d k=s=p is exactly that GEMM) -> cls + pos assembly (lr2_vit_assemble)
@@ -14,7 +17,7 @@ from argparse import Namespace
 import torch
 import torch.nn as nn
 
-from ... import engine, ops
+from ... import engine, ops, runtime
 from ..layers.layer_norm import LayerNorm
 
 
@@ -69,44 +72,121 @@ class Embedding(nn.Module):
         setattr(self, embedding_name, embedding)
         self.embedding_name_list.append(embedding_name)
 
-    @torch.no_grad()
     def forward(self, src, seg):
         names = self.embedding_name_list
         if names and names[0] == "dual":
             return self.dual(src, seg)
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("embedding dropout (training) is outside this round's scope; call .eval()")
-        dev = src.device
         if not src.is_cuda:
             raise TypeError("lr2ppo_amd: inputs must live on the HIP device (no CPU path)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _EmbeddingFn.apply(self, src, seg, *list(self.parameters()))
+        out, _ = self._run(src, seg, save=False)
+        return out
+
+    @torch.no_grad()
+    def _run(self, src, seg, save):
+        """-> (out, saved).  Train mode applies dropout (site 0 of a fresh seed from the runtime's mask stream)."""
+        names = self.embedding_name_list
+        dev = src.device
         if self._ws is None or self._ws.device != dev:
             self._ws = engine.Workspace(dev)
         ws = self._ws
+        saved = {"kind": tuple(names)}
         if names == ["patch", "pos"]:
             pe = self.patch
             pe.check(src)
             B, C, H, W = src.shape
             ps = pe.patch_size
             P, E, Kd = (H // ps) * (W // ps), pe.cls_emb.shape[-1], C * ps * ps
-            patches = ws.mat("patches", B * P, Kd)
+            patches = torch.empty(B * P, Kd, device=dev) if save else ws.mat("patches", B * P, Kd)
             ops.patchify(src.contiguous().float(), patches, B=B, Cc=C, H=H, W=W, ps=ps)
             proj = ws.mat("proj", B * P, E)
             engine.linear_fwd(ws, patches, pe.projection.weight.data.view(E, Kd), None, proj, B * P, E, Kd)
             out = torch.empty(B, P + 1, E, device=dev)
             ops.vit_assemble(proj, pe.cls_emb.data.view(-1), self.pos.embedding.weight.data, out, B=B, P=P, D=E)
+            saved.update(patches=patches, dims=(B, P, E, Kd))
         elif names == ["word", "pos", "seg"]:
             B, L = src.shape
             E = self.word.emb_size
+            ids = src.contiguous().view(-1).long()
+            sg = seg.to(dev).contiguous().view(-1).long()
             out = torch.empty(B, L, E, device=dev)
-            ops.text_embed(src.contiguous().view(-1).long(), seg.to(dev).contiguous().view(-1).long(),
-                           self.word.embedding.weight.data, self.pos.embedding.weight.data, self.seg.embedding.weight.data,
-                           out.view(B * L, E), rows=B * L, L=L, D=E)
+            ops.text_embed(ids, sg, self.word.embedding.weight.data, self.pos.embedding.weight.data,
+                           self.seg.embedding.weight.data, out.view(B * L, E), rows=B * L, L=L, D=E)
+            saved.update(ids=ids, seg=sg, dims=(B, L, E))
         else:
             raise NotImplementedError(f"embedding composition {names}: only ['patch','pos'] and ['word','pos','seg'] "
                                       "(ViT-B/16, RoBERTa-base) are on the HIP path")
         if not self.remove_embedding_layernorm:
-            out = self.layer_norm(out)
+            ln = self.layer_norm
+            M, E = out.shape[0] * out.shape[1], out.shape[2]
+            y = torch.empty_like(out)
+            mean, rstd = (torch.empty(M, device=dev), torch.empty(M, device=dev)) if save else (None, None)
+            ops.layernorm_fwd(out.view(M, E), ln.gamma.data, ln.beta.data, y.view(M, E), mean, rstd, rows=M, D=E, eps=ln.eps,
+                              mode=1)
+            saved.update(x=out, mean=mean, rstd=rstd)
+            out = y
+        p = float(self.dropout.p) if self.training else 0.0
+        saved["drop"] = None
+        if p > 0:
+            saved["drop"] = ops.Drop(p, runtime.next_drop(p, 0).seed, 0)
+            ops.dropout_apply(out, out, saved["drop"])
+        return out, saved
+
+    @torch.no_grad()
+    def _backward(self, saved, dout):
+        """-> {parameter: gradient} (inputs are data: token ids / pixels get no gradient)."""
+        dev = dout.device
+        ws = self._ws
+        G = {}
+        dy = dout.contiguous()
+        if saved["drop"] is not None:
+            dy = ops.dropout_apply(dy, torch.empty_like(dy), saved["drop"])
+        if not self.remove_embedding_layernorm:
+            ln = self.layer_norm
+            M, E = dy.shape[0] * dy.shape[1], dy.shape[2]
+            dx = torch.empty(M, E, device=dev)
+            G[ln.gamma], G[ln.beta] = torch.empty(E, device=dev), torch.empty(E, device=dev)
+            ops.layernorm_bwd(dy.view(M, E), saved["x"].view(M, E), ln.gamma.data, saved["mean"], saved["rstd"], dx,
+                              ws.vec("ln_partials", 256 * 2 * E), G[ln.gamma], G[ln.beta], rows=M, D=E, mode=1, eps=ln.eps)
+            dy = dx.view_as(dy)
+        if saved["kind"] == ("patch", "pos"):
+            pe = self.patch
+            B, P, E, Kd = saved["dims"]
+            dpos = torch.zeros_like(self.pos.embedding.weight)
+            ops.period_rows_grad(dy.view(B * (P + 1), E), dpos, rows=B * (P + 1), D=E, period=P + 1)
+            G[self.pos.embedding.weight] = dpos
+            G[pe.cls_emb] = dpos[0].clone().view_as(pe.cls_emb)            # out[b, 0] = cls + pos[0]: same gradient rows
+            dproj = torch.empty(B, 1, P * E, device=dev)
+            ops.gather_rows(dy.view(B, (P + 1) * E)[:, E:], None, dproj, B=B, t_in=1, t_out=1, row_elems=P * E,
+                            src_bstride=(P + 1) * E, src_tstride=0)
+            dproj_p = ops.split_planes(dproj.view(B * P, E), ops.Planes.empty(B * P, E, dev))
+            patches_p = ops.split_planes(saved["patches"], ops.Planes.empty(B * P, Kd, dev))
+            dw = torch.empty(E, Kd, device=dev)
+            engine.linear_wgrad(ws, dproj_p, patches_p, dw, None, B * P, Kd, E)
+            G[pe.projection.weight] = dw.view_as(pe.projection.weight)
+        else:
+            B, L, E = saved["dims"]
+            dword, dseg = torch.zeros_like(self.word.embedding.weight), torch.zeros_like(self.seg.embedding.weight)
+            dpos = torch.zeros_like(self.pos.embedding.weight)
+            ops.text_embed_bwd(dy.view(B * L, E), saved["ids"], saved["seg"], dword, dseg, rows=B * L, D=E)
+            ops.period_rows_grad(dy.view(B * L, E), dpos, rows=B * L, D=E, period=L)
+            G[self.word.embedding.weight], G[self.seg.embedding.weight], G[self.pos.embedding.weight] = dword, dseg, dpos
+        return G
+
+
+class _EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, src, seg, *params):
+        out, saved = emb._run(src, seg, save=True)
+        ctx.emb, ctx.saved = emb, saved
         return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        G = ctx.emb._backward(ctx.saved, dout)
+        ctx.saved = None
+        return (None, None, None) + tuple(G.get(q) if q.requires_grad else None for q in ctx.emb.parameters())
 
 
 class DualEmbedding(nn.Module):

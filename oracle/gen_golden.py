@@ -513,6 +513,46 @@ def gen_embeddings_small():
     _save("embeddings_small.npz", **arrays)
 
 
+def gen_embeddings_bwd():
+    """Parameter gradients of the reference Embedding modules (autograd, eval mode) for sum(out * w): the two
+    compositions of the dual encoder at small sizes (same seeds / shapes as gen_embeddings_small)."""
+    from tencentpretrain.embeddings import Embedding, str2embedding
+    arrays = {}
+    g = torch.Generator().manual_seed(52)
+    a = _encoder_args("models/vit/base-16-224_config.json", emb_size=32, image_height=32, image_width=48, patch_size=8,
+                      max_seq_length=25, dropout=0.1)
+    emb = Embedding(a)
+    for e in a.embedding:
+        emb.update(str2embedding[e](a, 100), e)
+    emb.eval()
+    emb.load_state_dict(O.seeded_params(O.vit_embedding_spec(32, 3, 8, 25), seed=51, std=0.5), strict=True)
+    img = torch.randn(2, 3, 32, 48, generator=g)
+    w = torch.randn(2, 25, 32, generator=g)
+    out = emb(img, torch.ones(2, 25, dtype=torch.long))
+    (out * w).sum().backward()
+    arrays["vit_img"], arrays["vit_w"], arrays["vit_out"] = img, w, out.detach()
+    for n, p_ in emb.named_parameters():
+        arrays["vit_grad." + n] = p_.grad.detach()
+    a = _encoder_args("models/xlm-roberta/base_config.json", emb_size=32, max_seq_length=20, dropout=0.1)
+    emb = Embedding(a)
+    for e in a.embedding:
+        emb.update(str2embedding[e](a, 100), e)
+    emb.eval()
+    emb.load_state_dict(O.seeded_params(O.text_embedding_spec(32, 100, 20), seed=53, std=0.5, skip_gamma_beta=False), strict=True)
+    src = torch.randint(0, 100, (3, 11), generator=g)
+    src[0, :4] = 7                                  # repeated token ids: their rows accumulate
+    seg = torch.ones(3, 11, dtype=torch.long)
+    seg[1, 7:] = 0
+    seg[2, 5:] = 2
+    w = torch.randn(3, 11, 32, generator=g)
+    out = emb(src, seg)
+    (out * w).sum().backward()
+    arrays["txt_src"], arrays["txt_seg"], arrays["txt_w"], arrays["txt_out"] = src, seg, w, out.detach()
+    for n, p_ in emb.named_parameters():
+        arrays["txt_grad." + n] = p_.grad.detach()
+    _save("embeddings_bwd_small.npz", **arrays)
+
+
 def gen_encoder_full():
     """ViT-B/16 and RoBERTa-base stacks from the shipped JSON configs, seeded weights, eval."""
     from tencentpretrain.embeddings import Embedding, str2embedding
@@ -565,7 +605,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

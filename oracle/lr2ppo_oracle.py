@@ -443,19 +443,20 @@ def patch_embedding(P: Params, prefix: str, img: torch.Tensor, patch: int) -> to
     return torch.cat([cls, pe], dim=1)
 
 
-def vit_embedding(P: Params, img: torch.Tensor, patch: int, prefix: str = "") -> torch.Tensor:
-    """Embedding(['patch','pos'], remove_embedding_layernorm) (embeddings/embedding.py:19-34)."""
+def vit_embedding(P: Params, img: torch.Tensor, patch: int, prefix: str = "", drop=None) -> torch.Tensor:
+    """Embedding(['patch','pos'], remove_embedding_layernorm) (embeddings/embedding.py:19-34); drop: train-mode dropout
+    of embedding.py:33 with the HIP path's counter-based mask (site 0 of the embedding's own seed)."""
     e = patch_embedding(P, prefix + "patch", img, patch)
     L = e.shape[1]
-    return e + P[prefix + "pos.embedding.weight"][:L].unsqueeze(0)
+    return _apply_dropout(e + P[prefix + "pos.embedding.weight"][:L].unsqueeze(0), drop, 0)
 
 
-def text_embedding(P: Params, src: torch.Tensor, seg: torch.Tensor, prefix: str = "") -> torch.Tensor:
-    """Embedding(['word','pos','seg']) + TP LayerNorm (embeddings/embedding.py:19-34)."""
+def text_embedding(P: Params, src: torch.Tensor, seg: torch.Tensor, prefix: str = "", drop=None) -> torch.Tensor:
+    """Embedding(['word','pos','seg']) + TP LayerNorm (embeddings/embedding.py:19-34) + dropout (:33)."""
     L = src.shape[1]
     e = P[prefix + "word.embedding.weight"][src] + P[prefix + "pos.embedding.weight"][:L].unsqueeze(0) \
         + P[prefix + "seg.embedding.weight"][seg]
-    return layernorm_tp(e, P[prefix + "layer_norm.gamma"], P[prefix + "layer_norm.beta"])
+    return _apply_dropout(layernorm_tp(e, P[prefix + "layer_norm.gamma"], P[prefix + "layer_norm.beta"]), drop, 0)
 
 
 def vit_embedding_spec(emb: int, channels: int, patch: int, max_seq: int, prefix: str = ""):

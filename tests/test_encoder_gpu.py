@@ -180,3 +180,88 @@ def test_encoder_train_mode_dropout_matches_oracle(dev, tag):
         _cmp(p.grad, Pg[n].grad, n)
     out2 = enc(e, seg.to(dev))                             # the mask stream advances: a second forward differs
     assert not torch.equal(out2, out)
+
+
+def _small_embeddings(dev, train):
+    from lr2ppo_amd.tencentpretrain.embeddings import Embedding, str2embedding
+    built = []
+    for cfg, spec, seed, kw in ((VIT, O.vit_embedding_spec(32, 3, 8, 25), 51, dict(emb_size=32, image_height=32, image_width=48,
+                                                                                 patch_size=8, max_seq_length=25)),
+                               (ROBERTA, O.text_embedding_spec(32, 100, 20), 53, dict(emb_size=32, max_seq_length=20))):
+        a = _args(**{**cfg, **kw, "dropout": 0.1})
+        emb = Embedding(a)
+        for n in a.embedding:
+            emb.update(str2embedding[n](a, 100), n)
+        P = O.seeded_params(spec, seed=seed, std=0.5, skip_gamma_beta=cfg is VIT)
+        emb.load_state_dict(P, strict=True)
+        emb = emb.to(dev)
+        built.append((emb.train() if train else emb.eval(), P))
+    return built
+
+
+def test_embedding_backward_matches_reference_golden(dev):
+    """A15 backward (eval mode): parameter gradients of both compositions against the reference modules' autograd."""
+    g = load_golden("embeddings_bwd_small.npz")
+    (vit, _), (txt, _) = _small_embeddings(dev, train=False)
+    out = vit(g["vit_img"].to(dev), torch.ones(2, 25, dtype=torch.long, device=dev))
+    (out * g["vit_w"].to(dev)).sum().backward()
+    _cmp(out, g["vit_out"], "vit out", rel=2e-4)
+    for n, p in vit.named_parameters():
+        _cmp(p.grad, g["vit_grad." + n], "vit " + n)
+    out = txt(g["txt_src"].to(dev), g["txt_seg"].to(dev))
+    (out * g["txt_w"].to(dev)).sum().backward()
+    _cmp(out, g["txt_out"], "txt out", rel=1e-5)
+    for n, p in txt.named_parameters():
+        _cmp(p.grad, g["txt_grad." + n], "txt " + n, rel=1e-4)
+
+
+def test_embedding_train_mode_dropout_matches_oracle(dev):
+    from lr2ppo_amd import runtime
+    g = load_golden("embeddings_bwd_small.npz")
+    (vit, Pv), (txt, Pt) = _small_embeddings(dev, train=True)
+    for emb, P, fwd, inputs, w in ((vit, Pv, lambda Pg, d: O.vit_embedding(Pg, g["vit_img"], 8, drop=d),
+                                    (g["vit_img"], torch.ones(2, 25, dtype=torch.long)), g["vit_w"]),
+                                   (txt, Pt, lambda Pg, d: O.text_embedding(Pg, g["txt_src"], g["txt_seg"], drop=d),
+                                    (g["txt_src"], g["txt_seg"]), g["txt_w"])):
+        runtime.set_dropout_seed(31, calls=4)
+        seed = runtime.peek_drop_seed()
+        out = emb(inputs[0].to(dev), inputs[1].to(dev))
+        (out * w.to(dev)).sum().backward()
+        Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        ref = fwd(Pg, {"p": 0.1, "seed": seed, "site_base": 0})
+        (ref * w).sum().backward()
+        _cmp(out, ref.detach(), "out", rel=2e-4)
+        assert float((out == 0).float().mean()) > 0.05          # the mask really dropped elements
+        for n, p in emb.named_parameters():
+            _cmp(p.grad, Pg[n].grad, n, rel=2e-4 if emb is txt else 1e-3)
+
+
+def test_embedding_plus_encoder_chain_backward(dev):
+    """Token ids -> Embedding -> TransformerEncoder -> loss.backward(): the two hand-written autograd nodes chained;
+    every gradient (word / position / segment tables, LayerNorms, all layer weights) against the oracle chain."""
+    from lr2ppo_amd.tencentpretrain.embeddings import Embedding, str2embedding
+    from lr2ppo_amd.tencentpretrain.encoders import str2encoder
+    a = _args(**{**ROBERTA, "hidden_size": 128, "emb_size": 128, "feedforward_size": 256, "heads_num": 2, "layers_num": 2,
+                 "max_seq_length": 40, "dropout": 0.0})
+    emb = Embedding(a)
+    for n in a.embedding:
+        emb.update(str2embedding[n](a, 100), n)
+    Pe = O.seeded_params(O.text_embedding_spec(128, 100, 40), seed=71, std=0.3, skip_gamma_beta=False)
+    Pl = O.seeded_params(O.encoder_param_spec(2, 128, 256, False), seed=72, std=0.15, skip_gamma_beta=False)
+    emb.load_state_dict(Pe, strict=True)
+    enc = str2encoder["transformer"](a)
+    enc.load_state_dict(Pl, strict=True)
+    emb, enc = emb.to(dev).train(), enc.to(dev).train()          # dropout probability is 0: train mode = eval numerics
+    g = torch.Generator().manual_seed(73)
+    src = torch.randint(0, 100, (3, 33), generator=g)
+    seg = torch.ones(3, 33, dtype=torch.long)
+    seg[2, 20:] = 0
+    w = torch.randn(3, 33, 128, generator=g)
+    out = enc(emb(src.to(dev), seg.to(dev)), seg.to(dev))
+    (out * w.to(dev)).sum().backward()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in {**Pe, **Pl}.items()}
+    ref = O.transformer_encoder(Pg, O.text_embedding(Pg, src, seg), seg, 2, 2, False)
+    (ref * w).sum().backward()
+    _cmp(out, ref.detach(), "out", rel=1e-4)
+    for n, p in list(emb.named_parameters()) + list(enc.named_parameters()):
+        _cmp(p.grad, Pg[n].grad, n)

@@ -268,3 +268,28 @@ def test_dp_factor_gather_path_equals_local_gradient(dev):
     for n in ref:
         scale = float(ref[n].abs().max())
         assert _maxerr(G[n], ref[n]) <= 1e-9 + 1e-4 * scale, n
+
+
+def test_evaluate_ndcg_matches_oracle_scores(dev):
+    """north_star: NDCG@3 within +-0.002 of the reference on identical seeds.  evaluate() over a synthetic validation set
+    (4 items x 20 tags) on the HIP actor against NDCG computed from the oracle's CPU scores with the same weights."""
+    from lr2ppo_amd.finetune import ppo
+    from torch.utils.data import DataLoader
+    args = _ns(**ARGS, is_master=True, device=dev)
+    model = ppo.ActorCritic(args, None)
+    P = O.seeded_params(O.head_param_spec("actor"), seed=7)
+    model.actor.load_state_dict(P, strict=True)
+    args.model = model.to(dev)
+    ds = ppo.SyntheticMovieNet(4, 20, 16, seed=5)
+    vals = ppo.evaluate(args, DataLoader(ds, batch_size=1), 0, split="val", num_tasks=1)
+    rows = []
+    with torch.no_grad():
+        for i in range(len(ds)):
+            text, img, tgts = ds[i]
+            scores = O.actor_forward(P, text.unsqueeze(0), img.unsqueeze(0).unsqueeze(1).repeat(1, 20, 1, 1), None).view(-1)
+            rows.append(O.ndcg_vector(scores, tgts))
+    ref = torch.stack(rows).mean(0)                  # NDCG@{1,3,5,10,20,all}
+    got = args.last_ndcg
+    for j, k in enumerate((1, 3, 5, 10, 20, 100000000)):
+        assert abs(got[k] - float(ref[j])) <= 0.002, (k, got[k], float(ref[j]))
+    assert abs(float(vals) - float(ref[5])) <= 0.002

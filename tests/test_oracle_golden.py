@@ -255,3 +255,23 @@ def test_encoder_backward_oracle_matches_reference_autograd(tag):
     for k in P:
         ref = g[f"{tag}_grad.{k}"]
         assert (Pg[k].grad - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max())), k
+
+
+def test_embedding_backward_oracle_matches_reference_autograd():
+    """A15 backward: the oracle's two embedding compositions under autograd against the reference modules' gradients."""
+    g = load_golden("embeddings_bwd_small.npz")
+    P = {k: v.clone().requires_grad_(True) for k, v in O.seeded_params(O.vit_embedding_spec(32, 3, 8, 25), seed=51, std=0.5).items()}
+    out = O.vit_embedding(P, g["vit_img"], 8)
+    (out * g["vit_w"]).sum().backward()
+    assert (out - g["vit_out"]).abs().max() < 1e-4
+    for k in P:
+        ref = g["vit_grad." + k]
+        assert (P[k].grad - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max())), k
+    P = {k: v.clone().requires_grad_(True)
+         for k, v in O.seeded_params(O.text_embedding_spec(32, 100, 20), seed=53, std=0.5, skip_gamma_beta=False).items()}
+    out = O.text_embedding(P, g["txt_src"], g["txt_seg"])
+    (out * g["txt_w"]).sum().backward()
+    assert (out - g["txt_out"]).abs().max() < 1e-5
+    for k in P:
+        ref = g["txt_grad." + k]
+        assert (P[k].grad - ref).abs().max() < 1e-5 * max(1.0, float(ref.abs().max())), k
