@@ -56,6 +56,7 @@ struct GemmParams {
   int tiles_m, tiles_n;         // output tile grid
   float* partial;               // split-K workspace [splits][M][N] or nullptr
   int dma_stages;               // LDS images per planes operand: 2 = double buffered (1 workgroup/CU at BM=128), 1 = single
+  int waves8;                   // planes x planes, 128 x 128 tiles: 8-wave workgroups (wave tile 64 x 32)
   int ablate;                   // diagnostics only (LR2_GEMM_ABLATE): 2 no global loads, 4 no LDS fill
   Epilogue epi;
 };
@@ -151,10 +152,10 @@ struct RegStager {
 // ---- operand source 2: bf16 hi/lo planes in HBM, LDS-DMA ---------------------------------------
 // LDS-DMA writes lane-linearly (wave-uniform base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE
 // address; the LDS image is then identical to the one RegStager writes and read_frag() serves both.
-template <int BR, int BK, bool TR, int PASSES>
+template <int BR, int BK, bool TR, int PASSES, int NW = 4>
 struct DmaStager {
-  static constexpr int UNITS = BR * BK / 8;        // 16-byte units per plane tile (BR x BK bf16)
-  static constexpr int PER_WAVE = UNITS / 64 / 4;  // DMA instructions per wave per plane
+  static constexpr int UNITS = BR * BK / 8;         // 16-byte units per plane tile (BR x BK bf16)
+  static constexpr int PER_WAVE = UNITS / 64 / NW;  // DMA instructions per wave per plane
   static constexpr int UPR = TR ? BR / 8 : BK / 8;
   static constexpr int TILE_BYTES = BR * BK * 2;
   uint32_t voff[PER_WAVE];
@@ -492,8 +493,10 @@ __device__ __forceinline__ void epilogue_wave_adam(const GemmParams& g, f32x4_t 
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------
-template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int PASSES, bool APL, bool BPL>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams g) {
+template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int PASSES, bool APL, bool BPL, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_kernel(GemmParams g) {
+  static_assert(NW == 4 || (APL && BPL), "8-wave workgroups exist for planes x planes operands only");
+  static_assert((BM / WM) * (BN / WN) == NW, "wave grid");
   constexpr int MI = WM / 16, NI = WN / 16;
   constexpr int WAVES_N = BN / WN;
   constexpr int NIMG = PASSES == 3 ? 2 : 1;
@@ -544,8 +547,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams g) {
 
   RegStager<BM, BK, TA, PASSES> ra;
   RegStager<BN, BK, TB, PASSES> rb;
-  DmaStager<BM, BK, TA, PASSES> da;
-  DmaStager<BN, BK, TB, PASSES> db;
+  DmaStager<BM, BK, TA, PASSES, NW> da;
+  DmaStager<BN, BK, TB, PASSES, NW> db;
   if (APL) da.init(wave, lane, m0, g.lda, kt_begin);
   else ra.init(tid, m0, g.lda, kt_begin);
   if (BPL) db.init(wave, lane, n0, g.ldb, kt_begin);
@@ -633,6 +636,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   LR2_GEMM_INST_SRC(BM, WN, false, false, P)     \
   LR2_GEMM_INST_SRC(BM, WN, false, true, P)      \
   LR2_GEMM_INST_SRC(BM, WN, true, true, P)
+#define LR2_GEMM_INST_W8(BK, TA, TB) \
+  template __global__ void gemm_kernel<128, 128, BK, 64, 32, TA, TB, 3, true, true, 8>(GemmParams);
+LR2_GEMM_INST_W8(64, false, false)
+LR2_GEMM_INST_W8(64, false, true)
+LR2_GEMM_INST_W8(64, true, true)
+LR2_GEMM_INST_W8(32, false, false)
+LR2_GEMM_INST_W8(32, false, true)
+LR2_GEMM_INST_W8(32, true, true)
 LR2_GEMM_INST_FORM(128, 64, 1)
 LR2_GEMM_INST_FORM(128, 64, 3)
 LR2_GEMM_INST_FORM(64, 32, 1)
@@ -650,6 +661,20 @@ int launch(const GemmParams& p_in, int splits, hipStream_t stream) {
   constexpr size_t epi_lds = (size_t)4 * 32 * (WN + 4) * 4;
   const size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
   constexpr size_t max_lds = (size_t)2 * NIMG * BM * BK * 2 + (size_t)2 * NIMG * BN * BK * 2;
+  if constexpr (APL && BPL && BM == 128 && PASSES == 3) {
+    if (p.waves8) {   // 8 waves per workgroup, wave tile 64 x 32
+      auto k8 = gemm_kernel<128, 128, BK, 64, 32, TA, TB, 3, true, true, 8>;
+      constexpr size_t epi8 = (size_t)8 * 32 * (32 + 4) * 4;
+      const size_t lds8 = main_lds > epi8 ? main_lds : epi8;
+      static bool attr_set8 = false;
+      if (!attr_set8) {
+        if (lr2_allow_dynamic_lds(k8, max_lds > epi8 ? max_lds : epi8, "gemm")) return LR2_ERR_LAUNCH;
+        attr_set8 = true;
+      }
+      LR2_LAUNCH(k8, grid, dim3(512), lds8, stream, p);
+      return lr2_launch_status(__func__);
+    }
+  }
   auto kern = gemm_kernel<BM, BN, BK, WM, WN, TA, TB, PASSES, APL, BPL>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -728,7 +753,7 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   if (block_m != 64) block_m = 128;
   // K-contiguous operands need whole K tiles (a ragged K would read into the next row, not zeros); ragged M / N are
   // handled by the zero-filling range check on loads plus masked stores.
-  static int bk_env = -1, ablate = -1, stages = -1;
+  static int bk_env = -1, ablate = -1, stages = -1, w8_env = 0;
   if (ablate < 0) {
     const char* e = getenv("LR2_GEMM_ABLATE");
     ablate = e ? atoi(e) : 0;
@@ -736,6 +761,8 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
     stages = st ? atoi(st) : 0;
     const char* bk = getenv("LR2_GEMM_BK");
     bk_env = bk ? (atoi(bk) == 64 ? 64 : 32) : 0;
+    const char* w8 = getenv("LR2_GEMM_W8");
+    w8_env = w8 ? atoi(w8) : 1;
   }
   // planes x planes with a contraction-strided B (NN, TN): 32-deep K tiles, two LDS stages (64 KB), two workgroups per
   // CU -- measured +10-14 % on the wgrad shapes; NT and anything with an fp32 operand: 64-deep tiles, one stage.
@@ -771,6 +798,9 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   p.partial = splits > 1 ? (float*)splitk_ws : nullptr;
   p.epi = to_device_epilogue(epi);
   p.ablate = ablate;
+  // 128 x 128 planes tiles, NT / NN: 8-wave workgroups (two workgroups per CU = 4 waves per SIMD) overlap the MFMA issue,
+  // the LDS-DMA issue and the fragment waits of different waves: +5..21 % over 4 waves (tools/gemm_bench.py); TN: equal.
+  p.waves8 = (w8_env && !trans_a) ? 1 : 0;
   // 64-deep planes tiles: one image + 2 workgroups/CU measured faster than two images + 1 workgroup/CU
   p.dma_stages = stages ? (stages == 1 ? 1 : 2) : (BK == 32 ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;

@@ -205,7 +205,7 @@ def choose_tiling(M: int, N: int, K: int, trans_a: bool, trans_b: bool = False):
         # (588 tiles) +9..15 %, M=6304 N=768 K=768 (300) +17 %, M=6304 N=3072 (1200) +17 %; full rounds (4096^3: 1024
         # tiles) and M=12544 N=3072 (2352) are 10-25 % faster with 128-row tiles.
         last = tiles % 512
-        if (tiles > 512 and 0 < last <= 400) or (256 < tiles <= 512 and K < 1536):
+        if (tiles > 512 and 0 < last <= 128) or (256 < tiles <= 512 and K < 1536):
             return 64, 1
     k_tiles = (K + 63) // 64
     slots = 768 if bm == 64 else 512
