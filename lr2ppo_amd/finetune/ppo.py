@@ -521,6 +521,11 @@ def rollout_step(model, reward_model, text_emb, img_emb, tgts, state=None):
     return [state, next_state, scores.clone(), rewards, value, text_emb, img_emb, tgts]
 
 
+class _DoneWork:
+    def wait(self):
+        return True
+
+
 class _DataParallel:
     """Gradient exchange of the north-star data-parallel mode (the reference trains independent replicas,
     finetune/ppo.py has no DDP).  Per model and minibatch:
@@ -539,6 +544,11 @@ class _DataParallel:
         out, inp = out.view(torch.uint8), inp.view(torch.uint8)   # raw bytes: int16 is not a NCCL/gloo element type
         if self.backend == "nccl":
             return dist.all_gather_into_tensor(out, inp, async_op=True)
+        if inp.is_cuda:      # gloo has no device all_gather: stage through the host (rehearsals of the N > 1 path only)
+            host = [torch.empty(inp.numel(), dtype=torch.uint8) for _ in range(self.world)]
+            dist.all_gather(host, inp.cpu())
+            out.copy_(torch.cat(host).to(out.device))
+            return _DoneWork()
         return dist.all_gather(list(out.view(self.world, -1).unbind(0)), inp, async_op=True)
 
     def gather_planes_start(self, pl: ops.Planes, ws, name: str):
