@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 8
+#define LR2_ABI_VERSION 9
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -96,6 +96,10 @@ int lr2_copy_rows(const void* src, void* dst, int dst_planes, uint64_t dst_lo_of
                   uint64_t dst_gstride, uint64_t dst_off, void* stream);
 /* fp32 -> bf16 planes: dst_hi[i] = bf16(src[i]), dst_hi[lo_off + i] = bf16(src[i] - hi) for i < n (n % 4 == 0). */
 int lr2_split_planes(const void* src, void* dst_hi, uint64_t lo_off, uint64_t n, void* stream);
+/* Transposing split: src fp32 [R][C] -> planes [C][R] (hi at dst_hi, lo lo_off elements behind).  An nn.Linear weight
+ * [out, in] re-laid as [in, out] lets its forward x.W^T run as the (0,1) form of lr2_gemm, the fastest of the three on wide
+ * outputs; nothing in the reference corresponds to it (layout choice of this build). */
+int lr2_split_planes_t(const void* src, void* dst_hi, uint64_t lo_off, int R, int C, void* stream);
 /* planes of dropout_mask(src) / (1 - p), mask element index = flat element index (the gradient entering a dropped branch).
  * replaces: autograd of nn.Dropout at tencentpretrain/layers/transformer.py:55,58,65,72 on the pre-LN residual paths. */
 int lr2_dropout_planes(const void* src, void* dst_hi, uint64_t lo_off, uint64_t n, float drop_p, uint64_t drop_seed,

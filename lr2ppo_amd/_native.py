@@ -90,6 +90,7 @@ SIGNATURES = {
     "lr2_dropout_planes": [_P, _P, _U64, _U64, _F, _U64, _U32, _P],
     "lr2_dropout_apply": [_P, _P, _U64, _F, _U64, _U32, _P],
     "lr2_text_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "lr2_split_planes_t": [_P, _P, _U64, _I, _I, _P],
     "lr2_split_planes_multi": [_P, _I, _P],
     "lr2_layernorm_fwd": [_P, _P, _P, _P, _P, _U64, _P, _P, _I, _I, _F, _I, _I, _U64, _P],
     "lr2_layernorm_bwd": [_P, _I, _U64, _P, _P, _P, _P, _P, _P, _P, _U64, _F, _U64, _U32, _P, _I, _I, _I, _I, _F, _P],
@@ -141,7 +142,7 @@ def lib() -> C.CDLL:
                 raise RuntimeError(f"lr2ppo_amd: {LIB_PATH} does not export {name}") from e
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        if handle.lr2_abi_version() != 8:
+        if handle.lr2_abi_version() != 9:
             raise RuntimeError("lr2ppo_amd: ABI version mismatch between python package and native library")
         _lib = handle
         return _lib

@@ -114,6 +114,31 @@ __global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __rest
     if (sseg[i] != 0.f) atomicAdd(dseg + i, sseg[i]);
 }
 
+// dst planes [C][R] = transpose of src fp32 [R][C] (weights re-laid so that the forward GEMM can run in its NN form).
+// 32 x 32 tiles through LDS; reads and writes are both row-contiguous.
+__global__ __launch_bounds__(256) void split_planes_t_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t lo_off,
+                                                             int R, int C) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;             // output row c, column r
+    if (c < C && r < R) {
+      const float v = tile[tx][ty + 8 * i];
+      const bf16_t h = f2bf(v);
+      dst[(size_t)c * R + r] = h;
+      dst[(size_t)c * R + r + lo_off] = f2bf(v - bf2f(h));
+    }
+  }
+}
+
 struct SplitChunk {
   const float* src;
   bf16_t* dst_hi;
@@ -543,6 +568,13 @@ extern "C" int lr2_text_embed_bwd(const void* dx, const int64_t* src, const int6
   const int rows_per_block = 16;
   LR2_LAUNCH(text_embed_bwd_kernel, dim3((rows + rows_per_block - 1) / rows_per_block), dim3(256), (size_t)3 * D * sizeof(float),
              (hipStream_t)stream, (const float*)dx, src, seg, (float*)dword, (float*)dseg, rows, D, rows_per_block);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_split_planes_t(const void* src, void* dst_hi, uint64_t lo_off, int R, int C, void* stream) {
+  if (!src || !dst_hi || R <= 0 || C <= 0) return LR2_ERR_ARG;
+  LR2_LAUNCH(split_planes_t_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream, (const float*)src,
+             (bf16_t*)dst_hi, (size_t)lo_off, R, C);
   CHECK_LAUNCH();
 }
 

@@ -195,7 +195,8 @@ class _Head(nn.Module):
         fp32 parameters at the start of every forward."""
         if self._wp is None or not self._wp.matches(P):
             names = engine.TRUNK_GEMM_WEIGHTS + (engine.XITT.gemm_weights() if self.has_tail else [])
-            self._wp = engine.WeightPlanes(P, names)
+            tnames = engine.TRUNK_T_WEIGHTS + ([engine.XITT.f1_w] if self.has_tail else [])
+            self._wp = engine.WeightPlanes(P, names, transposed=tnames)
             refresh = True
         if refresh:
             self._wp.refresh()

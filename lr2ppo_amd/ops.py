@@ -111,9 +111,10 @@ class Drop:
 class Planes:
     """A matrix stored as two bf16 planes [hi | lo] (x = hi + lo) -- the operand format of the split-bf16 GEMM.
     Same bytes as the fp32 [rows, cols] tensor it replaces.  `lo_off` = elements from the hi plane to the lo plane."""
-    __slots__ = ("buf", "rows", "cols", "lo_off")
+    __slots__ = ("buf", "rows", "cols", "lo_off", "transposed")
 
     def __init__(self, buf: torch.Tensor, rows: int, cols: int, lo_off: Optional[int] = None):
+        self.transposed = False      # True: this is W^T [in, out] of an nn.Linear weight (see split_planes_t)
         if buf.dtype != torch.int16 or not buf.is_cuda:
             raise TypeError("Planes storage must be an int16 HIP tensor")
         self.buf, self.rows, self.cols = buf, rows, cols
@@ -143,6 +144,17 @@ def split_planes(src: torch.Tensor, dst: Planes):
     _chk_f32(src)
     n = src.numel()
     _nat.check(_nat.lib().lr2_split_planes(src.data_ptr(), dst.data_ptr(), dst.lo_off, n, _stream()), "lr2_split_planes")
+    return dst
+
+
+def split_planes_t(src: torch.Tensor, dst: Planes):
+    """dst [C, R] planes = transpose of the fp32 matrix src [R, C]; marks dst as a transposed weight."""
+    _chk_f32(src)
+    R, C = src.shape
+    if dst.rows != C or dst.cols != R or not src.is_contiguous():
+        raise ValueError("split_planes_t: dst must be [C, R] planes of a contiguous [R, C] matrix")
+    _nat.check(_nat.lib().lr2_split_planes_t(src.data_ptr(), dst.data_ptr(), dst.lo_off, R, C, _stream()), "lr2_split_planes_t")
+    dst.transposed = True
     return dst
 
 

@@ -57,6 +57,9 @@ class TransformerEncoder(nn.Module):
                 pl = ops.Planes.empty(w.shape[0], w.shape[1], dev)
                 ops.split_planes(w.contiguous(), pl)
                 ent[name] = pl
+            # wide outputs (QKV, FFN1): the forward runs the NN form on W^T planes (~10 % faster than NT there)
+            for name, w in (("wqkv_t", wqkv), ("w1_t", ffn.linear_1.weight.data)):
+                ent[name] = ops.split_planes_t(w.contiguous(), ops.Planes.empty(w.shape[1], w.shape[0], dev))
             out.append(ent)
         self._wplanes = (sig, out)
         return out
@@ -96,16 +99,16 @@ class TransformerEncoder(nn.Module):
             ln1, ln2 = layer.layer_norm_1, layer.layer_norm_2
             if pre:                                                   # layers/transformer.py:63-73
                 ops.layernorm_fwd(h, ln1.gamma.data, ln1.beta.data, None, rows=M, D=E, eps=ln1.eps, mode=1, out_planes=x_p)
-            engine.linear_fwd(ws, x_p, w["wqkv"], w["bqkv"], None, M, 3 * E, E, out_planes=qkv_p)
+            engine.linear_fwd(ws, x_p, w["wqkv_t"], w["bqkv"], None, M, 3 * E, E, out_planes=qkv_p)
             ops.self_attn_fwd(qkv_p, seg, o_p, batch=B, heads=H, L=L, head_dim=hd, scale=scale)
             engine.linear_fwd(ws, o_p, w["wo"], att.final_linear.bias.data, h2, M, E, E, resid=h)
             if pre:
                 ops.layernorm_fwd(h2, ln2.gamma.data, ln2.beta.data, None, rows=M, D=E, eps=ln2.eps, mode=1, out_planes=t_p)
-                engine.linear_fwd(ws, t_p, w["w1"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_planes=ff_p)
+                engine.linear_fwd(ws, t_p, w["w1_t"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_planes=ff_p)
                 engine.linear_fwd(ws, ff_p, w["w2"], ffn.linear_2.bias.data, h, M, E, F, resid=h2)
             else:                                                     # layers/transformer.py:54-61
                 ops.layernorm_fwd(h2, ln1.gamma.data, ln1.beta.data, h, rows=M, D=E, eps=ln1.eps, mode=1, out_planes=t_p)
-                engine.linear_fwd(ws, t_p, w["w1"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_planes=ff_p)
+                engine.linear_fwd(ws, t_p, w["w1_t"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_planes=ff_p)
                 engine.linear_fwd(ws, ff_p, w["w2"], ffn.linear_2.bias.data, h2, M, E, F, resid=h)
                 ops.layernorm_fwd(h2, ln2.gamma.data, ln2.beta.data, h, rows=M, D=E, eps=ln2.eps, mode=1, out_planes=x_p)
         out = torch.empty(B, L, E, device=emb.device)
@@ -155,7 +158,7 @@ class TransformerEncoder(nn.Module):
             else:
                 x_p = h_p
             qkv_p, o_p, t1 = pl(M, 3 * E), pl(M, E), mat(M, E)
-            engine.linear_fwd(ws, x_p, w["wqkv"], w["bqkv"], None, M, 3 * E, E, out_planes=qkv_p)
+            engine.linear_fwd(ws, x_p, w["wqkv_t"], w["bqkv"], None, M, 3 * E, E, out_planes=qkv_p)
             ops.self_attn_fwd(qkv_p, seg, o_p, batch=B, heads=H, L=L, head_dim=hd, scale=scale, drop=drop(s0))
             engine.linear_fwd(ws, o_p, w["wo"], att.final_linear.bias.data, t1, M, E, E, resid=h, drop=drop(s0 + 1))
             z, ff_p = mat(M, F), pl(M, F)
@@ -164,7 +167,7 @@ class TransformerEncoder(nn.Module):
                 x2_p, S["m2"], S["r2"] = pl(M, E), vec(M), vec(M)
                 ops.layernorm_fwd(t1, ln2.gamma.data, ln2.beta.data, None, S["m2"], S["r2"], rows=M, D=E, eps=ln2.eps, mode=1,
                                   out_planes=x2_p)
-                engine.linear_fwd(ws, x2_p, w["w1"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_z=z, out_planes=ff_p)
+                engine.linear_fwd(ws, x2_p, w["w1_t"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_z=z, out_planes=ff_p)
                 hn = mat(M, E)
                 engine.linear_fwd(ws, ff_p, w["w2"], ffn.linear_2.bias.data, hn, M, E, F, resid=t1, drop=drop(s0 + 2))
                 S["x2_p"] = x2_p
@@ -173,7 +176,7 @@ class TransformerEncoder(nn.Module):
                 inter, inter_p, S["m1"], S["r1"] = mat(M, E), pl(M, E), vec(M), vec(M)
                 ops.layernorm_fwd(t1, ln1.gamma.data, ln1.beta.data, inter, S["m1"], S["r1"], rows=M, D=E, eps=ln1.eps, mode=1,
                                   out_planes=inter_p)
-                engine.linear_fwd(ws, inter_p, w["w1"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_z=z, out_planes=ff_p)
+                engine.linear_fwd(ws, inter_p, w["w1_t"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_z=z, out_planes=ff_p)
                 t2 = mat(M, E)
                 engine.linear_fwd(ws, ff_p, w["w2"], ffn.linear_2.bias.data, t2, M, E, F, resid=inter, drop=drop(s0 + 2))
                 hn, hn_p, S["m2"], S["r2"] = mat(M, E), pl(M, E), vec(M), vec(M)

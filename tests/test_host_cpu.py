@@ -118,7 +118,7 @@ def test_header_symbols_are_declared_bound_and_exported(native):
     exported = set(re.findall(r" T (lr2_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
     lib = native.lib()
-    assert lib.lr2_abi_version() == int(re.search(r"#define LR2_ABI_VERSION (\d+)", hdr).group(1)) == 8
+    assert lib.lr2_abi_version() == int(re.search(r"#define LR2_ABI_VERSION (\d+)", hdr).group(1)) == 9
 
 
 def test_ctypes_structs_have_the_layout_the_c_compiler_gives_the_header(native, tmp_path):

@@ -563,3 +563,24 @@ def test_gemm_fused_adamw_epilogue_equals_gemm_then_adamw(ops, dev, M, N, K, spl
         assert torch.equal(oa.state[pa]["exp_avg"], ob.state[pb]["exp_avg"])
         assert torch.equal(oa.state[pa]["exp_avg_sq"], ob.state[pb]["exp_avg_sq"])
     assert not torch.equal(pa.detach(), p0) and oa.state[pa]["step"] == ob.state[pb]["step"] == 2
+
+
+def test_split_planes_t_and_nn_forward_equals_nt(ops, dev):
+    """Transposed weight planes W^T: exact transpose of the plain split, and the forward GEMM on them (NN form) agrees with
+    the NT form on the original layout."""
+    g = torch.Generator().manual_seed(12)
+    w = _rand(g, 300, 200)                                  # ragged against the 32 x 32 transpose tiles
+    wt = ops.split_planes_t(w.to(dev), ops.Planes.empty(200, 300, dev))
+    ref = _planes(ops, w, dev)
+    n = 300 * 200
+    assert torch.equal(wt.buf[:n].view(200, 300), ref.buf[:n].view(300, 200).t())
+    assert torch.equal(wt.buf[wt.lo_off:wt.lo_off + n].view(200, 300), ref.buf[ref.lo_off:ref.lo_off + n].view(300, 200).t())
+    assert wt.transposed and not ref.transposed
+    M, N, K = 260, 384, 192
+    x, w = _rand(g, M, K), _rand(g, N, K)
+    xp = _planes(ops, x, dev)
+    o_nt, o_nn = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    ops.gemm(xp, _planes(ops, w, dev), o_nt, M, N, K)
+    ops.gemm(xp, ops.split_planes_t(w.to(dev), ops.Planes.empty(K, N, dev)), o_nn, M, N, K, trans_b=True, ldb=N)
+    _close(o_nn, x.double() @ w.double().t(), atol=6e-5 * math.sqrt(K), rtol=5e-5, what="NN on W^T")
+    _close(o_nn, o_nt.double(), atol=1e-5 * math.sqrt(K), rtol=1e-5, what="NN vs NT")

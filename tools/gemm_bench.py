@@ -17,6 +17,9 @@ SHAPES = [  # (form, M, N, K) as ops.gemm sees them
     ("NT", 4096, 4096, 4096),
     # dual-encoder forward at batch 32 (M = 32 * 197)
     ("NT", 6304, 2304, 768), ("NT", 6304, 768, 768), ("NT", 6304, 3072, 768), ("NT", 6304, 768, 3072),
+    # NT vs NN (forward on W or on W^T) at the encoder's shapes
+    ("NN", 6304, 2304, 768), ("NN", 6304, 3072, 768), ("NT", 100864, 2304, 768), ("NN", 100864, 2304, 768),
+    ("NT", 100864, 3072, 768), ("NN", 100864, 3072, 768),
 ]
 
 
