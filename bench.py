@@ -54,11 +54,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    local = local % torch.cuda.device_count()        # rehearsals of N > 1 on a one-GPU box share the device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL ("nccl") is the product path; LR2_BENCH_BACKEND=gloo exists only to rehearse the N > 1 code on one GPU
+        dist.init_process_group(os.environ.get("LR2_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     if a.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
