@@ -169,7 +169,10 @@ def evaluate(args, model, dataloader, step, split="test", num_tasks=None):
     local = []
     for text_emb, img_emb, tgts in dataloader:
         logits = model.engine_forward(text_emb.to(args.device), img_emb.to(args.device), save=False)
-        local.append((logits.view(-1).cpu(), tgts.view(-1).cpu()))
+        local.append((logits.view(-1), tgts.view(-1).cpu()))
+    if local:                                   # one device-to-host copy for the whole split
+        flat = torch.cat([s for s, _ in local]).cpu()
+        local = [(c, g) for c, (_, g) in zip(torch.split(flat, [s.numel() for s, _ in local]), local)]
     vecs = [ndcg_obj.return_ndcg_at_k_from_scores(s, g) for s, g in local]
     mine = torch.stack(vecs) if vecs else torch.zeros(0, len(ndcg_obj.ndcg_at_k))
     world = num_tasks or 1

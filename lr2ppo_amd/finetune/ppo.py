@@ -652,7 +652,11 @@ def evaluate(args, val_loader, step, split="test", num_tasks=None):
         text_emb = text_emb.to(args.device)
         img_emb = img_emb.to(args.device)            # [1, n_img, 768]: shared by all tags of the item
         logits = args.model.actor.engine_forward(text_emb, img_emb, save=False)
-        local.append((logits.view(-1).cpu(), tgts.view(-1).cpu()))
+        local.append((logits.view(-1), tgts.view(-1).cpu()))
+    # one device-to-host copy for the whole split (the reference synchronises once per item, finetune/ppo.py:640-655)
+    if local:
+        flat = torch.cat([s for s, _ in local]).cpu()
+        local = [(c, g) for c, (_, g) in zip(torch.split(flat, [s.numel() for s, _ in local]), local)]
     vecs = [ndcg_obj.return_ndcg_at_k_from_scores(s, g) for s, g in local]
     mine = torch.stack(vecs) if vecs else torch.zeros(0, len(ndcg_obj.ndcg_at_k))
     world = num_tasks or 1
