@@ -75,8 +75,9 @@ class MovieNet(Dataset):
                 by_label = {c: [i for i, t in enumerate(tags) if int(t["target"]) == c] for c in range(3)}
                 if min(len(v) for v in by_label.values()) == 0:
                     continue
-                for _ in range(self.max_tags):
-                    triple = [by_label[c][random.randint(0, len(by_label[c]) - 1)] for c in range(3)]
+                triples = [[by_label[c][random.randint(0, len(by_label[c]) - 1)] for c in range(3)]
+                           for _ in range(self.max_tags)]        # upstream draws all triples first, then orders each
+                for triple in triples:
                     chosen, reject = get_index([tags[i] for i in triple])
                     self.items.append((item["id"], triple, [int(tags[i]["target"]) for i in triple], chosen, reject))
 

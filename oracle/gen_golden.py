@@ -553,6 +553,34 @@ def gen_embeddings_bwd():
     _save("embeddings_bwd_small.npz", **arrays)
 
 
+def gen_readers():
+    """Outputs of the reference's three LRMovieNet readers on the in-memory stand-in of oracle.fake_movienet (fake
+    h5py.File, temp json), RNGs seeded: first items of every split, as plain integers."""
+    import random
+    import tempfile
+    import ppo
+    import pointwise
+    import reward_pair_dataloader as rp
+    items, h5 = O.fake_movienet()
+    sys.modules["h5py"].File = lambda *a, **k: h5
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump(items, f)
+        path = f.name
+    out = {}
+    for name, mod, max_tags in (("ppo", ppo, 4), ("pointwise", pointwise, 6), ("reward_pair", rp, 4)):
+        for is_train in (True, False):
+            random.seed(11), np.random.seed(12), torch.manual_seed(13)
+            ds = mod.MovieNet(_ns(is_master=False, max_imgs=16, max_tags=max_tags), path, is_train=is_train)
+            torch.manual_seed(14)
+            n = len(ds)
+            out[f"{name}_{'train' if is_train else 'val'}"] = {"len": n, "max_tags": max_tags,
+                                                              "items": [O.describe_reader_item(ds[i]) for i in range(min(n, 12))]}
+    os.unlink(path)
+    with open(os.path.join(GOLD, "readers.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote readers.json", {k: v["len"] for k, v in out.items()})
+
+
 def gen_encoder_full():
     """ViT-B/16 and RoBERTa-base stacks from the shipped JSON configs, seeded weights, eval."""
     from tencentpretrain.embeddings import Embedding, str2embedding
@@ -605,7 +633,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

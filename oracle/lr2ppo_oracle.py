@@ -540,3 +540,36 @@ def stage2_loss(P: Params, batch, drop=None):
     scores = critic_forward(P, torch.cat([text, text]), torch.cat([img, img]), torch.cat([chosen, reject]), n_pos=4, drop=drop)
     loss, acc = pair_hinge(scores[:bs], scores[bs:])
     return loss, acc, scores
+
+
+# ---------------------------------------------------------------------------------------------
+# A13 / 8f-3: a small in-memory stand-in for LRMovieNet (clean_feat.h5 + the split json) so that the three readers can be
+# exercised without h5py or data.  Feature VALUES encode their origin: text_emb[t] == 100 * item + t everywhere and image
+# row j == 1000 * item + j, so a reader's tag selection, image shuffle and cyclic padding can be read back from its output.
+# ---------------------------------------------------------------------------------------------
+def fake_movienet(seed: int = 3, n_items: int = 5):
+    """-> (items, h5) where items is the split json (id, tags[{target}], index[[a, b], ...]) and h5 mimics
+    h5py.File: h5[str(id)]["text_emb"][:] -> [n_tags, 2, 4], h5[str(id)]["img_emb"][:] -> [1, n_img, 768]."""
+    rng = np.random.RandomState(seed)
+    items, h5 = [], {}
+    for i in range(n_items):
+        n_tags = int(rng.randint(3, 9))
+        n_img = int(rng.randint(3, 24))
+        targets = [int(t) for t in rng.randint(0, 3, size=n_tags)]
+        targets[:3] = [0, 1, 2]                                   # every label present: the stage-2 val reader keeps the item
+        pairs = [[int(a), int(b)] for a, b in (rng.choice(n_tags, 2, replace=False) for _ in range(3))]
+        items.append({"id": i, "tags": [{"target": t} for t in targets], "index": pairs})
+        text = np.zeros((n_tags, 2, 4), dtype=np.float32) + (100 * i + np.arange(n_tags, dtype=np.float32))[:, None, None]
+        img = np.zeros((1, n_img, 768), dtype=np.float32) + (1000 * i + np.arange(n_img, dtype=np.float32))[None, :, None]
+        h5[str(i)] = {"text_emb": text, "img_emb": img}
+    return items, h5
+
+
+def describe_reader_item(sample):
+    """Reader output -> plain ints: which tags / image rows it holds (see fake_movienet's value encoding)."""
+    text, img, tgt = sample[0], sample[1], sample[2]
+    out = {"tags": [int(v) for v in text[:, 0, 0].tolist()], "img_rows": [int(v) for v in img[:, 0].tolist()],
+           "tgts": [int(v) for v in tgt.tolist()]}
+    if len(sample) > 3:
+        out["chosen"], out["reject"] = [int(v) for v in sample[3].tolist()], [int(v) for v in sample[4].tolist()]
+    return out

@@ -222,3 +222,33 @@ def test_stage_launcher_arguments_parse():
     assert a.batch_size == 2 and a.max_tags == 20 and a.mode == "reg"
     b = rp.build_parser().parse_args(common + ["--batch_size", "64", "--report_steps", "100", "--mode", "cls"])
     assert b.batch_size == 64 and b.mode == "cls"
+
+
+def test_movienet_readers_match_reference_on_a_fake_h5(tmp_path, monkeypatch):
+    """A13 / 8f-3: the three LRMovieNet readers (stage 1, 2, 3; train and validation splits) against the outputs of the
+    reference's readers on the same in-memory stand-in for clean_feat.h5 (tests/golden/readers.json): tag selection and
+    padding, pair layouts, get_index ordering, image shuffle + cyclic padding, labels -- with the RNGs seeded alike."""
+    import random
+    import sys
+    import types
+    from oracle import lr2ppo_oracle as O
+    from lr2ppo_amd.finetune import pointwise as pw, ppo, reward_pair_dataloader as rp
+    items, h5 = O.fake_movienet()
+    fake = types.ModuleType("h5py")
+    fake.File = lambda *a, **k: h5
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    path = tmp_path / "split.json"
+    path.write_text(json.dumps(items))
+    with open(os.path.join(GOLD, "readers.json")) as f:
+        gold = json.load(f)
+    for name, mod in (("ppo", ppo), ("pointwise", pw), ("reward_pair", rp)):
+        for split in ("train", "val"):
+            g = gold[f"{name}_{split}"]
+            random.seed(11), np.random.seed(12), torch.manual_seed(13)
+            ds = mod.MovieNet(argparse.Namespace(is_master=False, max_imgs=16, max_tags=g["max_tags"]), str(path),
+                              is_train=split == "train")
+            torch.manual_seed(14)
+            assert len(ds) == g["len"], (name, split)
+            for i, want in enumerate(g["items"]):
+                got = O.describe_reader_item(ds[i])
+                assert got == want, (name, split, i, got, want)
