@@ -221,6 +221,10 @@ def choose_tiling(M: int, N: int, K: int, trans_a: bool, trans_b: bool = False):
             return 64, 1
     k_tiles = (K + 63) // 64
     slots = 768 if bm == 64 else 512
+    if bm == 128 and not trans_a and tiles < 512 and K <= 1024 and ((M + 63) // 64) * ((N + 127) // 128) >= 64:
+        # small short-K GEMMs (image tokens: M = 1024, K = 768): one pass of 64-row tiles beats split-K + its reduce launch
+        # (NT 1024x768x768: 16.6 vs 19.0 us, NN 1024x3072x768: 21.9 vs 28.7 us)
+        return 64, 1
     if tiles >= slots or k_tiles < 8:
         return bm, 1
     slab_cost = M * N * 6.4e-7            # one fp32 slab written + read, in units of one K-tile step (~2.5 us)

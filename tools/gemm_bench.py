@@ -20,6 +20,9 @@ SHAPES = [  # (form, M, N, K) as ops.gemm sees them
     # NT vs NN (forward on W or on W^T) at the encoder's shapes
     ("NN", 6304, 2304, 768), ("NN", 6304, 3072, 768), ("NT", 100864, 2304, 768), ("NN", 100864, 2304, 768),
     ("NT", 100864, 3072, 768), ("NN", 100864, 3072, 768),
+    # small GEMMs of the PPO step (image tokens, tail, out_layer.fc2): where split-K + its reduce launch compete with one pass
+    ("NT", 1024, 768, 768), ("NN", 1024, 3072, 768), ("NT", 1024, 768, 3072), ("NT", 64, 768, 3072), ("NT", 256, 768, 768),
+    ("TN", 768, 768, 1024), ("TN", 3072, 768, 1024), ("NN", 1024, 768, 3072),
 ]
 
 
