@@ -1,0 +1,190 @@
+"""The `_trad` pointwise ranker on MI355X -- drop-in for the model / step of the reference's finetune/pointwise_trad.py
+(BASELINE.json configs[0], the reference's own small "plumbing" case).
+
+`Classifier` (pointwise_trad.py:132-177) is the LR2PPO head at sequence length 1: one pre-projected 768-d feature per
+document serves as both streams of the XiT block, is concatenated behind the block's output, and goes through
+out_layer = Mlp(1536, 3072, 768) and a Linear(768, 1) head; SmoothL1(beta=0.3) against the relevance label, AdamW,
+per-batch scheduler.  Same kernels and engine schedule as stage 3 (`engine.xit_forward / xit_backward`, fused GEMM epilogues,
+`lr2_smooth_l1`, `lr2_adamw_multi`); mode 'reg' only.  The LETOR h5 reader (`LTRDataset`, needs h5py + pandas-made files)
+is not rebuilt: `SyntheticLTR` provides data of its shapes.  No CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+from torch.utils.data import Dataset
+
+from .. import engine, ops, runtime
+from ..tencentpretrain.utils.optimizers import str2optimizer, str2scheduler
+from .ppo import FEAT, Mlp, _grouped, _init_normal
+from .xit import XiT
+
+OUT_FC1, OUT_FC2 = "out_layer.fc1.weight", "out_layer.fc2.weight"
+
+
+class Classifier(nn.Module):
+    """pointwise_trad.py:132-177.  forward(text_emb [bs, docs, 768], img_emb (ignored, as upstream), tgts) ->
+    (loss, logits [bs*docs, 1]) or logits."""
+
+    def __init__(self, args, vit_args=None):
+        super().__init__()
+        self.mode, self.labels_num = args.mode, args.labels_num
+        if self.mode != "reg":
+            raise NotImplementedError("the HIP path implements mode='reg'")
+        self.xit = XiT(feat_size=FEAT)
+        self.out_layer = Mlp(2 * FEAT, 4 * FEAT, FEAT, nn.GELU, 0)
+        self.head = nn.Linear(FEAT, 1)
+        self._ws: Optional[engine.Workspace] = None
+        self._wp: Optional[engine.WeightPlanes] = None
+        self._G: Optional[Dict[str, torch.Tensor]] = None
+        self._saved = None
+
+    # ---- plumbing ----
+    def _P(self):
+        return {n: p.data for n, p in self.named_parameters()}
+
+    def _weights(self, P):
+        if self._wp is None or not self._wp.matches(P):
+            self._wp = engine.WeightPlanes(P, engine.XIT.gemm_weights() + [OUT_FC1, OUT_FC2],
+                                           transposed=[engine.XIT.f1_w, OUT_FC1])
+        self._wp.refresh()
+        return self._wp.planes
+
+    def grad_buffers(self):
+        dev = next(self.parameters()).device
+        if self._G is None or next(iter(self._G.values())).device != dev:
+            self._G = {n: torch.zeros_like(p) for n, p in self.named_parameters()}
+        return self._G
+
+    def bind_grads(self):
+        for n, p in self.named_parameters():
+            p.grad = self.grad_buffers()[n]
+
+    # ---- engine schedule ----
+    @torch.no_grad()
+    def engine_forward(self, text_emb, *, save: bool):
+        if text_emb.dtype != torch.float32 or not text_emb.is_cuda:
+            raise TypeError("lr2ppo_amd: text_emb must be a float32 tensor on the HIP device (no CPU path)")
+        if text_emb.dim() != 3 or text_emb.shape[-1] != FEAT:
+            raise ValueError(f"text_emb must be [bs, docs, {FEAT}] (pointwise_trad.py:146-152)")
+        dev = text_emb.device
+        if self._ws is None or self._ws.device != dev:
+            self._ws = engine.Workspace(dev)
+        ws, P = self._ws, self._P()
+        W = self._weights(P)
+        N, E, F = text_emb.shape[0] * text_emb.shape[1], FEAT, 4 * FEAT
+        x0 = text_emb.contiguous().view(N, E)
+        drop = runtime.next_drop(engine.DROP_P, 0) if self.training else None
+        cat = ws.planes("cat", N, 2 * E)                         # [XiT(x0, x0) | x0]  (pointwise_trad.py:154-155)
+        ops.copy_rows(x0, cat, rows=N, D=E, group=1, dst_gstride=2 * E, dst_off=E)
+        engine.xit_forward(ws, "xit.", P, W, engine.XIT, x0, x0, N, 1, 1, E, cat, save=save, drop=drop, out_group=1,
+                           out_gstride=2 * E)
+        g1 = ws.planes("g1", N, F)
+        zo = ws.mat("zo", N, F) if save else None
+        engine.linear_fwd(ws, cat, engine.fwd_weight(W, OUT_FC1), P["out_layer.fc1.bias"], None, N, F, 2 * E, act=1, out_z=zo,
+                          out_planes=g1)
+        g2 = ws.mat("g2", N, E)
+        engine.linear_fwd(ws, g1, W[OUT_FC2], P["out_layer.fc2.bias"], g2, N, E, F)
+        logits = torch.empty(N, device=dev)
+        ops.head_fwd(g2, P["head.weight"], P["head.bias"], logits, rows=N, D=E)
+        if save:
+            self._saved = (x0, N, drop)
+        return logits.view(-1, 1)
+
+    @torch.no_grad()
+    def engine_backward(self, dlogits):
+        x0, N, drop = self._saved
+        ws, P, G = self._ws, self._P(), self.grad_buffers()
+        W = self._wp.planes
+        E, F = FEAT, 4 * FEAT
+        cat, g1, zo, g2 = ws.planes("cat", N, 2 * E), ws.planes("g1", N, F), ws.mat("zo", N, F), ws.mat("g2", N, E)
+        dg2 = ws.mat("dg2", N, E)
+        ops.head_bwd(g2, P["head.weight"], dlogits.contiguous().view(-1), dg2, G["head.weight"], G["head.bias"], rows=N, D=E)
+        dg2p = ops.split_planes(dg2, ws.planes("dg2p", N, E))
+        engine.linear_wgrad(ws, dg2p, g1, G[OUT_FC2], G["out_layer.fc2.bias"], N, F, E)
+        dzo = ws.planes("dzo", N, F)
+        engine.linear_dgrad(ws, dg2p, W[OUT_FC2], None, N, F, E, act=2, aux_z=zo, out_planes=dzo)
+        engine.linear_wgrad(ws, dzo, cat, G[OUT_FC1], G["out_layer.fc1.bias"], N, 2 * E, F)
+        dcat = ws.mat("dcat", N, 2 * E)
+        engine.linear_dgrad(ws, dzo, W[OUT_FC1], dcat, N, 2 * E, F)
+        # the feature is data: only the block's parameters need gradients; d(out)/d(block output) = dcat[:, :E]
+        engine.xit_backward(ws, "xit.", P, W, G, engine.XIT, x0, x0, dcat, N, 1, 1, E, ws.mat("dx0", N, E), None, drop=drop,
+                            out_group=1, out_gstride=2 * E, same_xy=True)
+        self._saved = None
+
+    def forward(self, text_emb, img_emb=None, tgts=None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            logits = _TradFn.apply(self, text_emb, *list(self.parameters()))
+        else:
+            logits = self.engine_forward(text_emb, save=False)
+        if tgts is None:
+            return logits
+        return nn.SmoothL1Loss(beta=0.3)(logits.view(-1), tgts.view(-1).to(torch.float32)), logits
+
+
+class _TradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, text_emb, *params):
+        ctx.model = model
+        return model.engine_forward(text_emb, save=True)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        m = ctx.model
+        m.engine_backward(dlogits.contiguous())
+        G = m.grad_buffers()
+        return (None, None) + tuple(G[n].clone() if p.requires_grad else None for n, p in m.named_parameters())
+
+
+def load_or_initialize_parameters(args, model):
+    """pointwise_trad.py:179-211 (see lr2ppo_amd/finetune/pointwise.py for the strict=False quirk)."""
+    if getattr(args, "pretrained_model_path", None) is not None:
+        model.load_state_dict(torch.load(args.pretrained_model_path, map_location="cpu"), strict=False)
+    else:
+        _init_normal(model)
+
+
+def build_optimizer(args, model):
+    """pointwise_trad.py:214-237."""
+    if args.optimizer not in str2optimizer:
+        raise NotImplementedError(f"optimizer {args.optimizer!r}: only adamw is on the HIP path")
+    optimizer = str2optimizer[args.optimizer](_grouped(list(model.named_parameters())), lr=args.learning_rate,
+                                              correct_bias=False)
+    if args.scheduler in ["constant"]:
+        scheduler = str2scheduler[args.scheduler](optimizer)
+    elif args.scheduler in ["constant_with_warmup"]:
+        scheduler = str2scheduler[args.scheduler](optimizer, args.train_steps * args.warmup)
+    else:
+        scheduler = str2scheduler[args.scheduler](optimizer, args.train_steps * args.warmup, args.train_steps)
+    return optimizer, scheduler
+
+
+def train_model(args, model, optimizer, scheduler, text_emb_batch, img_emb_batch, tgts_batch):
+    """One batch (pointwise_trad.py:240-255) on the engine path -> loss (0-dim device tensor)."""
+    dev = text_emb_batch.device
+    model.bind_grads()
+    logits = model.engine_forward(text_emb_batch, save=True).view(-1)
+    target = tgts_batch.to(device=dev, dtype=torch.float32).contiguous().view(-1)
+    loss, dlogits = torch.empty(1, device=dev), torch.empty_like(logits)
+    ops.smooth_l1(logits, target, loss, dlogits, n=logits.numel(), beta=0.3)
+    model.engine_backward(dlogits)
+    optimizer.step()
+    scheduler.step()
+    return loss[0]
+
+
+class SyntheticLTR(Dataset):
+    """Seeded stand-in with LTRDataset's item shape (pointwise_trad.py:88-109): 20 documents per query, 768-d features,
+    labels in {0, 1, 2}."""
+
+    def __init__(self, n_queries, docs=20, seed=7):
+        self.n, self.docs, self.seed = n_queries, docs, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        return torch.randn(self.docs, FEAT, generator=g), torch.zeros(1), torch.randint(0, 3, (self.docs,), generator=g)

@@ -581,6 +581,39 @@ def gen_readers():
     print("wrote readers.json", {k: v["len"] for k, v in out.items()})
 
 
+def gen_trad():
+    """BASELINE configs[0]: finetune/pointwise_trad.py's Classifier (seq-len-1 XiT head on 768-d document features),
+    the config SURVEY 8d describes (2 queries x 20 documents): three train_model steps in eval mode + an inference pass."""
+    import pointwise_trad as pt
+    bs, docs, steps = 2, 20, 3
+    args = _ns(mode="reg", labels_num=3, optimizer="adamw", scheduler="linear", learning_rate=1e-3, train_steps=21, warmup=0.1)
+    model = pt.Classifier(args, None)
+    assert _spec_of(model) == [[n, list(sh)] for n, sh in O.trad_param_spec()]
+    _load(model, O.seeded_params(O.trad_param_spec(), seed=27))
+    opt, sch = pt.build_optimizer(args, model)
+    model.eval()
+    named = dict(model.named_parameters())
+    names = ["xit.0.0.0.fn.0.ln_x.weight", "xit.0.0.0.fn.1.queries.weight", "xit.0.0.0.fn.1.projection.bias",
+             "xit.0.0.1.fn.1.0.weight", "xit.1.0.bias", "out_layer.fc1.weight", "out_layer.fc2.weight", "head.weight", "head.bias"]
+    idx = _sampled(named, names, 277)
+    arrays = {"bs": np.array(bs), "docs": np.array(docs), "steps": np.array(steps)}
+    for n in names:
+        arrays["idx." + n] = idx[n]
+    g = torch.Generator().manual_seed(28)
+    for step in range(steps):
+        feats = torch.randn(bs, docs, 768, generator=g)
+        tgts = torch.randint(0, 3, (bs, docs), generator=g).float()
+        arrays[f"feats_{step}"], arrays[f"tgts_{step}"] = feats, tgts
+        arrays[f"lr_{step}"] = np.array(opt.param_groups[0]["lr"])
+        loss = pt.train_model(args, model, opt, sch, feats, None, tgts)
+        arrays[f"loss_{step}"] = loss.detach().clone()
+        for n in names:
+            arrays[f"w{step}." + n] = named[n].detach().flatten()[idx[n]].clone()
+    with torch.no_grad():
+        arrays["eval_logits"] = model(arrays["feats_0"], None, None).clone()
+    _save("trad_step.npz", **arrays)
+
+
 def gen_encoder_full():
     """ViT-B/16 and RoBERTa-base stacks from the shipped JSON configs, seeded weights, eval."""
     from tencentpretrain.embeddings import Embedding, str2embedding
@@ -633,7 +666,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, trad=gen_trad)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

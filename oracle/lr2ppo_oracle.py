@@ -573,3 +573,24 @@ def describe_reader_item(sample):
     if len(sample) > 3:
         out["chosen"], out["reject"] = [int(v) for v in sample[3].tolist()], [int(v) for v in sample[4].tolist()]
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[0] ("plumbing" case): the *_trad Classifier -- the same XiT / Mlp head on one pre-projected
+# 768-d feature per document, sequence length 1 (finetune/pointwise_trad.py:132-177).
+# ---------------------------------------------------------------------------------------------
+def trad_param_spec(feat: int = FEAT):
+    return _xit_spec("xit", feat) + _mlp_spec("out_layer", 2 * feat, 4 * feat, feat) + [("head.weight", (1, feat)), ("head.bias", (1,))]
+
+
+def trad_forward(P: Params, text_emb: torch.Tensor, tgts=None, drop=None):
+    """pointwise_trad.Classifier.forward, mode 'reg': text_emb [bs, docs, 768] -> (SmoothL1 loss, logits[bs*docs, 1]) or
+    logits.  The document feature is both streams of the XiT block (:154) and is concatenated behind its output (:155)."""
+    bs, docs = text_emb.shape[:2]
+    f = text_emb.to(torch.float32).reshape(bs * docs, 1, FEAT)
+    x = xit(P, "xit", f, f, drop=drop)
+    x = mlp(P, "out_layer", torch.cat([x, f], dim=1).reshape(bs * docs, -1))
+    logits = linear(P, "head", x).view(-1, 1)
+    if tgts is None:
+        return logits
+    return smooth_l1(logits.view(-1), tgts.view(-1).to(torch.float32)), logits

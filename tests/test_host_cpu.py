@@ -181,7 +181,9 @@ def test_stage1_stage2_modules_mirror_the_reference_surface():
     """finetune/pointwise.py and finetune/reward_pair_dataloader.py: same public names; host-side helpers checked
     against fixtures generated from the imported reference (get_index) or worked out from pointwise.py:96-119."""
     import random
-    from lr2ppo_amd.finetune import pointwise as pw, reward_pair_dataloader as rp
+    from lr2ppo_amd.finetune import pointwise as pw, pointwise_trad as pt, reward_pair_dataloader as rp
+    for n in ("Mlp", "Classifier", "load_or_initialize_parameters", "build_optimizer", "train_model"):
+        assert hasattr(pt, n), n
     for n in ("get_scores", "log_sig", "get_def_cls", "MovieNet", "Mlp", "Classifier", "load_or_initialize_parameters",
               "build_optimizer", "train_model", "evaluate", "get_dataloader", "main"):
         assert hasattr(pw, n), n

@@ -275,3 +275,22 @@ def test_embedding_backward_oracle_matches_reference_autograd():
     for k in P:
         ref = g["txt_grad." + k]
         assert (P[k].grad - ref).abs().max() < 1e-5 * max(1.0, float(ref.abs().max())), k
+
+
+def test_trad_classifier_train_steps_match_reference():
+    """BASELINE configs[0]: the seq-len-1 `_trad` head (finetune/pointwise_trad.py) -- three train steps + inference."""
+    g = load_golden("trad_step.npz")
+    steps = int(g["steps"])
+    P = O.seeded_params(O.trad_param_spec(), seed=27)
+    batches = [(g[f"feats_{s}"], g[f"tgts_{s}"]) for s in range(steps)]
+    outs = O.sgd_free_train_steps(P, lambda Pg, b: O.trad_forward(Pg, b[0], b[1]), batches, 1e-3, 2.1, 21)
+    for s in range(steps):
+        ref = float(g[f"loss_{s}"])
+        assert abs(float(outs[s][0]) - ref) < 2e-5 * max(1.0, abs(ref)), s
+    for key in [k for k in g if k.startswith(f"w{steps - 1}.")]:
+        n = key[len(f"w{steps - 1}."):]
+        assert (P[n].flatten()[g["idx." + n]] - g[key]).abs().max() < 2e-6, n
+    with torch.no_grad():
+        logits = O.trad_forward(P, g["feats_0"])
+    ref = g["eval_logits"]
+    assert (logits - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))

@@ -129,3 +129,51 @@ def test_pair_hinge_kernel(dev):
         loss.backward()
         assert abs(float(out[0]) - float(loss)) < 1e-5 and abs(float(out[1]) - float(acc)) < 1e-6
         assert torch.allclose(ds.cpu().double(), sc.grad, atol=1e-7)
+
+
+def test_trad_classifier_matches_reference_golden(dev):
+    """BASELINE configs[0] (finetune/pointwise_trad.py, 2 queries x 20 documents, 768-d features): three train steps and an
+    inference pass of the seq-len-1 head against the imported reference."""
+    from lr2ppo_amd.finetune import pointwise_trad as pt
+    g = load_golden("trad_step.npz")
+    steps = int(g["steps"])
+    args = argparse.Namespace(mode="reg", labels_num=3, optimizer="adamw", scheduler="linear", learning_rate=1e-3, train_steps=21,
+                              warmup=0.1)
+    model = pt.Classifier(args, None)
+    model.load_state_dict(O.seeded_params(O.trad_param_spec(), seed=27), strict=True)
+    model = model.to(dev).eval()
+    opt, sch = pt.build_optimizer(args, model)
+    named = dict(model.named_parameters())
+    for step in range(steps):
+        assert abs(opt.param_groups[0]["lr"] - float(g[f"lr_{step}"])) < 1e-12
+        loss = pt.train_model(args, model, opt, sch, g[f"feats_{step}"].to(dev), None, g[f"tgts_{step}"].to(dev))
+        ref = float(g[f"loss_{step}"])
+        assert abs(float(loss) - ref) < 2e-5 * max(1.0, abs(ref)), step
+        _check_weights(g, named, step, "trad")
+    with torch.no_grad():
+        logits = model(g["feats_0"].to(dev), None, None).cpu()
+    ref = g["eval_logits"]
+    assert logits.shape == ref.shape and (logits - ref).abs().max() < 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_trad_classifier_dropout_and_autograd_match_oracle(dev):
+    from lr2ppo_amd import runtime
+    from lr2ppo_amd.finetune import pointwise_trad as pt
+    g = load_golden("trad_step.npz")
+    P = O.seeded_params(O.trad_param_spec(), seed=27)
+    model = pt.Classifier(argparse.Namespace(mode="reg", labels_num=3), None)
+    model.load_state_dict(P, strict=True)
+    model = model.to(dev).train()
+    runtime.set_dropout_seed(909, calls=1)
+    seed = runtime.peek_drop_seed()
+    feats, tgts = g["feats_1"], g["tgts_1"]
+    loss, logits = model(feats.to(dev), None, tgts.to(dev))          # drop-in autograd path
+    loss.backward()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref_loss, ref_logits = O.trad_forward(Pg, feats, tgts, drop={"p": 0.1, "seed": seed, "site_base": 0})
+    ref_loss.backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-4 and (logits.cpu() - ref_logits.detach()).abs().max() < 1e-3
+    for n, p in model.named_parameters():
+        ref = Pg[n].grad
+        err = (p.grad.cpu() - ref).abs().max().item()
+        assert err < 1e-6 + 2e-3 * ref.abs().max().item(), f"grad {n}: {err} vs {ref.abs().max().item()}"
