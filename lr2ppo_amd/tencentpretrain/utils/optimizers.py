@@ -69,7 +69,9 @@ class AdamW(Optimizer):
         ps = [p for p in group["params"] if p.grad is not None and id(p) not in self._external]
         if not ps:
             return None, 0, ps, 0
-        sig = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
+        # the table holds raw pointers: parameters, gradients AND both moment tensors (load_state_dict replaces the latter)
+        sig = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel(), self._ensure_state(p)["exp_avg"].data_ptr(),
+                     self.state[p]["exp_avg_sq"].data_ptr()) for p in ps)
         gi = (gi, len(ps))        # separate cached tables with / without externally updated parameters
         cached = self._tables.get(gi)
         if cached is not None and cached[0] == sig:

@@ -293,3 +293,57 @@ def test_evaluate_ndcg_matches_oracle_scores(dev):
     for j, k in enumerate((1, 3, 5, 10, 20, 100000000)):
         assert abs(got[k] - float(ref[j])) <= 0.002, (k, got[k], float(ref[j]))
     assert abs(float(vals) - float(ref[5])) <= 0.002
+
+
+def test_full_batch_properties(dev):
+    """BASELINE-size batch (32 items x 2 tags), where the CPU oracle is too slow to be the checker: size-independent
+    properties of the HIP path.  (1) determinism: the same rollout twice gives the same bits; (2) items are independent:
+    permuting the batch permutes scores / values / rewards bit for bit; (3) an update at lr = 0 leaves every weight
+    untouched while still producing finite metrics; (4) the fused and the separate out_layer.fc1 update agree bit for bit."""
+    import copy
+    from lr2ppo_amd import runtime
+    from lr2ppo_amd.finetune import ppo
+    bs, tags = 32, 2
+    args = _ns(**ARGS, is_master=False, kl_div_loss_weight=0.001, entropy_weight=0.001, value_clip=0.5, optimizer="adamw",
+               scheduler="linear", learning_rate=1e-3, critic_learning_rate=1e-3, train_steps=100, warmup=0.1, device=dev)
+    torch.manual_seed(3)
+    model = ppo.ActorCritic(args, None)
+    reward = ppo.Reward(args, None)
+    ppo._init_normal(model.actor), ppo._init_normal(model.critic), ppo._init_normal(reward)
+    model, reward = model.to(dev).eval(), reward.to(dev).eval()
+    g = torch.Generator().manual_seed(4)
+    text = torch.randn(bs, tags, 196, 768, generator=g).to(dev)
+    img = torch.randn(bs, 16, 768, generator=g).to(dev)
+    tgts = torch.randint(0, 3, (bs, tags), generator=g).to(dev)
+    rec = ppo.rollout_step(model, reward, text, img, tgts)
+    rec2 = ppo.rollout_step(model, reward, text, img, tgts)
+    for a, b in zip(rec[1:5], rec2[1:5]):
+        assert torch.equal(a, b)                                           # (1)
+    perm = torch.randperm(bs, generator=g).to(dev)
+    recp = ppo.rollout_step(model, reward, text[perm].contiguous(), img[perm].contiguous(), tgts[perm].contiguous())
+    for a, b in zip(rec[1:5], recp[1:5]):
+        assert torch.equal(a[perm], b)                                     # (2)
+    opt, copt, sch, csch = ppo.build_optimizer(args, model)                # LambdaLR: lr = 0 until the first scheduler.step()
+    before = {n: p.detach().clone() for n, p in model.named_parameters() if "fc1.weight" not in n or "out_layer" not in n}
+    probe = model.actor.out_layer.fc1.weight[:8, :256].clone()
+    model.train()
+    out = ppo.train_model(args, model, opt, copt, sch, csch, [rec], 1)
+    assert all(v == v and abs(v) < 1e6 for v in out)
+    for n, p in model.named_parameters():
+        if n in before:
+            assert torch.equal(p.detach(), before[n]), n                   # (3)
+    assert torch.equal(probe, model.actor.out_layer.fc1.weight[:8, :256])
+    # (4): one more cycle (lr > 0 now) from identical state, fused vs separate
+    state = copy.deepcopy({"m": model.state_dict(), "o": opt.state_dict(), "c": copt.state_dict()})
+    results = []
+    for fuse in (True, False):
+        model.load_state_dict(state["m"])
+        opt.load_state_dict(copy.deepcopy(state["o"])), copt.load_state_dict(copy.deepcopy(state["c"]))
+        args.fuse_fc1_update = fuse
+        runtime.set_dropout_seed(77)
+        ppo.update_minibatch(args, model, opt, copt, rec)
+        results.append((model.actor.out_layer.fc1.weight[:64, :512].clone(), model.critic.out_layer.fc1.weight[-64:, -512:].clone(),
+                        model.actor.head.weight.clone()))
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+    assert not torch.equal(results[0][0][:8, :256], probe)                  # and the step did move the weights
