@@ -265,3 +265,49 @@ def test_embedding_plus_encoder_chain_backward(dev):
     _cmp(out, ref.detach(), "out", rel=1e-4)
     for n, p in list(emb.named_parameters()) + list(enc.named_parameters()):
         _cmp(p.grad, Pg[n].grad, n)
+
+
+def test_encoder_properties_padding_permutation_and_weight_cache(dev):
+    """Size-independent properties at ViT-B/16 / RoBERTa-base width (12 heads x 64, 2 layers to stay quick):
+    (1) sequences are independent: permuting the batch permutes the output bit for bit;
+    (2) padded keys (seg == 0) are invisible: changing their embeddings leaves every non-padded position unchanged;
+    (3) the cached weight planes follow the HIP optimizer: after AdamW.step() the inference path uses the new weights
+        (same output as a freshly built encoder holding them)."""
+    from lr2ppo_amd.tencentpretrain.encoders import str2encoder
+    from lr2ppo_amd.tencentpretrain.utils.optimizers import AdamW
+    cfg = {**ROBERTA, "layers_num": 2, "dropout": 0.0}
+    enc = str2encoder["transformer"](_args(**cfg))
+    P = O.seeded_params(O.encoder_param_spec(2, 768, 3072, False), seed=81, std=0.05, skip_gamma_beta=False)
+    enc.load_state_dict(P, strict=True)
+    enc = enc.to(dev).eval()
+    g = torch.Generator().manual_seed(82)
+    emb = torch.randn(5, 196, 768, generator=g).to(dev)
+    seg = torch.ones(5, 196, dtype=torch.long)
+    seg[1, 150:] = 0
+    seg[3, 40:] = 0
+    seg = seg.to(dev)
+    with torch.no_grad():
+        out = enc(emb, seg)
+        perm = torch.tensor([3, 0, 4, 1, 2], device=dev)
+        assert torch.equal(enc(emb[perm].contiguous(), seg[perm].contiguous()), out[perm])           # (1)
+        emb2 = emb.clone()
+        emb2[1, 150:] += 5.0
+        emb2[3, 40:] = torch.randn(156, 768, generator=g).to(dev)
+        out2 = enc(emb2, seg)
+        assert torch.equal(out2[1, :150], out[1, :150]) and torch.equal(out2[3, :40], out[3, :40])   # (2)
+        assert torch.equal(out2[0], out[0]) and not torch.equal(out2[3, 40:], out[3, 40:])
+    # (3)
+    enc.train()
+    opt = AdamW([{"params": list(enc.parameters()), "weight_decay": 0.01}], lr=1e-3, correct_bias=False)
+    e = emb.clone().requires_grad_(True)
+    enc(e, seg).square().mean().backward()
+    opt.step()
+    enc.eval()
+    with torch.no_grad():
+        after = enc(emb, seg)
+    assert not torch.equal(after, out)
+    fresh = str2encoder["transformer"](_args(**cfg))
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in enc.state_dict().items()}, strict=True)
+    fresh = fresh.to(dev).eval()
+    with torch.no_grad():
+        assert torch.equal(fresh(emb, seg), after)

@@ -347,3 +347,74 @@ def test_full_batch_properties(dev):
     for a, b in zip(*results):
         assert torch.equal(a, b)
     assert not torch.equal(results[0][0][:8, :256], probe)                  # and the step did move the weights
+
+
+def test_checkpoint_round_trip_and_optimizer_resume(dev, tmp_path):
+    """save_model -> load_state_dict(strict) into a fresh ActorCritic: identical rollout bits; optimizer state_dict round
+    trip: resuming from the saved optimizer continues exactly like the uninterrupted run."""
+    import copy
+    from lr2ppo_amd import runtime
+    from lr2ppo_amd.finetune import ppo
+    from lr2ppo_amd.tencentpretrain.model_saver import save_model
+    args = _ns(**ARGS, is_master=False, kl_div_loss_weight=0.001, entropy_weight=0.001, value_clip=0.5, optimizer="adamw",
+               scheduler="linear", learning_rate=1e-3, critic_learning_rate=1e-3, train_steps=100, warmup=0.1, device=dev)
+    torch.manual_seed(5)
+    model = ppo.ActorCritic(args, None)
+    reward = ppo.Reward(args, None)
+    ppo._init_normal(model.actor), ppo._init_normal(model.critic), ppo._init_normal(reward)
+    model, reward = model.to(dev), reward.to(dev).eval()
+    opt, copt, sch, csch = ppo.build_optimizer(args, model)
+    for _ in range(3):
+        sch.step(), csch.step()
+    text, img, tgts = (t.to(dev) for t in O.seeded_head_inputs(21, 2, 2))
+    model.eval()
+    rec = ppo.rollout_step(model, reward, text, img, tgts)
+    model.train()
+    runtime.set_dropout_seed(5)
+    ppo.update_minibatch(args, model, opt, copt, rec)                      # creates the moments
+    path = str(tmp_path / "ac.bin")
+    save_model(model, path)
+    ostate = copy.deepcopy((opt.state_dict(), copt.state_dict()))
+    model2 = ppo.ActorCritic(args, None)
+    model2.load_state_dict(torch.load(path, map_location="cpu"), strict=True)
+    model2 = model2.to(dev)
+    model.eval(), model2.eval()
+    r1 = ppo.rollout_step(model, reward, text, img, tgts)
+    r2 = ppo.rollout_step(model2, reward, text, img, tgts)
+    for a, b in zip(r1[1:5], r2[1:5]):
+        assert torch.equal(a, b)
+    opt2, copt2, _, _ = ppo.build_optimizer(args, model2)
+    opt2.load_state_dict(ostate[0]), copt2.load_state_dict(ostate[1])
+    model.train(), model2.train()
+    runtime.set_dropout_seed(6)
+    ppo.update_minibatch(args, model, opt, copt, r1)
+    runtime.set_dropout_seed(6)
+    ppo.update_minibatch(args, model2, opt2, copt2, r2)
+    for (n, p), (_, q) in zip(model.named_parameters(), model2.named_parameters()):
+        assert torch.equal(p.detach(), q.detach()), n
+
+
+def test_dedup_paths_equal_gather_paths(dev):
+    """The inference schedules skip provably redundant trunk work (image tokens shared by the tags of an item, repeated
+    tags in the reward model's 4-long index).  With dropout off, they must give what the plain gather-then-trunk schedule
+    of the training path gives: Critic / Reward save=False vs save=True, Actor with [bs, n, 768] vs repeated image tokens."""
+    from lr2ppo_amd.finetune import ppo
+    args = _ns(**ARGS)
+    text, img, _ = O.seeded_head_inputs(41, 3, 2)
+    text, img3 = text.to(dev), img[:, 0].contiguous().to(dev)            # [bs, 16, 768]
+    img4 = img.to(dev)                                                   # [bs, tags, 16, 768] materialised repeat
+    actor = ppo.Actor(args, None)
+    ppo._init_normal(actor)
+    actor = actor.to(dev).eval()
+    with torch.no_grad():
+        a3, a4 = actor(text, img3, None), actor(text, img4, None)
+    assert torch.equal(a3, a4)
+    for cls, index in ((ppo.Critic, torch.tensor([[0, 1], [1, 0], [1, 1]])),
+                       (ppo.Reward, torch.tensor([[0, 1, 0, 1], [0, 1, 1, 0], [1, 0, 1, 0]]))):
+        m = cls(args, None)
+        ppo._init_normal(m)
+        m = m.to(dev).eval()
+        idx = index.to(dev)
+        fast = m.engine_forward(text, img3, idx, save=False)
+        slow = m.engine_forward(text, img3, idx, save=True)
+        assert torch.allclose(fast, slow, rtol=0, atol=2e-6 * max(1.0, float(slow.abs().max()))), cls.__name__
