@@ -205,7 +205,10 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         import encoder_bench
         torch.cuda.empty_cache()
-        out["config"]["dual_encoder_forward"] = encoder_bench.measure_forward(a.batch, a.tags, 16, iters=3, passes=a.passes, dev=dev)
+        enc = encoder_bench.measure_forward(a.batch, a.tags, 16, iters=3, passes=a.passes, dev=dev)
+        out["config"]["dual_encoder_forward"] = enc
+        # what one step would cost if the features were extracted online instead of read from clean_feat.h5
+        out["config"]["steps_per_sec_with_online_feature_extraction"] = round(1e3 / (ms_per_step + enc["ms"]), 3)
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
     if world == 1 and not a.no_cpu_baseline:
         del model, reward, opt, copt, data
