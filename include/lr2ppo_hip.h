@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 9
+#define LR2_ABI_VERSION 10
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -228,15 +228,20 @@ typedef struct lr2_adamw_chunk {
 int lr2_adamw_multi(const lr2_adamw_chunk* table_dev, int n_chunks, double lr, double beta1, double beta2,
                     double eps, void* stream);
 
-/* Tokens -> embeddings: out[r,:] = word[src[r]] + pos[r % L] + seg_table[seg[r]].
+/* Tokens -> embeddings: out[r,:] = word[src[r]] + pos[r % L] + seg_table[seg[r]].  Ids outside [0, vocab) / [0, n_seg) never
+ * index memory: the row is taken from index 0 and *err_flag (device int, may be NULL) gets bit 0 (token) / bit 1 (segment)
+ * OR-ed in, for the host to raise the IndexError nn.Embedding would.
  * replaces: tencentpretrain/embeddings/{word,pos,seg}_embedding.py forward sums (embedding.py:19-30). */
 int lr2_text_embed(const int64_t* src, const int64_t* seg, const void* word, const void* pos, const void* seg_table,
-                   void* out, int rows, int L, int D, void* stream);
-/* Backward of lr2_text_embed's word / segment gathers (the position table's gradient is lr2_period_rows_grad):
- * dword[src[r], :] += dx[r, :], dseg[seg[r], :] += dx[r, :]; both tables must be zeroed by the caller; float atomics.
+                   void* out, int rows, int L, int D, int64_t vocab, int n_seg, int* err_flag, void* stream);
+/* Backward of lr2_text_embed's word / segment gathers (the position table's gradient is lr2_period_rows_grad), deterministic:
+ * `order` = stable argsort of the token ids, `sorted_ids` = ids in that order; dword[tok, :] = sum of dx rows carrying tok, added
+ * in original row order (rows of dword for absent tokens are NOT written: zero the table first); dseg[s, :] = sum of dx rows with
+ * segment s via `seg_partials` (fp32 scratch, ceil(rows / LR2_TEXT_EMBED_BWD_ROWS_PER_BLOCK) * n_seg * D floats).  No atomics.
  * replaces: autograd of nn.Embedding in tencentpretrain/embeddings/{word,seg}_embedding.py. */
-int lr2_text_embed_bwd(const void* dx, const int64_t* src, const int64_t* seg, void* dword, void* dseg, int rows, int D,
-                       void* stream);
+#define LR2_TEXT_EMBED_BWD_ROWS_PER_BLOCK 64
+int lr2_text_embed_bwd(const void* dx, const int64_t* sorted_ids, const int64_t* order, const int64_t* seg, void* dword,
+                       void* dseg, void* seg_partials, int rows, int D, int64_t vocab, int n_seg, void* stream);
 /* dst = dropout_mask(src) / (1 - p), fp32, mask element index = flat element index (src == dst allowed).
  * replaces: self.dropout of tencentpretrain/embeddings/embedding.py:33 and its autograd. */
 int lr2_dropout_apply(const void* src, void* dst, uint64_t n, float drop_p, uint64_t drop_seed, uint32_t drop_site,
@@ -244,6 +249,20 @@ int lr2_dropout_apply(const void* src, void* dst, uint64_t n, float drop_p, uint
 /* Image -> patch rows: out[(b*P + p), c*ps*ps + i*ps + j] = img[b, c, py*ps+i, px*ps+j].
  * replaces: the unfold implied by nn.Conv2d(k=s=patch) in tencentpretrain/embeddings/patch_embedding.py:18,27. */
 int lr2_patchify(const void* img, void* out, int B, int C, int H, int W, int ps, void* stream);
+/* Image -> patch rows as bf16 hi/lo planes (the A operand of the patch-projection GEMM); element layout of lr2_patchify with row
+ * stride ld >= C*ps*ps (columns past C*ps*ps are written as zeros: ViT-L/14's 588 -> 640 so the GEMM sees whole K tiles); ps even.
+ * img: fp32 [B,C,H,W] (is_u8 = 0) or uint8 frames [B,C,H,W] (is_u8 = 1); with is_u8 and mean3/std3 (HOST float[3]) given, pixels
+ * are normalised on the fly: (x / 255 - mean[c]) / std[c].
+ * replaces: ZeroOneNormalize + transforms.Normalize (tencentpretrain/utils/dataloader.py:559-561) + the unfold implied by
+ * nn.Conv2d(k=s=patch) (embeddings/patch_embedding.py:18,27). */
+int lr2_patchify_planes(const void* img, int is_u8, void* out_hi, uint64_t lo_off, int ld, int B, int C, int H, int W, int ps,
+                        const float* mean3, const float* std3, void* stream);
+/* NDCG@ks[q] per ragged item i (elements offsets[i] .. offsets[i+1], at most 64): sort by score descending (stable), gain
+ * 2^rel - 1, discount disc[j] (= log2(j + 2), device fp32 table supplied by the caller), sequential fp32 sums, 1 when the ideal
+ * DCG <= 1e-6.  out: fp32 [n_items, n_k].
+ * replaces: finetune/ppo.py:651-659 + ndcg.py:28-65 (AverageNDCGMeter.return_ndcg_at_k). */
+int lr2_ndcg(const void* scores, const int64_t* gold, const int64_t* offsets, const void* disc, const int64_t* ks, int n_k,
+             void* out, int n_items, void* stream);
 /* ViT embedding assembly: out[b,0,:] = cls + pos[0]; out[b,1+p,:] = patch_proj[b*P+p,:] + pos[1+p].
  * replaces: patch_embedding.py:28-29 (cls concat) + pos_embedding.py:30-35 + embedding.py:27-30. */
 int lr2_vit_assemble(const void* patch_proj, const void* cls, const void* pos, void* out, int B, int P, int D,

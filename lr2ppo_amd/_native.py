@@ -18,6 +18,8 @@ LIB_PATH = os.path.join(CSRC, "liblr2ppo_hip.so")
 SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
 
+ABI_VERSION = 10     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
+
 _lock = threading.Lock()
 _lib = None
 
@@ -89,7 +91,7 @@ SIGNATURES = {
     "lr2_split_planes": [_P, _P, _U64, _U64, _P],
     "lr2_dropout_planes": [_P, _P, _U64, _U64, _F, _U64, _U32, _P],
     "lr2_dropout_apply": [_P, _P, _U64, _F, _U64, _U32, _P],
-    "lr2_text_embed_bwd": [_P, _P, _P, _P, _P, _I, _I, _P],
+    "lr2_text_embed_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, C.c_int64, _I, _P],
     "lr2_split_planes_t": [_P, _P, _U64, _I, _I, _P],
     "lr2_split_planes_multi": [_P, _I, _P],
     "lr2_layernorm_fwd": [_P, _P, _P, _P, _P, _U64, _P, _P, _I, _I, _F, _I, _I, _U64, _P],
@@ -109,7 +111,9 @@ SIGNATURES = {
     "lr2_smooth_l1": [_P, _P, _I, _F, _P, _P, _P],
     "lr2_pair_hinge": [_P, _I, _F, _P, _P, _P],
     "lr2_adamw_multi": [_P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _P],
-    "lr2_text_embed": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "lr2_text_embed": [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.c_int64, _I, _P, _P],
+    "lr2_patchify_planes": [_P, _I, _P, _U64, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P],
+    "lr2_ndcg": [_P, _P, _P, _P, _P, _I, _P, _I, _P],
     "lr2_patchify": [_P, _P, _I, _I, _I, _I, _I, _P],
     "lr2_vit_assemble": [_P, _P, _P, _P, _I, _I, _I, _P],
 }
@@ -142,8 +146,13 @@ def lib() -> C.CDLL:
                 raise RuntimeError(f"lr2ppo_amd: {LIB_PATH} does not export {name}") from e
             fn.argtypes = argtypes
             fn.restype = C.c_int
-        if handle.lr2_abi_version() != 9:
-            raise RuntimeError("lr2ppo_amd: ABI version mismatch between python package and native library")
+        if handle.lr2_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"lr2ppo_amd: ABI version mismatch: {LIB_PATH} reports {handle.lr2_abi_version()}, the python "
+                               f"package needs {ABI_VERSION}; rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
+        if _stale():
+            # a library older than its sources with an unchanged ABI number would otherwise load silently
+            import warnings
+            warnings.warn(f"lr2ppo_amd: {LIB_PATH} is older than its sources; rebuild with __graft_entry__.build()", RuntimeWarning)
         _lib = handle
         return _lib
 

@@ -90,28 +90,53 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
   }
 }
 
-// Backward of the word / segment embedding gathers: dword[src[r]] += dx[r], dseg[seg[r]] += dx[r] (tables pre-zeroed).
-// Word rows by float atomics (token ids collide rarely); the 3 segment rows are first reduced per workgroup in LDS.
-__global__ __launch_bounds__(256) void text_embed_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ src,
-                                                             const int64_t* __restrict__ seg, float* __restrict__ dword,
-                                                             float* __restrict__ dseg, int rows, int D, int rows_per_block) {
-  extern __shared__ float sseg[];   // [3][D]
-  for (int i = threadIdx.x; i < 3 * D; i += 256) sseg[i] = 0.f;
-  __syncthreads();
+// Backward of the word / segment embedding gathers, deterministic (no float atomics: run-to-run identical bits).
+// Word table: the caller passes the rows sorted by token id (`order` = stable argsort of the ids, `sorted_ids` = ids in
+// that order).  Workgroup r owns the run of equal ids that STARTS at sorted position r (others exit at once) and adds
+// its rows in sorted order -- i.e. in original row order, the order a sequential scatter-add would use.
+__global__ __launch_bounds__(256) void text_embed_bwd_word_kernel(const float* __restrict__ dx, const int64_t* __restrict__ sorted_ids,
+                                                                  const int64_t* __restrict__ order, float* __restrict__ dword,
+                                                                  int rows, int D, int64_t vocab) {
+  const int r = blockIdx.x;
+  const int64_t tok = sorted_ids[r];
+  if (r > 0 && sorted_ids[r - 1] == tok) return;
+  if (tok < 0 || tok >= vocab) return;          // flagged by the forward; never written
+  int end = r + 1;
+  while (end < rows && sorted_ids[end] == tok) ++end;
+  for (int c = threadIdx.x * 4; c < D; c += 256 * 4) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = r; j < end; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(dx + (size_t)order[j] * D + c);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dword + (size_t)tok * D + c) = a;
+  }
+}
+// Segment table (n_seg <= 4 rows): per-workgroup partial sums over a contiguous chunk of rows, [block][n_seg][D];
+// lr2_colsum_partials_finish-style tree is replaced by a fixed-order sum over blocks in text_embed_bwd_seg_finish.
+__global__ __launch_bounds__(256) void text_embed_bwd_seg_kernel(const float* __restrict__ dx, const int64_t* __restrict__ seg,
+                                                                 float* __restrict__ partials, int rows, int D, int n_seg,
+                                                                 int rows_per_block) {
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
-  for (int r = r0; r < r1; ++r) {
-    const int64_t tok = src[r];
-    const int sg = (int)seg[r];
-    for (int c = threadIdx.x; c < D; c += 256) {
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; ++r) {
+      const int sg = (int)seg[r];
       const float v = dx[(size_t)r * D + c];
-      atomicAdd(dword + (size_t)tok * D + c, v);
-      sseg[sg * D + c] += v;        // column c is owned by one thread: no race inside the block
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] += (sg == k) ? v : 0.f;
     }
+    for (int k = 0; k < n_seg; ++k) partials[((size_t)blockIdx.x * n_seg + k) * D + c] = a[k];
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 3 * D; i += 256)
-    if (sseg[i] != 0.f) atomicAdd(dseg + i, sseg[i]);
+}
+__global__ __launch_bounds__(256) void text_embed_bwd_seg_finish(const float* __restrict__ partials, float* __restrict__ dseg,
+                                                                 int nblocks, int total) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float a = 0.f;
+  for (int b = 0; b < nblocks; ++b) a += partials[(size_t)b * total + i];
+  dseg[i] = a;
 }
 
 // dst planes [C][R] = transpose of src fp32 [R][C] (weights re-laid so that the forward GEMM can run in its NN form).
@@ -435,17 +460,110 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict_
 __global__ __launch_bounds__(256) void text_embed_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ seg,
                                                          const float* __restrict__ word, const float* __restrict__ pos,
                                                          const float* __restrict__ seg_table, float* __restrict__ out,
-                                                         int rows, int L, int D) {
+                                                         int rows, int L, int D, int64_t vocab, int n_seg, int* __restrict__ err) {
   const int d4 = D / 4;
   const size_t total = (size_t)rows * d4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int r = (int)(i / d4), c = (int)(i % d4) * 4;
-    const float4 a = *reinterpret_cast<const float4*>(word + (size_t)src[r] * D + c);
+    int64_t tok = src[r], sg = seg[r];
+    // nn.Embedding raises on an out-of-range index; here the row is read from index 0 and the error word is set
+    // (bit 0: token id, bit 1: segment id) for the host to raise -- never an out-of-bounds access.
+    if (tok < 0 || tok >= vocab) { if (c == 0 && err) atomicOr(err, 1); tok = 0; }
+    if (sg < 0 || sg >= n_seg) { if (c == 0 && err) atomicOr(err, 2); sg = 0; }
+    const float4 a = *reinterpret_cast<const float4*>(word + (size_t)tok * D + c);
     const float4 b = *reinterpret_cast<const float4*>(pos + (size_t)(r % L) * D + c);
-    const float4 s = *reinterpret_cast<const float4*>(seg_table + (size_t)seg[r] * D + c);
+    const float4 s = *reinterpret_cast<const float4*>(seg_table + (size_t)sg * D + c);
     // same association as the reference: (word + pos) + seg   (embeddings/embedding.py:24-30)
     *reinterpret_cast<float4*>(out + (size_t)r * D + c) =
         make_float4((a.x + b.x) + s.x, (a.y + b.y) + s.y, (a.z + b.z) + s.z, (a.w + b.w) + s.w);
+  }
+}
+
+// Image -> patch rows, written directly as the bf16 hi/lo planes the projection GEMM streams.
+// out[(b*P + p), c*ps*ps + i*ps + j] = pixel(b, c, py*ps + i, px*ps + j); one thread owns 16 consecutive k (one pixel row of
+// one patch and channel: 16 contiguous input pixels -> 32 contiguous bytes per plane); the 16 lanes of a group cover the 16
+// pixel rows, so a group writes 512 contiguous bytes per plane, and all reads of a workgroup (one strip of patches) fall in
+// 16 image rows per channel (L1/L2 hits).  U8: pixels are uint8 frames, normalised on the fly as the reference's loader
+// does: x.float().div(255) then (x - mean[c]) / std[c] (tencentpretrain/utils/dataloader.py:559-561), IEEE division.
+template <bool U8>
+__global__ __launch_bounds__(256) void patchify_planes_kernel(const void* __restrict__ img, bf16_t* __restrict__ out, size_t lo_off,
+                                                              int B, int C, int H, int W, float m0, float m1, float m2,
+                                                              float s0, float s1, float s2, int normalize) {
+  constexpr int ps = 16;
+  const int px = W / ps, py = H / ps, P = px * py, Kd = C * ps * ps;
+  const int strip = blockIdx.x;               // b * py + y
+  const int b = strip / py, y = strip % py;
+  const int per_strip = px * C * ps;          // (patch x, channel, pixel row) triples
+  for (int t = threadIdx.x; t < per_strip; t += 256) {
+    const int i = t % ps, c = (t / ps) % C, x = t / (ps * C);
+    const size_t src = (((size_t)b * C + c) * H + (size_t)y * ps + i) * W + (size_t)x * ps;
+    float v[16];
+    if (U8) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(img) + src);
+      const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+      const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        float f = (float)((w4[k >> 2] >> (8 * (k & 3))) & 0xffu) / 255.0f;
+        if (normalize) f = (f - mean) / sd;
+        v[k] = f;
+      }
+    } else {
+      const float4* p4 = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(img) + src);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 q = p4[k];
+        v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+      }
+    }
+    bf16_t* dst = out + ((size_t)b * P + (size_t)y * px + x) * Kd + (size_t)c * ps * ps + (size_t)i * ps;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) store_planes4(dst + 4 * k, lo_off, make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]));
+  }
+}
+
+// Any even patch size / padded row length (ViT-L/14: ps = 14, Kd = 588 padded to ld = 640 so that the projection GEMM sees
+// whole K tiles): one thread per VEC consecutive k of one patch row; columns [Kd, ld) are written as zeros.
+template <bool U8, int VEC>
+__global__ __launch_bounds__(256) void patchify_planes_generic_kernel(const void* __restrict__ img, bf16_t* __restrict__ out,
+                                                                      size_t lo_off, int B, int C, int H, int W, int ps, int ld,
+                                                                      float m0, float m1, float m2, float s0, float s1, float s2,
+                                                                      int normalize) {
+  const int px = W / ps, py = H / ps, P = px * py, Kd = C * ps * ps;
+  const int vpr = ld / VEC;                         // vectors per output row
+  const size_t total = (size_t)B * P * vpr;
+  for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+    const int k = (int)(t % vpr) * VEC;
+    const size_t bp = t / vpr;
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+    if (k < Kd) {
+      const int p = (int)(bp % P), b = (int)(bp / P);
+      const int c = k / (ps * ps), ij = k % (ps * ps), ii = ij / ps, jj = ij % ps;
+      const size_t src = (((size_t)b * C + c) * H + (size_t)(p / px) * ps + ii) * W + (size_t)(p % px) * ps + jj;
+      const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float f;
+        if (U8) {
+          f = (float)reinterpret_cast<const uint8_t*>(img)[src + e] / 255.0f;
+          if (normalize) f = (f - mean) / sd;
+        } else {
+          f = reinterpret_cast<const float*>(img)[src + e];
+        }
+        v[e] = f;
+      }
+    }
+    bf16_t* dst = out + bp * (size_t)ld + k;
+    if (VEC == 4) {
+      store_planes4(dst, lo_off, make_float4(v[0], v[1], v[VEC > 2 ? 2 : 0], v[VEC > 3 ? 3 : 0]));
+    } else {
+      const uint32_t h = cvt_pk_bf16(v[0], v[1]);
+      const uint32_t l = cvt_pk_bf16(v[0] - __uint_as_float(h << 16), v[1] - __uint_as_float(h & 0xffff0000u));
+      *reinterpret_cast<uint32_t*>(dst) = h;
+      *reinterpret_cast<uint32_t*>(dst + lo_off) = l;
+    }
   }
 }
 
@@ -460,6 +578,44 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const int c = k / (ps * ps), ij = k % (ps * ps), ii = ij / ps, jj = ij % ps;
     const int y = (p / px) * ps + ii, x = (p % px) * ps + jj;
     out[i] = img[(((size_t)b * C + c) * H + y) * W + x];
+  }
+}
+
+// NDCG@k per item with the reference's arithmetic (ndcg.py:28-65, finetune/ppo.py:651-659): items are ragged
+// (offsets[i] .. offsets[i+1]); one thread per item: stable insertion sort by score (descending, earlier index first on
+// ties), ideal order = labels sorted descending, DCG summed sequentially in fp32 with gain (2^rel - 1) and the discount
+// table disc[i] = log2(i + 2) supplied by the host (so the only device arithmetic is IEEE divide / add: bit parity with
+// the CPU reference); NDCG = 1 when the ideal DCG <= 1e-6.
+constexpr int NDCG_MAX_T = 64;
+__global__ __launch_bounds__(64) void ndcg_kernel(const float* __restrict__ scores, const int64_t* __restrict__ gold,
+                                                  const int64_t* __restrict__ offsets, const float* __restrict__ disc,
+                                                  const int64_t* __restrict__ ks, int n_k, float* __restrict__ out, int n_items) {
+  const int item = blockIdx.x * 64 + threadIdx.x;
+  if (item >= n_items) return;
+  const int64_t o0 = offsets[item];
+  int T = (int)(offsets[item + 1] - o0);
+  if (T > NDCG_MAX_T) T = NDCG_MAX_T;
+  float sc[NDCG_MAX_T];
+  int64_t by_score[NDCG_MAX_T], ideal[NDCG_MAX_T];
+  for (int i = 0; i < T; ++i) {           // insertion sorts (T <= 64, typically 20)
+    const float s = scores[o0 + i];
+    const int64_t g = gold[o0 + i];
+    int j = i;
+    while (j > 0 && sc[j - 1] < s) { sc[j] = sc[j - 1]; by_score[j] = by_score[j - 1]; --j; }
+    sc[j] = s; by_score[j] = g;
+    j = i;
+    while (j > 0 && ideal[j - 1] < g) { ideal[j] = ideal[j - 1]; --j; }
+    ideal[j] = g;
+  }
+  for (int q = 0; q < n_k; ++q) {
+    const int64_t k = ks[q];
+    const int n = (int)(k < (int64_t)T ? k : (int64_t)T);
+    float pred = 0.f, tru = 0.f;
+    for (int i = 0; i < n; ++i) {
+      pred += (float)((1ll << by_score[i]) - 1) / disc[i];
+      tru += (float)((1ll << ideal[i]) - 1) / disc[i];
+    }
+    out[(size_t)item * n_k + q] = (tru <= 1e-6f) ? 1.0f : pred / tru;
   }
 }
 
@@ -562,12 +718,22 @@ extern "C" int lr2_dropout_apply(const void* src, void* dst, uint64_t n, float d
   CHECK_LAUNCH();
 }
 
-extern "C" int lr2_text_embed_bwd(const void* dx, const int64_t* src, const int64_t* seg, void* dword, void* dseg, int rows,
-                                  int D, void* stream) {
-  if (!dx || !src || !seg || !dword || !dseg || rows <= 0 || D <= 0) return LR2_ERR_ARG;
-  const int rows_per_block = 16;
-  LR2_LAUNCH(text_embed_bwd_kernel, dim3((rows + rows_per_block - 1) / rows_per_block), dim3(256), (size_t)3 * D * sizeof(float),
-             (hipStream_t)stream, (const float*)dx, src, seg, (float*)dword, (float*)dseg, rows, D, rows_per_block);
+extern "C" int lr2_text_embed_bwd(const void* dx, const int64_t* sorted_ids, const int64_t* order, const int64_t* seg,
+                                  void* dword, void* dseg, void* seg_partials, int rows, int D, int64_t vocab, int n_seg,
+                                  void* stream) {
+  if (!dx || !sorted_ids || !order || !seg || !dword || !dseg || !seg_partials || rows <= 0 || D <= 0) return LR2_ERR_ARG;
+  if (D % 4 || n_seg < 1 || n_seg > 4) return LR2_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  LR2_LAUNCH(text_embed_bwd_word_kernel, dim3(rows), dim3(256), 0, s, (const float*)dx, sorted_ids, order, (float*)dword, rows,
+             D, vocab);
+  if (lr2_launch_status(__func__)) return LR2_ERR_LAUNCH;
+  const int rows_per_block = LR2_TEXT_EMBED_BWD_ROWS_PER_BLOCK;
+  const int nb = (rows + rows_per_block - 1) / rows_per_block;
+  LR2_LAUNCH(text_embed_bwd_seg_kernel, dim3(nb), dim3(256), 0, s, (const float*)dx, seg, (float*)seg_partials, rows, D, n_seg,
+             rows_per_block);
+  if (lr2_launch_status(__func__)) return LR2_ERR_LAUNCH;
+  LR2_LAUNCH(text_embed_bwd_seg_finish, dim3((n_seg * D + 255) / 256), dim3(256), 0, s, (const float*)seg_partials,
+             (float*)dseg, nb, n_seg * D);
   CHECK_LAUNCH();
 }
 
@@ -669,11 +835,50 @@ extern "C" int lr2_adamw_multi(const lr2_adamw_chunk* table_dev, int n_chunks, d
 }
 
 extern "C" int lr2_text_embed(const int64_t* src, const int64_t* seg, const void* word, const void* pos,
-                              const void* seg_table, void* out, int rows, int L, int D, void* stream) {
-  if (!src || !seg || !word || !pos || !seg_table || !out || rows <= 0 || L <= 0) return LR2_ERR_ARG;
+                              const void* seg_table, void* out, int rows, int L, int D, int64_t vocab, int n_seg, int* err_flag,
+                              void* stream) {
+  if (!src || !seg || !word || !pos || !seg_table || !out || rows <= 0 || L <= 0 || vocab <= 0 || n_seg <= 0) return LR2_ERR_ARG;
   if (D % 4) return LR2_ERR_SHAPE;
   LR2_LAUNCH(text_embed_kernel, dim3(grid_for((size_t)rows * D / 4)), dim3(256), 0, (hipStream_t)stream, src,
-                     seg, (const float*)word, (const float*)pos, (const float*)seg_table, (float*)out, rows, L, D);
+                     seg, (const float*)word, (const float*)pos, (const float*)seg_table, (float*)out, rows, L, D, vocab, n_seg,
+                     err_flag);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_patchify_planes(const void* img, int is_u8, void* out_hi, uint64_t lo_off, int ld, int B, int C, int H,
+                                   int W, int ps, const float* mean3, const float* std3, void* stream) {
+  if (!img || !out_hi || B <= 0 || C <= 0 || ps <= 0) return LR2_ERR_ARG;
+  const int Kd = C * ps * ps;
+  if (H % ps || W % ps || C > 3 || (ps & 1) || ld < Kd || (ld & 3) || (lo_off & 1)) return LR2_ERR_SHAPE;
+  const int normalize = (is_u8 && mean3 && std3) ? 1 : 0;
+  const float m0 = normalize ? mean3[0] : 0.f, m1 = normalize && C > 1 ? mean3[1] : 0.f, m2 = normalize && C > 2 ? mean3[2] : 0.f;
+  const float s0 = normalize ? std3[0] : 1.f, s1 = normalize && C > 1 ? std3[1] : 1.f, s2 = normalize && C > 2 ? std3[2] : 1.f;
+  hipStream_t s = (hipStream_t)stream;
+  bf16_t* o = (bf16_t*)out_hi;
+  if (ps == 16 && ld == Kd && (lo_off & 3) == 0) {    // ViT-B/16, ViT-L/16: the coalesced strip kernel
+    const dim3 grid(B * (H / ps));
+    if (is_u8) LR2_LAUNCH(patchify_planes_kernel<true>, grid, dim3(256), 0, s, img, o, (size_t)lo_off, B, C, H, W, m0, m1, m2, s0, s1, s2, normalize);
+    else LR2_LAUNCH(patchify_planes_kernel<false>, grid, dim3(256), 0, s, img, o, (size_t)lo_off, B, C, H, W, m0, m1, m2, s0, s1, s2, 0);
+    CHECK_LAUNCH();
+  }
+  const size_t P = (size_t)(H / ps) * (W / ps);
+  if ((ps & 3) == 0 && (lo_off & 3) == 0) {
+    const dim3 grid(grid_for((size_t)B * P * (ld / 4)));
+    if (is_u8) LR2_LAUNCH((patchify_planes_generic_kernel<true, 4>), grid, dim3(256), 0, s, img, o, (size_t)lo_off, B, C, H, W, ps, ld, m0, m1, m2, s0, s1, s2, normalize);
+    else LR2_LAUNCH((patchify_planes_generic_kernel<false, 4>), grid, dim3(256), 0, s, img, o, (size_t)lo_off, B, C, H, W, ps, ld, m0, m1, m2, s0, s1, s2, 0);
+  } else {
+    const dim3 grid(grid_for((size_t)B * P * (ld / 2)));
+    if (is_u8) LR2_LAUNCH((patchify_planes_generic_kernel<true, 2>), grid, dim3(256), 0, s, img, o, (size_t)lo_off, B, C, H, W, ps, ld, m0, m1, m2, s0, s1, s2, normalize);
+    else LR2_LAUNCH((patchify_planes_generic_kernel<false, 2>), grid, dim3(256), 0, s, img, o, (size_t)lo_off, B, C, H, W, ps, ld, m0, m1, m2, s0, s1, s2, 0);
+  }
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_ndcg(const void* scores, const int64_t* gold, const int64_t* offsets, const void* disc, const int64_t* ks,
+                        int n_k, void* out, int n_items, void* stream) {
+  if (!scores || !gold || !offsets || !disc || !ks || !out || n_items <= 0 || n_k <= 0) return LR2_ERR_ARG;
+  LR2_LAUNCH(ndcg_kernel, dim3((n_items + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const float*)scores, gold, offsets,
+             (const float*)disc, ks, n_k, (float*)out, n_items);
   CHECK_LAUNCH();
 }
 

@@ -21,7 +21,7 @@ from torch.utils.data import DataLoader, Dataset
 from torch.utils.data.distributed import DistributedSampler
 
 from .. import ops
-from ..ndcg import AverageNDCGMeter
+from ..ndcg import AverageNDCGMeter, ndcg_rows
 from ..tencentpretrain.model_saver import save_model
 from ..tencentpretrain.opts import adv_opts, finetune_opts, tokenizer_opts
 from ..tencentpretrain.utils.config import load_hyperparam
@@ -166,15 +166,11 @@ def evaluate(args, model, dataloader, step, split="test", num_tasks=None):
     score; master returns (NDCG@all, 0)."""
     ndcg_obj = AverageNDCGMeter()
     model.eval()
-    local = []
+    scores, golds = [], []
     for text_emb, img_emb, tgts in dataloader:
-        logits = model.engine_forward(text_emb.to(args.device), img_emb.to(args.device), save=False)
-        local.append((logits.view(-1), tgts.view(-1).cpu()))
-    if local:                                   # one device-to-host copy for the whole split
-        flat = torch.cat([s for s, _ in local]).cpu()
-        local = [(c, g) for c, (_, g) in zip(torch.split(flat, [s.numel() for s, _ in local]), local)]
-    vecs = [ndcg_obj.return_ndcg_at_k_from_scores(s, g) for s, g in local]
-    mine = torch.stack(vecs) if vecs else torch.zeros(0, len(ndcg_obj.ndcg_at_k))
+        scores.append(model.engine_forward(text_emb.to(args.device), img_emb.to(args.device), save=False).view(-1))
+        golds.append(tgts.view(-1))
+    mine = ndcg_rows(scores, golds, args.device, tuple(ndcg_obj.ndcg_at_k))   # one kernel + one copy for the whole split
     world = num_tasks or 1
     if world > 1 and dist.is_initialized():
         gathered = [None] * world

@@ -34,7 +34,7 @@ from torch.utils.data import DataLoader, Dataset
 from torch.utils.data.distributed import DistributedSampler
 
 from .. import engine, ops, runtime
-from ..ndcg import AverageNDCGMeter
+from ..ndcg import AverageNDCGMeter, ndcg_rows
 from ..tencentpretrain.model_saver import save_model
 from ..tencentpretrain.opts import adv_opts, finetune_opts, tokenizer_opts
 from ..tencentpretrain.utils.config import load_hyperparam
@@ -647,18 +647,16 @@ def train_model(args, model, optimizer, critic_optim, scheduler, critic_schedule
 def evaluate(args, val_loader, step, split="test", num_tasks=None):
     ndcg_obj = AverageNDCGMeter()
     args.model.eval()
-    local = []
+    scores, golds = [], []
     for text_emb, img_emb, tgts in val_loader:
         text_emb = text_emb.to(args.device)
         img_emb = img_emb.to(args.device)            # [1, n_img, 768]: shared by all tags of the item
-        logits = args.model.actor.engine_forward(text_emb, img_emb, save=False)
-        local.append((logits.view(-1), tgts.view(-1).cpu()))
-    # one device-to-host copy for the whole split (the reference synchronises once per item, finetune/ppo.py:640-655)
-    if local:
-        flat = torch.cat([s for s, _ in local]).cpu()
-        local = [(c, g) for c, (_, g) in zip(torch.split(flat, [s.numel() for s, _ in local]), local)]
-    vecs = [ndcg_obj.return_ndcg_at_k_from_scores(s, g) for s, g in local]
-    mine = torch.stack(vecs) if vecs else torch.zeros(0, len(ndcg_obj.ndcg_at_k))
+        scores.append(args.model.actor.engine_forward(text_emb, img_emb, save=False).view(-1))
+        golds.append(tgts.view(-1))
+    # scores never leave the device: one batched NDCG kernel over the whole split (lr2_ndcg: sort by score, gain 2^rel - 1,
+    # discount log2(i + 2), ideal DCG <= 1e-6 -> 1) and ONE device-to-host copy of the [items, 6] result -- the reference
+    # synchronises and loops in Python once per item (finetune/ppo.py:640-659, ndcg.py:28-65)
+    mine = ndcg_rows(scores, golds, args.device, tuple(ndcg_obj.ndcg_at_k))
     world = num_tasks or 1
     if world > 1 and dist.is_initialized():
         gathered = [None] * world

@@ -1,7 +1,24 @@
-"""NDCG meter with the reference's definition (ndcg.py:9-65): gain 2^rel - 1, discount log2(i + 2),
-k in {1, 3, 5, 10, 20, 1e8}, NDCG := 1 when the ideal DCG <= 1e-6.  Host-side and vectorised (the metric is
-a few dozen flops per item; the reference's per-element Python loop is what made its eval take 13 s)."""
+"""NDCG with the reference's definition (ndcg.py:9-65): gain 2^rel - 1, discount log2(i + 2),
+k in {1, 3, 5, 10, 20, 1e8}, NDCG := 1 when the ideal DCG <= 1e-6.
+
+`ndcg_rows` is what the evaluate() functions of this package use: the scores of a whole split stay on the device and ONE
+launch of lr2_ndcg (csrc/misc.hip) produces the [items, 6] table (the reference loops in Python per item and per rank,
+13 s per evaluation in its logs).  `AverageNDCGMeter` keeps the reference's host-side class API (vectorised)."""
 import torch
+
+
+def ndcg_rows(scores, golds, device, ks=(1, 3, 5, 10, 20, 100000000)):
+    """scores / golds: per-item 1-D tensors (device scores, labels anywhere) -> CPU fp32 [items, len(ks)]."""
+    from . import ops
+    if not scores:
+        return torch.zeros(0, len(ks))
+    sizes = [int(s.numel()) for s in scores]
+    if max(sizes) > 64:
+        raise ValueError("an item carries more than 64 tags (lr2_ndcg's per-item limit)")
+    offsets = torch.tensor([0] + sizes, dtype=torch.int64).cumsum(0).to(device)
+    flat_s = torch.cat([s.reshape(-1).to(device=device, dtype=torch.float32) for s in scores])
+    flat_g = torch.cat([g.reshape(-1).to(device=device, dtype=torch.int64) for g in golds])
+    return ops.ndcg(flat_s, flat_g, offsets, tuple(ks)).cpu()
 
 
 class AverageNDCGMeter(object):

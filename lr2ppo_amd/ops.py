@@ -180,12 +180,18 @@ def dropout_apply(src: torch.Tensor, dst: torch.Tensor, drop: Optional[Drop]):
 
 
 def text_embed_bwd(dx, src, seg, dword, dseg, *, rows, D):
-    """dword[src[r]] += dx[r]; dseg[seg[r]] += dx[r] (tables zeroed by the caller)."""
+    """dword[src[r]] += dx[r]; dseg[seg[r]] += dx[r] (tables zeroed by the caller).  Deterministic: rows are grouped by
+    token with a stable device sort and summed in row order by one workgroup per distinct token (no float atomics)."""
     _chk_f32(dx, dword, dseg)
     if src.dtype != torch.int64 or seg.dtype != torch.int64:
         raise TypeError("src / seg must be int64")
-    _nat.check(_nat.lib().lr2_text_embed_bwd(dx.data_ptr(), src.data_ptr(), seg.data_ptr(), dword.data_ptr(), dseg.data_ptr(),
-                                             rows, D, _stream()), "lr2_text_embed_bwd")
+    sorted_ids, order = torch.sort(src.view(-1), stable=True)
+    rpb = 64                                                     # LR2_TEXT_EMBED_BWD_ROWS_PER_BLOCK
+    n_seg = dseg.shape[0]
+    partials = torch.empty(((rows + rpb - 1) // rpb) * n_seg * D, dtype=torch.float32, device=dx.device)
+    _nat.check(_nat.lib().lr2_text_embed_bwd(dx.data_ptr(), sorted_ids.data_ptr(), order.data_ptr(), seg.data_ptr(),
+                                             dword.data_ptr(), dseg.data_ptr(), partials.data_ptr(), rows, D, dword.shape[0],
+                                             n_seg, _stream()), "lr2_text_embed_bwd")
 
 
 def split_planes_multi(table_dev: torch.Tensor, n_chunks: int):
@@ -505,10 +511,62 @@ def adamw_multi(table_dev: torch.Tensor, n_chunks: int, lr: float, beta1: float,
                    "lr2_adamw_multi")
 
 
-def text_embed(src, seg, word, pos, seg_table, out, *, rows, L, D):
+def text_embed(src, seg, word, pos, seg_table, out, *, rows, L, D, err: Optional[torch.Tensor] = None):
+    """err: optional int32[1] device word; bit 0 / bit 1 are set when a token / segment id is out of range."""
     _chk_f32(word, pos, seg_table, out)
+    if src.dtype != torch.int64 or seg.dtype != torch.int64:
+        raise TypeError("src / seg must be int64")
+    if L > pos.shape[0]:
+        raise IndexError(f"sequence length {L} exceeds the position table ({pos.shape[0]} rows)")
     _nat.check(_nat.lib().lr2_text_embed(src.data_ptr(), seg.data_ptr(), word.data_ptr(), pos.data_ptr(), seg_table.data_ptr(),
-                                   out.data_ptr(), rows, L, D, _stream()), "lr2_text_embed")
+                                         out.data_ptr(), rows, L, D, word.shape[0], seg_table.shape[0], _ptr(err), _stream()),
+               "lr2_text_embed")
+    return out
+
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)     # tencentpretrain/utils/dataloader.py:561
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def patchify_planes(img, out: Planes, *, B, Cc, H, W, ps, mean=None, std=None):
+    """Patch rows of `img` as planes [B*P, Cc*ps*ps].  img: fp32 [B,Cc,H,W], or uint8 frames (then normalised on the fly
+    with mean / std per channel when both are given: (x / 255 - mean) / std)."""
+    is_u8 = img.dtype == torch.uint8
+    if not is_u8:
+        _chk_f32(img)
+    if not img.is_cuda or not img.is_contiguous():
+        raise TypeError("patchify_planes: img must be a contiguous HIP tensor")
+    P = (H // ps) * (W // ps)
+    if out.rows != B * P or out.cols < Cc * ps * ps:
+        raise ValueError("patchify_planes: out must be [B*P, >= C*ps*ps] planes (extra columns are zero-filled)")
+    m3 = s3 = None
+    if is_u8 and mean is not None and std is not None:
+        m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    _nat.check(_nat.lib().lr2_patchify_planes(img.data_ptr(), 1 if is_u8 else 0, out.data_ptr(), out.lo_off, out.cols, B, Cc, H, W,
+                                              ps, m3, s3, _stream()), "lr2_patchify_planes")
+    return out
+
+
+_NDCG_TABLES = {}
+
+
+def ndcg(scores, gold, offsets, ks=(1, 3, 5, 10, 20, 100000000)):
+    """-> fp32 [n_items, len(ks)] NDCG@k of ragged items (scores / gold flat, offsets int64 [n_items + 1]), on the device."""
+    _chk_f32(scores)
+    if gold.dtype != torch.int64 or offsets.dtype != torch.int64:
+        raise TypeError("gold / offsets must be int64")
+    dev = scores.device
+    key = (str(dev), tuple(ks))
+    if key not in _NDCG_TABLES:
+        # discount table computed exactly as the reference does (torch.log2 of an int64 tensor on the host, ndcg.py:31)
+        disc = torch.log2(torch.arange(64, dtype=torch.int64) + 2).to(dev)
+        _NDCG_TABLES[key] = (disc, torch.tensor(list(ks), dtype=torch.int64, device=dev))
+    disc, ks_t = _NDCG_TABLES[key]
+    n_items = offsets.numel() - 1
+    out = torch.empty(n_items, len(ks), dtype=torch.float32, device=dev)
+    if n_items > 0:
+        _nat.check(_nat.lib().lr2_ndcg(scores.data_ptr(), gold.data_ptr(), offsets.data_ptr(), disc.data_ptr(), ks_t.data_ptr(),
+                                       len(ks), out.data_ptr(), n_items, _stream()), "lr2_ndcg")
     return out
 
 

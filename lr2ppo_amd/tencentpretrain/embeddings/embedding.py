@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from ... import engine, ops, runtime
-from ..layers.layer_norm import LayerNorm
+from ..layers.layer_norm import LayerNorm, device_dropout
 
 
 class WordEmbedding(nn.Module):
@@ -51,6 +51,9 @@ class PatchEmbedding(nn.Module):
         self.patch_size, self.channels_num = args.patch_size, args.channels_num
         self.projection = nn.Conv2d(args.channels_num, args.emb_size, kernel_size=(args.patch_size, args.patch_size),
                                     stride=(args.patch_size, args.patch_size), bias=False)
+        # uint8 frames are converted as the reference's image loader does (tencentpretrain/utils/dataloader.py:559-561):
+        # x / 255 then Normalize(mean, std) with the CLIP statistics; set both to None for ZeroOneNormalize only
+        self.u8_mean, self.u8_std = ops.CLIP_MEAN, ops.CLIP_STD
 
     def check(self, src):
         _, _, height, width = src.shape
@@ -67,6 +70,21 @@ class Embedding(nn.Module):
         if not self.remove_embedding_layernorm and "dual" not in args.embedding:
             self.layer_norm = LayerNorm(args.emb_size)
         self._ws = None
+        self._err = None
+        # True: the out-of-range-id check (one device -> host read) is left to an explicit check_ids() call, so that a
+        # caller with its own synchronisation point (lr2ppo_amd.finetune.features) keeps the stream asynchronous
+        self.defer_id_check = False
+
+    def check_ids(self):
+        """Raise the IndexError nn.Embedding raises for an out-of-range token / segment id (the kernel itself never
+        indexes out of bounds: it reads row 0 and sets a device error word)."""
+        if self._err is None:
+            return
+        code = int(self._err.item())
+        if code:
+            self._err.zero_()
+            what = [w for bit, w in ((1, "token id outside [0, vocab_size)"), (2, "segment id outside [0, 3)")) if code & bit]
+            raise IndexError("lr2ppo_amd Embedding: " + " and ".join(what))
 
     def update(self, embedding, embedding_name):
         setattr(self, embedding_name, embedding)
@@ -98,10 +116,20 @@ class Embedding(nn.Module):
             B, C, H, W = src.shape
             ps = pe.patch_size
             P, E, Kd = (H // ps) * (W // ps), pe.cls_emb.shape[-1], C * ps * ps
-            patches = torch.empty(B * P, Kd, device=dev) if save else ws.mat("patches", B * P, Kd)
-            ops.patchify(src.contiguous().float(), patches, B=B, Cc=C, H=H, W=W, ps=ps)
+            Kp = (Kd + 63) // 64 * 64        # whole K tiles for the projection GEMM (ViT-L/14: 588 -> 640, zero padded)
+            # patch rows straight to bf16 hi/lo planes (uint8 frames are normalised on the fly); kept for the backward
+            patches = ops.Planes.empty(B * P, Kp, dev) if save else ws.planes("patches", B * P, Kp)
+            img = src.contiguous() if src.dtype == torch.uint8 else src.contiguous().float()
+            ops.patchify_planes(img, patches, B=B, Cc=C, H=H, W=W, ps=ps, mean=pe.u8_mean, std=pe.u8_std)
+            w2 = pe.projection.weight.data.view(E, Kd)
+            if Kp != Kd:
+                wpad = ws.mat("patch_w_pad", E, Kp)
+                wpad.zero_()
+                wpad[:, :Kd].copy_(w2)
+                w2 = wpad
+            w_p = ops.split_planes(w2, ws.planes("patch_w", E, Kp))
             proj = ws.mat("proj", B * P, E)
-            engine.linear_fwd(ws, patches, pe.projection.weight.data.view(E, Kd), None, proj, B * P, E, Kd)
+            engine.linear_fwd(ws, patches, w_p, None, proj, B * P, E, Kp)
             out = torch.empty(B, P + 1, E, device=dev)
             ops.vit_assemble(proj, pe.cls_emb.data.view(-1), self.pos.embedding.weight.data, out, B=B, P=P, D=E)
             saved.update(patches=patches, dims=(B, P, E, Kd))
@@ -111,8 +139,12 @@ class Embedding(nn.Module):
             ids = src.contiguous().view(-1).long()
             sg = seg.to(dev).contiguous().view(-1).long()
             out = torch.empty(B, L, E, device=dev)
+            if self._err is None or self._err.device != dev:
+                self._err = torch.zeros(1, dtype=torch.int32, device=dev)
             ops.text_embed(ids, sg, self.word.embedding.weight.data, self.pos.embedding.weight.data,
-                           self.seg.embedding.weight.data, out.view(B * L, E), rows=B * L, L=L, D=E)
+                           self.seg.embedding.weight.data, out.view(B * L, E), rows=B * L, L=L, D=E, err=self._err)
+            if not self.defer_id_check:
+                self.check_ids()
             saved.update(ids=ids, seg=sg, dims=(B, L, E))
         else:
             raise NotImplementedError(f"embedding composition {names}: only ['patch','pos'] and ['word','pos','seg'] "
@@ -161,10 +193,11 @@ class Embedding(nn.Module):
             ops.gather_rows(dy.view(B, (P + 1) * E)[:, E:], None, dproj, B=B, t_in=1, t_out=1, row_elems=P * E,
                             src_bstride=(P + 1) * E, src_tstride=0)
             dproj_p = ops.split_planes(dproj.view(B * P, E), ops.Planes.empty(B * P, E, dev))
-            patches_p = ops.split_planes(saved["patches"], ops.Planes.empty(B * P, Kd, dev))
-            dw = torch.empty(E, Kd, device=dev)
-            engine.linear_wgrad(ws, dproj_p, patches_p, dw, None, B * P, Kd, E)
-            G[pe.projection.weight] = dw.view_as(pe.projection.weight)
+            patches_p = saved["patches"]
+            Kp = patches_p.cols
+            dw = torch.empty(E, Kp, device=dev)
+            engine.linear_wgrad(ws, dproj_p, patches_p, dw, None, B * P, Kp, E)
+            G[pe.projection.weight] = (dw if Kp == Kd else dw[:, :Kd].contiguous()).view_as(pe.projection.weight)
         else:
             B, L, E = saved["dims"]
             dword, dseg = torch.zeros_like(self.word.embedding.weight), torch.zeros_like(self.seg.embedding.weight)
@@ -190,33 +223,36 @@ class _EmbeddingFn(torch.autograd.Function):
 
 
 class DualEmbedding(nn.Module):
-    """Two-stream embedding (embeddings/dual_embedding.py:7-66 of the reference)."""
+    """Two-stream embedding (embeddings/dual_embedding.py:7-66 of the reference).  As upstream, each stream is a full
+    `Embedding` (with its own LayerNorm unless removed, and its own dropout) followed by the stream LayerNorm (unless
+    `remove_embedding_layernorm` in the stream's options) and the shared dropout (:51-52): in train mode every stream is
+    dropped twice.  Both LayerNorms and both dropouts are differentiable (autograd nodes over the HIP kernels)."""
 
     def __init__(self, args, vocab_size):
         super().__init__()
         from . import str2embedding
-        built = []
-        for over in (args.stream_0, args.stream_1):
+        # registration order = the reference's (dual_embedding.py:15-33): embedding_0, stream_0_layer_norm, embedding_1,
+        # stream_1_layer_norm -- named_parameters() / optimizer parameter order follow it
+        for i, over in enumerate((args.stream_0, args.stream_1)):
             d = copy.deepcopy(vars(args))
             d.update(over)
             ns = Namespace(**d)
             emb = Embedding(ns)
             for name in ns.embedding:
                 emb.update(str2embedding[name](ns, vocab_size), name)
-            built.append((emb, ns))
-        (self.embedding_0, a0), (self.embedding_1, a1) = built
-        self.stream_0_remove_embedding_layernorm = a0.remove_embedding_layernorm
-        if not self.stream_0_remove_embedding_layernorm:
-            self.stream_0_layer_norm = LayerNorm(a0.emb_size)
-        self.stream_1_remove_embedding_layernorm = a1.remove_embedding_layernorm
-        if not self.stream_1_remove_embedding_layernorm:
-            self.stream_1_layer_norm = LayerNorm(a1.emb_size)
+            setattr(self, f"embedding_{i}", emb)
+            setattr(self, f"stream_{i}_remove_embedding_layernorm", ns.remove_embedding_layernorm)
+            if not ns.remove_embedding_layernorm:
+                setattr(self, f"stream_{i}_layer_norm", LayerNorm(ns.emb_size))
         self.dropout = nn.Dropout(args.dropout)
         if args.tie_weights:
             self.embedding_0 = self.embedding_1
 
     def forward(self, src, seg):
-        return self.get_embedding_0(src[0], seg[0]), self.get_embedding_1(src[1], seg[1])
+        emb_0 = self.get_embedding_0(src[0], seg[0])
+        emb_1 = self.get_embedding_1(src[1], seg[1])
+        p = float(self.dropout.p)                        # dual_embedding.py:51-52: dropout on both streams
+        return device_dropout(emb_0, p, self.training), device_dropout(emb_1, p, self.training)
 
     def get_embedding_0(self, src, seg):
         emb = self.embedding_0(src, seg)

@@ -34,7 +34,8 @@ class TransformerEncoder(nn.Module):
         if unsupported or self.mask != "fully_visible":
             raise NotImplementedError(f"HIP TransformerEncoder: unsupported options {unsupported or self.mask}")
         self.transformer = nn.ModuleList([TransformerLayer(args) for _ in range(self.layers_num)])
-        if self.layernorm_positioning == "pre":
+        self.final_layernorm = self.layernorm_positioning == "pre"       # transformer_encoder.py:36-37,134-135 upstream
+        if self.final_layernorm:
             self.layer_norm = LayerNorm(args.hidden_size)
         self._ws = None
         self._wplanes = None
@@ -112,7 +113,7 @@ class TransformerEncoder(nn.Module):
                 engine.linear_fwd(ws, ff_p, w["w2"], ffn.linear_2.bias.data, h2, M, E, F, resid=h)
                 ops.layernorm_fwd(h2, ln2.gamma.data, ln2.beta.data, h, rows=M, D=E, eps=ln2.eps, mode=1, out_planes=x_p)
         out = torch.empty(B, L, E, device=emb.device)
-        if pre:
+        if self.final_layernorm:
             ops.layernorm_fwd(h, self.layer_norm.gamma.data, self.layer_norm.beta.data, out.view(M, E), rows=M, D=E,
                               eps=self.layer_norm.eps, mode=1)
         else:
@@ -185,7 +186,7 @@ class TransformerEncoder(nn.Module):
                 S.update(inter_p=inter_p, t2=t2)
                 h, h_p = hn, hn_p
             saved["layers"].append(S)
-        if pre:
+        if self.final_layernorm:
             out = torch.empty(B, L, E, device=dev)
             saved["h_final"], saved["mf"], saved["rf"] = h, vec(M), vec(M)
             ops.layernorm_fwd(h, self.layer_norm.gamma.data, self.layer_norm.beta.data, out.view(M, E), saved["mf"], saved["rf"],
@@ -216,7 +217,7 @@ class TransformerEncoder(nn.Module):
         pre = self.layernorm_positioning == "pre"
         scale = 1.0 / math.sqrt(float(hd))
         dh = dout.contiguous().view(M, E)
-        if pre:
+        if self.final_layernorm:
             ln = self.layer_norm
             dnew = mat(M, E)
             ops.layernorm_bwd(dh, saved["h_final"], ln.gamma.data, saved["mf"], saved["rf"], dnew, partials, G[ln.gamma],
@@ -286,3 +287,34 @@ class _EncoderFn(torch.autograd.Function):
         demb, G = ctx.enc._backward_train(ctx.saved, dout.contiguous())
         ctx.saved = None
         return (None, demb, None) + tuple(G[q] if q.requires_grad else None for q in ctx.enc.parameters())
+
+
+class _OneLayerStack(TransformerEncoder):
+    """A TransformerLayer run on its own (`TransformerLayer.forward(hidden, mask)`, layers/transformer.py:50-73 upstream):
+    the one-layer case of the encoder schedule, without the stack's final LayerNorm.  Shares the layer's parameters."""
+
+    def __init__(self, layer):
+        nn.Module.__init__(self)
+        att = layer.self_attn
+        self.mask, self.layers_num = "fully_visible", 1
+        self.layernorm_positioning = layer.layernorm_positioning
+        self.heads_num, self.hidden_size = att.heads_num, att.final_linear.out_features
+        self.transformer = nn.ModuleList([layer])
+        self.final_layernorm = False
+        self._ws = None
+        self._wplanes = None
+
+
+def seg_from_additive_mask(mask):
+    """[B, 1, L, L] additive mask of the 'fully_visible' form (0 where the KEY is visible, -10000 where it is padding, the
+    same for every query row: encoders/transformer_encoder.py:62-68 upstream) -> seg [B, L] (1 visible / 0 padded).
+    Other mask shapes (causal, per-query) are not on the HIP path."""
+    if mask.dim() != 4 or mask.shape[1] != 1 or mask.shape[2] != mask.shape[3]:
+        raise ValueError("mask must be [batch, 1, seq, seq]")
+    row0 = mask[:, 0, 0, :]
+    if not bool((mask[:, 0] == row0.unsqueeze(1)).all()):
+        raise NotImplementedError("HIP attention takes key-padding masks only (mask='fully_visible'); use the reference "
+                                  "for causal / per-query masks")
+    if not bool(((row0 == 0) | (row0 == -10000.0)).all()):
+        raise NotImplementedError("HIP attention supports additive masks with values 0 / -10000 only")
+    return (row0 == 0).to(torch.int64)

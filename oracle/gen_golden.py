@@ -553,6 +553,103 @@ def gen_embeddings_bwd():
     _save("embeddings_bwd_small.npz", **arrays)
 
 
+def _sample_idx(numel, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, numel, (min(n, numel),), generator=g)
+
+
+def gen_encoder_bwd_wide():
+    """Backward of the reference TransformerEncoder at the WIDTH of ViT-B/16 / RoBERTa-base (hidden 768, 12 heads of 64,
+    feed-forward 3072), two layers: pre-LN at L = 197 (all visible) and post-LN at L = 196 with a padded `seg` -- the shapes
+    that select the production instantiations of the attention-backward, LayerNorm-backward and GEMM kernels.  Inputs and
+    weights are rebuilt from seeds; stored: sampled outputs, sampled input / parameter gradients and every gradient's
+    sum of squares."""
+    from tencentpretrain.encoders import str2encoder
+    arrays = {}
+    for tag, L, cfg in (("pre", 197, "models/vit/base-16-224_config.json"), ("post", 196, "models/xlm-roberta/base_config.json")):
+        a = _encoder_args(cfg, layers_num=2, layernorm_positioning=tag)
+        enc = str2encoder["transformer"](a).eval()
+        spec = [(n, tuple(p.shape)) for n, p in enc.named_parameters()]
+        assert spec == O.encoder_param_spec(2, 768, 3072, tag == "pre"), tag
+        params = O.seeded_params(spec, seed=71, std=0.05, skip_gamma_beta=False)
+        enc.load_state_dict(params, strict=True)
+        g = torch.Generator().manual_seed(72)
+        emb = torch.randn(2, L, 768, generator=g).requires_grad_(True)
+        wout = torch.randn(2, L, 768, generator=g)
+        seg = torch.ones(2, L, dtype=torch.long)
+        if tag == "post":
+            seg[1, 131:] = 0
+        out = enc(emb, seg)
+        (out * wout).sum().backward()
+        idx = _sample_idx(out.numel(), 4096, 73)
+        arrays[f"{tag}_idx"], arrays[f"{tag}_out"] = idx, out.detach().flatten()[idx]
+        arrays[f"{tag}_demb"], arrays[f"{tag}_demb_sq"] = emb.grad.flatten()[idx], (emb.grad.double() ** 2).sum()
+        for j, (n, p_) in enumerate(enc.named_parameters()):
+            pi = _sample_idx(p_.numel(), 256, 100 + j)
+            arrays[f"{tag}_gidx.{n}"], arrays[f"{tag}_grad.{n}"] = pi, p_.grad.flatten()[pi]
+            arrays[f"{tag}_gsq.{n}"] = (p_.grad.double() ** 2).sum()
+    _save("encoder_bwd_wide.npz", **arrays)
+
+
+DUAL_STREAM_TEXT = {"embedding": ["word", "pos", "seg"], "encoder": "transformer", "remove_embedding_layernorm": False,
+                    "layernorm_positioning": "post", "max_seq_length": 20, "layers_num": 1}
+DUAL_STREAM_VIT = {"embedding": ["patch", "pos"], "encoder": "transformer", "remove_embedding_layernorm": True,
+                   "layernorm_positioning": "pre", "max_seq_length": 25, "layers_num": 1, "image_height": 32, "image_width": 48,
+                   "patch_size": 8, "channels_num": 3}
+
+
+def _dual_args(stream_0, stream_1, tie):
+    return _encoder_args("models/xlm-roberta/base_config.json", emb_size=128, hidden_size=128, feedforward_size=256, heads_num=2,
+                         layers_num=1, dropout=0.1, embedding=["dual"], encoder="dual", stream_0=dict(stream_0),
+                         stream_1=dict(stream_1), tie_weights=tie, image_height=32, image_width=48, patch_size=8, channels_num=3)
+
+
+def gen_dual():
+    """DualEmbedding + DualEncoder of the reference (embeddings/dual_embedding.py, encoders/dual_encoder.py) in eval mode:
+    a text stream (word + pos + seg, inner LayerNorm, stream LayerNorm, post-LN layer) beside an image stream (patch + pos,
+    no LayerNorms, pre-LN layer), and a tied text / text pair.  Stored: parameter names (the reference's order), the two
+    outputs, and every parameter gradient of sum(out_0 * w0) + sum(out_1 * w1)."""
+    from tencentpretrain.embeddings.dual_embedding import DualEmbedding
+    from tencentpretrain.encoders.dual_encoder import DualEncoder
+    arrays, meta = {}, {}
+    for tag, s0, s1, tie in (("tv", DUAL_STREAM_TEXT, DUAL_STREAM_VIT, False), ("tt", DUAL_STREAM_TEXT, DUAL_STREAM_TEXT, True)):
+        a = _dual_args(s0, s1, tie)
+        emb, enc = DualEmbedding(a, 100).eval(), DualEncoder(a).eval()
+        espec = [(n, tuple(p.shape)) for n, p in emb.named_parameters()]
+        nspec = [(n, tuple(p.shape)) for n, p in enc.named_parameters()]
+        meta[tag] = {"embedding": [[n, list(sh)] for n, sh in espec], "encoder": [[n, list(sh)] for n, sh in nspec]}
+        pe = O.seeded_params(espec, seed=81, std=0.3, skip_gamma_beta=False)
+        pn = O.seeded_params(nspec, seed=82, std=0.15, skip_gamma_beta=False)
+        # tied streams: state_dict() lists the shared tensors under both names, named_parameters() under the first only
+        emb.load_state_dict({k: pe[k if k in pe else k.replace("embedding_1.", "embedding_0.")] for k in emb.state_dict()}, strict=True)
+        enc.load_state_dict({k: pn[k if k in pn else k.replace("encoder_1.", "encoder_0.")] for k in enc.state_dict()}, strict=True)
+        g = torch.Generator().manual_seed(83)
+        src0 = torch.randint(0, 100, (3, 11), generator=g)
+        seg0 = torch.ones(3, 11, dtype=torch.long)
+        seg0[1, 7:] = 0
+        if tag == "tv":
+            src1 = torch.randn(3, 3, 32, 48, generator=g)
+            seg1 = torch.ones(3, 25, dtype=torch.long)
+        else:
+            src1 = torch.randint(0, 100, (3, 11), generator=g)
+            seg1 = torch.ones(3, 11, dtype=torch.long)
+            seg1[2, 4:] = 0
+        e0, e1 = emb((src0, src1), (seg0, seg1))
+        h0, h1 = enc((e0, e1), (seg0, seg1))
+        w0, w1 = torch.randn(h0.shape, generator=g), torch.randn(h1.shape, generator=g)
+        ((h0 * w0).sum() + (h1 * w1).sum()).backward()
+        arrays.update({f"{tag}_src0": src0, f"{tag}_seg0": seg0, f"{tag}_src1": src1, f"{tag}_seg1": seg1, f"{tag}_w0": w0,
+                       f"{tag}_w1": w1, f"{tag}_e0": e0.detach(), f"{tag}_e1": e1.detach(), f"{tag}_h0": h0.detach(),
+                       f"{tag}_h1": h1.detach()})
+        for n, p_ in emb.named_parameters():
+            arrays[f"{tag}_egrad.{n}"] = p_.grad.detach()
+        for n, p_ in enc.named_parameters():
+            arrays[f"{tag}_ngrad.{n}"] = p_.grad.detach()
+    with open(os.path.join(GOLD, "dual_keys.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+    _save("dual.npz", **arrays)
+
+
 def gen_readers():
     """Outputs of the reference's three LRMovieNet readers on the in-memory stand-in of oracle.fake_movienet (fake
     h5py.File, temp json), RNGs seeded: first items of every split, as plain integers."""
@@ -666,7 +763,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, trad=gen_trad)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -471,6 +471,27 @@ def text_embedding_spec(emb: int, vocab: int, max_seq: int, prefix: str = ""):
             (f"{prefix}seg.embedding.weight", (3, emb))]
 
 
+def dual_embedding(P: Params, src, seg, kinds, patch: int = 16, tied: bool = False):
+    """DualEmbedding.forward in eval mode (embeddings/dual_embedding.py:39-66): stream i = Embedding(kinds[i]) -- with its own
+    LayerNorm for the text composition (embedding.py:31-32) -- then `stream_i_layer_norm` when present (:56-58, :63-65).
+    kinds[i] in {"text", "vit"}; with tie_weights both streams use embedding_1's parameters, which the reference's
+    state_dict lists first under embedding_0 (:36-37)."""
+    outs = []
+    for i, kind in enumerate(kinds):
+        pre = "embedding_0." if tied else f"embedding_{i}."
+        e = text_embedding(P, src[i], seg[i], prefix=pre) if kind == "text" else vit_embedding(P, src[i], patch, prefix=pre)
+        if f"stream_{i}_layer_norm.gamma" in P:
+            e = layernorm_tp(e, P[f"stream_{i}_layer_norm.gamma"], P[f"stream_{i}_layer_norm.beta"])
+        outs.append(e)
+    return tuple(outs)
+
+
+def dual_encoder(P: Params, emb, seg, layers: int, heads: int, pre_ln, tied: bool = False):
+    """DualEncoder.forward (encoders/dual_encoder.py:27-47); pre_ln: one flag per stream."""
+    return tuple(transformer_encoder(P, emb[i], seg[i], layers, heads, pre_ln[i], prefix="encoder_0." if tied else f"encoder_{i}.")
+                 for i in range(2))
+
+
 def seeded_head_inputs(seed: int, bs: int, tags: int, n_img: int = 16, n_cls: int = 3):
     """Synthetic head inputs of the reference's shapes: text_emb ~ N(0,1) [bs,tags,196,768],
     img_emb ~ N(0,1) [bs,n_img,768] repeated over tags (finetune/ppo.py:831), tgts in {0..n_cls-1}."""

@@ -118,7 +118,7 @@ def test_header_symbols_are_declared_bound_and_exported(native):
     exported = set(re.findall(r" T (lr2_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
     lib = native.lib()
-    assert lib.lr2_abi_version() == int(re.search(r"#define LR2_ABI_VERSION (\d+)", hdr).group(1)) == 9
+    assert lib.lr2_abi_version() == int(re.search(r"#define LR2_ABI_VERSION (\d+)", hdr).group(1)) == native.ABI_VERSION
 
 
 def test_ctypes_structs_have_the_layout_the_c_compiler_gives_the_header(native, tmp_path):
@@ -254,3 +254,38 @@ def test_movienet_readers_match_reference_on_a_fake_h5(tmp_path, monkeypatch):
             for i, want in enumerate(g["items"]):
                 got = O.describe_reader_item(ds[i])
                 assert got == want, (name, split, i, got, want)
+
+
+def test_dual_embedding_and_encoder_keys_match_reference_order():
+    """dual_embedding.py:15-37 / dual_encoder.py:13-25: parameter names, shapes and registration order of the two-stream
+    wrappers (incl. tie_weights) equal the reference's (tests/golden/dual_keys.json, frozen from the imported reference)."""
+    import argparse
+    from lr2ppo_amd.tencentpretrain.embeddings import DualEmbedding
+    from lr2ppo_amd.tencentpretrain.encoders import DualEncoder
+    from lr2ppo_amd.tencentpretrain.opts import finetune_opts, tokenizer_opts
+    text = {"embedding": ["word", "pos", "seg"], "encoder": "transformer", "remove_embedding_layernorm": False,
+            "layernorm_positioning": "post", "max_seq_length": 20, "layers_num": 1}
+    vit = {"embedding": ["patch", "pos"], "encoder": "transformer", "remove_embedding_layernorm": True,
+           "layernorm_positioning": "pre", "max_seq_length": 25, "layers_num": 1, "image_height": 32, "image_width": 48,
+           "patch_size": 8, "channels_num": 3}
+    keys = json.load(open(os.path.join(GOLD, "dual_keys.json")))
+    for tag, s0, s1, tie in (("tv", text, vit, False), ("tt", text, text, True)):
+        p = argparse.ArgumentParser()
+        finetune_opts(p)
+        tokenizer_opts(p)
+        d = vars(p.parse_args([]))
+        d.update(emb_size=128, hidden_size=128, feedforward_size=256, heads_num=2, layers_num=1, dropout=0.1, hidden_act="gelu",
+                 embedding=["dual"], encoder="dual", stream_0=dict(s0), stream_1=dict(s1), tie_weights=tie, mask="fully_visible",
+                 image_height=32, image_width=48, patch_size=8, channels_num=3)
+        a = argparse.Namespace(**d)
+        emb, enc = DualEmbedding(a, 100), DualEncoder(a)
+        assert [[n, list(q.shape)] for n, q in emb.named_parameters()] == keys[tag]["embedding"], tag
+        assert [[n, list(q.shape)] for n, q in enc.named_parameters()] == keys[tag]["encoder"], tag
+        if tie:
+            assert emb.embedding_0 is emb.embedding_1 and enc.encoder_0 is enc.encoder_1
+
+
+def test_integration_doc_quotes_the_current_abi_version(native):
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    m = re.search(r"lr2_abi_version\(\) == (\d+)", doc)
+    assert m and int(m.group(1)) == native.ABI_VERSION

@@ -294,3 +294,78 @@ def test_trad_classifier_train_steps_match_reference():
         logits = O.trad_forward(P, g["feats_0"])
     ref = g["eval_logits"]
     assert (logits - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+# ---- round 2 fixtures: encoder backward at ViT-B/16 / RoBERTa-base width, DualEmbedding + DualEncoder ----------------------
+def sq_close(got, ref, rel):
+    """Sums of squares agree to `rel`; a gradient that is analytically zero (the key bias: softmax is shift-invariant
+    along the keys) is rounding noise on both sides and only has to stay tiny."""
+    return got < 1e-9 if ref < 1e-9 else abs(got / ref - 1.0) < rel
+
+
+def enc_bwd_wide_case(tag):
+    """Inputs of oracle/gen_golden.py::gen_encoder_bwd_wide, rebuilt from the same seeds (shared with the GPU test)."""
+    L = 197 if tag == "pre" else 196
+    P = O.seeded_params(O.encoder_param_spec(2, 768, 3072, tag == "pre"), seed=71, std=0.05, skip_gamma_beta=False)
+    g = torch.Generator().manual_seed(72)
+    emb = torch.randn(2, L, 768, generator=g)
+    wout = torch.randn(2, L, 768, generator=g)
+    seg = torch.ones(2, L, dtype=torch.long)
+    if tag == "post":
+        seg[1, 131:] = 0
+    return P, emb, wout, seg
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("tag", ["post", "pre"])
+def test_encoder_backward_wide_oracle_matches_reference_autograd(tag):
+    """A14 backward at hidden 768 / 12 heads / L = 197 and 196-with-padding: oracle autograd vs the reference's (sampled)."""
+    g = load_golden("encoder_bwd_wide.npz")
+    P, emb, wout, seg = enc_bwd_wide_case(tag)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    e = emb.clone().requires_grad_(True)
+    out = O.transformer_encoder(Pg, e, seg, 2, 12, tag == "pre")
+    (out * wout).sum().backward()
+    idx = g[f"{tag}_idx"]
+    assert (out.detach().flatten()[idx] - g[f"{tag}_out"]).abs().max() < 5e-5
+    ref = g[f"{tag}_demb"]
+    assert (e.grad.flatten()[idx] - ref).abs().max() < 5e-5 * max(1.0, float(ref.abs().max()))
+    assert abs(float((e.grad.double() ** 2).sum()) / float(g[f"{tag}_demb_sq"]) - 1.0) < 1e-4
+    for k in P:
+        ref = g[f"{tag}_grad.{k}"]
+        got = Pg[k].grad.flatten()[g[f"{tag}_gidx.{k}"]]
+        assert (got - ref).abs().max() < 5e-5 * max(1.0, float(ref.abs().max())), k
+        assert sq_close(float((Pg[k].grad.double() ** 2).sum()), float(g[f"{tag}_gsq.{k}"]), 1e-4), k
+
+
+def dual_case(tag):
+    """(embedding params, encoder params, kinds, pre_ln flags, tied) of oracle/gen_golden.py::gen_dual."""
+    import json
+    keys = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dual_keys.json")))[tag]
+    pe = O.seeded_params([(n, tuple(s)) for n, s in keys["embedding"]], seed=81, std=0.3, skip_gamma_beta=False)
+    pn = O.seeded_params([(n, tuple(s)) for n, s in keys["encoder"]], seed=82, std=0.15, skip_gamma_beta=False)
+    kinds = ("text", "vit") if tag == "tv" else ("text", "text")
+    pre_ln = (False, True) if tag == "tv" else (False, False)
+    return pe, pn, kinds, pre_ln, tag == "tt"
+
+
+@pytest.mark.parametrize("tag", ["tv", "tt"])
+def test_dual_embedding_and_encoder_oracle_match_reference(tag):
+    """A15: DualEmbedding (inner + stream LayerNorms) and DualEncoder (incl. tie_weights), forward and parameter gradients."""
+    g = load_golden("dual.npz")
+    pe, pn, kinds, pre_ln, tied = dual_case(tag)
+    Pe = {k: v.clone().requires_grad_(True) for k, v in pe.items()}
+    Pn = {k: v.clone().requires_grad_(True) for k, v in pn.items()}
+    src, seg = (g[f"{tag}_src0"], g[f"{tag}_src1"]), (g[f"{tag}_seg0"], g[f"{tag}_seg1"])
+    e = O.dual_embedding(Pe, src, seg, kinds, patch=8, tied=tied)
+    h = O.dual_encoder(Pn, e, seg, 1, 2, pre_ln, tied=tied)
+    ((h[0] * g[f"{tag}_w0"]).sum() + (h[1] * g[f"{tag}_w1"]).sum()).backward()
+    for i in range(2):
+        assert (e[i] - g[f"{tag}_e{i}"]).abs().max() < 2e-5
+        assert (h[i] - g[f"{tag}_h{i}"]).abs().max() < 5e-5
+    for k, v in Pe.items():
+        ref = g[f"{tag}_egrad.{k}"]
+        assert (v.grad - ref).abs().max() < 5e-5 * max(1.0, float(ref.abs().max())), k
+    for k, v in Pn.items():
+        ref = g[f"{tag}_ngrad.{k}"]
+        assert (v.grad - ref).abs().max() < 5e-5 * max(1.0, float(ref.abs().max())), k

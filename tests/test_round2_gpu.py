@@ -1,0 +1,296 @@
+"""Round-2 parity additions on a real MI355X: encoder backward at ViT-B/16 / RoBERTa-base width against the reference's
+autograd, DualEmbedding / DualEncoder (incl. tie_weights) forward + backward against the reference, the layer-level
+forwards, uint8 frame patchify, out-of-range ids, deterministic embedding backward, NDCG on the device."""
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import GOLD, load_golden
+from oracle import lr2ppo_oracle as O
+from test_encoder_gpu import ROBERTA, VIT, _args, _cmp, _err
+from test_oracle_golden import dual_case, enc_bwd_wide_case, sq_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", ["post", "pre"])
+def test_encoder_backward_at_production_width_matches_reference_autograd(dev, tag):
+    """2 layers x 768 x 12 heads, L = 197 (pre-LN) and L = 196 with padding (post-LN): the NT = 14 attention-backward
+    instantiation, LayerNorm backward at D = 768, dgrad / wgrad with GELU' at 768 / 3072 -- vs the reference (sampled)."""
+    from lr2ppo_amd.tencentpretrain.encoders import str2encoder
+    g = load_golden("encoder_bwd_wide.npz")
+    P, emb, wout, seg = enc_bwd_wide_case(tag)
+    cfg = dict(VIT if tag == "pre" else ROBERTA, layers_num=2, layernorm_positioning=tag)
+    enc = str2encoder["transformer"](_args(**cfg))
+    enc.load_state_dict(P, strict=True)
+    enc = enc.to(dev).eval()
+    e = emb.to(dev).requires_grad_(True)
+    out = enc(e, seg.to(dev))
+    (out * wout.to(dev)).sum().backward()
+    idx = g[f"{tag}_idx"]
+    _cmp(out.detach().flatten().cpu()[idx], g[f"{tag}_out"], "out")
+    _cmp(e.grad.flatten().cpu()[idx], g[f"{tag}_demb"], "demb")
+    assert sq_close(float((e.grad.double() ** 2).sum()), float(g[f"{tag}_demb_sq"]), 2e-3)
+    for n, p in enc.named_parameters():
+        ref = g[f"{tag}_grad.{n}"]
+        _cmp(p.grad.flatten().cpu()[g[f"{tag}_gidx.{n}"]], ref, n)
+        assert sq_close(float((p.grad.double() ** 2).sum()), float(g[f"{tag}_gsq.{n}"]), 2e-3), n
+
+
+DUAL_STREAM_TEXT = {"embedding": ["word", "pos", "seg"], "encoder": "transformer", "remove_embedding_layernorm": False,
+                    "layernorm_positioning": "post", "max_seq_length": 20, "layers_num": 1}
+DUAL_STREAM_VIT = {"embedding": ["patch", "pos"], "encoder": "transformer", "remove_embedding_layernorm": True,
+                   "layernorm_positioning": "pre", "max_seq_length": 25, "layers_num": 1, "image_height": 32, "image_width": 48,
+                   "patch_size": 8, "channels_num": 3}
+
+
+def _dual_modules(tag, dev, dropout=0.1):
+    from lr2ppo_amd.tencentpretrain.embeddings import DualEmbedding
+    from lr2ppo_amd.tencentpretrain.encoders import DualEncoder
+    s0, s1, tie = (DUAL_STREAM_TEXT, DUAL_STREAM_VIT, False) if tag == "tv" else (DUAL_STREAM_TEXT, DUAL_STREAM_TEXT, True)
+    a = _args(**{**ROBERTA, "emb_size": 128, "hidden_size": 128, "feedforward_size": 256, "heads_num": 2, "layers_num": 1,
+                 "dropout": dropout, "embedding": ["dual"], "encoder": "dual", "stream_0": dict(s0), "stream_1": dict(s1),
+                 "tie_weights": tie, "image_height": 32, "image_width": 48, "patch_size": 8, "channels_num": 3})
+    emb, enc = DualEmbedding(a, 100), DualEncoder(a)
+    keys = json.load(open(os.path.join(GOLD, "dual_keys.json")))[tag]
+    assert [[n, list(p.shape)] for n, p in emb.named_parameters()] == keys["embedding"]       # the reference's names and order
+    assert [[n, list(p.shape)] for n, p in enc.named_parameters()] == keys["encoder"]
+    pe, pn, _, _, _ = dual_case(tag)
+    emb.load_state_dict({k: pe[k if k in pe else k.replace("embedding_1.", "embedding_0.")] for k in emb.state_dict()}, strict=True)
+    enc.load_state_dict({k: pn[k if k in pn else k.replace("encoder_1.", "encoder_0.")] for k in enc.state_dict()}, strict=True)
+    return emb.to(dev), enc.to(dev)
+
+
+@pytest.mark.parametrize("tag", ["tv", "tt"])
+def test_dual_embedding_and_dual_encoder_match_reference(dev, tag):
+    """A15: DualEmbedding (inner + stream LayerNorm, both differentiable) + DualEncoder, untied text/image and tied
+    text/text: outputs and every parameter gradient against the reference's autograd (eval mode = dropout off)."""
+    g = load_golden("dual.npz")
+    emb, enc = _dual_modules(tag, dev)
+    emb.eval(), enc.eval()
+    if tag == "tt":
+        assert emb.embedding_0 is emb.embedding_1 and enc.encoder_0 is enc.encoder_1
+    src = (g[f"{tag}_src0"].to(dev), g[f"{tag}_src1"].to(dev))
+    seg = (g[f"{tag}_seg0"].to(dev), g[f"{tag}_seg1"].to(dev))
+    e = emb(src, seg)
+    h = enc(e, seg)
+    ((h[0] * g[f"{tag}_w0"].to(dev)).sum() + (h[1] * g[f"{tag}_w1"].to(dev)).sum()).backward()
+    for i in range(2):
+        _cmp(e[i], g[f"{tag}_e{i}"], f"e{i}")
+        _cmp(h[i], g[f"{tag}_h{i}"], f"h{i}")
+    for n, p in emb.named_parameters():
+        assert p.grad is not None, f"{n} received no gradient"
+        _cmp(p.grad, g[f"{tag}_egrad.{n}"], n)
+    for n, p in enc.named_parameters():
+        _cmp(p.grad, g[f"{tag}_ngrad.{n}"], n)
+
+
+def test_dual_embedding_train_mode_drops_both_streams_twice(dev):
+    """dual_embedding.py:51-52 applies self.dropout to both streams on top of each Embedding's own dropout: with p = 0.5 a
+    train-mode output keeps about a quarter of its entries (text stream: the inner drop is applied before the stream
+    LayerNorm, so only the outer one shows as zeros), and the masks are reproducible from the runtime's seed."""
+    from lr2ppo_amd import runtime
+    g = load_golden("dual.npz")
+    emb, _ = _dual_modules("tv", dev, dropout=0.5)
+    emb.train()
+    src = (g["tv_src0"].to(dev), g["tv_src1"].to(dev))
+    seg = (g["tv_seg0"].to(dev), g["tv_seg1"].to(dev))
+    runtime.set_dropout_seed(77)
+    with torch.no_grad():
+        a0, a1 = emb(src, seg)
+    runtime.set_dropout_seed(77)
+    with torch.no_grad():
+        b0, b1 = emb(src, seg)
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    z0, z1 = float((a0 == 0).float().mean()), float((a1 == 0).float().mean())
+    assert 0.4 < z0 < 0.6, z0                 # text: outer dropout only is visible after the stream LayerNorm
+    assert 0.65 < z1 < 0.85, z1               # image stream (no LayerNorms): inner and outer masks compound, 1 - 0.5^2
+    # and the gradient flows through both dropouts and the stream LayerNorm to the embedding tables
+    runtime.set_dropout_seed(77)
+    o0, o1 = emb(src, seg)
+    (o0.sum() + o1.sum()).backward()
+    assert emb.embedding_0.word.embedding.weight.grad.abs().sum() > 0
+    assert emb.stream_0_layer_norm.gamma.grad.abs().sum() > 0
+    assert emb.embedding_1.patch.projection.weight.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("tag", ["post", "pre"])
+def test_transformer_layer_forward_is_the_encoder_layer(dev, tag):
+    """layers/transformer.py:50-73: TransformerLayer.forward(hidden, mask) on its own == the matching layer of the oracle
+    encoder (no final LayerNorm), forward and backward; MultiHeadedAttention / PositionwiseFeedForward forwards too."""
+    from lr2ppo_amd.tencentpretrain.layers.transformer import TransformerLayer
+    a = _args(**{**ROBERTA, "hidden_size": 128, "emb_size": 128, "feedforward_size": 256, "heads_num": 2, "layers_num": 1,
+                 "layernorm_positioning": tag, "dropout": 0.0})
+    layer = TransformerLayer(a)
+    spec = [(n, tuple(p.shape)) for n, p in layer.named_parameters()]
+    P = O.seeded_params(spec, seed=5, std=0.2, skip_gamma_beta=False)
+    layer.load_state_dict(P, strict=True)
+    layer = layer.to(dev).eval()
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 40, 128, generator=gen)
+    seg = torch.ones(2, 40, dtype=torch.long)
+    seg[1, 25:] = 0
+    mask = ((1.0 - (seg > 0).unsqueeze(1).repeat(1, 40, 1).unsqueeze(1).float()) * -10000.0)
+    Pg = {"transformer.0." + k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xr = x.clone().requires_grad_(True)
+    # the oracle encoder adds the stack's final LayerNorm for pre-LN: give it an identity one and undo nothing -- compare
+    # against the layer body computed directly
+    mask_o = mask
+    if tag == "post":
+        ref = O.transformer_encoder(Pg, xr, seg, 1, 2, False)
+    else:
+        t = "transformer.0"
+        inter = O.layernorm_tp(xr, Pg[f"{t}.layer_norm_1.gamma"], Pg[f"{t}.layer_norm_1.beta"])
+        hmid = xr + O.tp_attention(Pg, f"{t}.self_attn", inter, mask_o, 2)
+        o = O.layernorm_tp(hmid, Pg[f"{t}.layer_norm_2.gamma"], Pg[f"{t}.layer_norm_2.beta"])
+        ref = O.linear(Pg, f"{t}.feed_forward.linear_2", O.gelu_erf(O.linear(Pg, f"{t}.feed_forward.linear_1", o))) + hmid
+    w = torch.randn(2, 40, 128, generator=gen)
+    (ref * w).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    out, prev = layer(xd, mask.to(dev))
+    assert prev is None
+    (out * w.to(dev)).sum().backward()
+    _cmp(out, ref.detach(), "layer out")
+    _cmp(xd.grad, xr.grad, "layer dx")
+    for n, p in layer.named_parameters():
+        if n.endswith("linear_layers.1.bias"):     # key bias: analytically zero gradient (softmax shift invariance), noise only
+            assert p.grad.abs().max().item() < 1e-4
+            continue
+        _cmp(p.grad, Pg["transformer.0." + n].grad, n)
+    with torch.no_grad():
+        xin = x.to(dev)
+        got, _ = layer.self_attn(xin, xin, xin, mask.to(dev))
+        want = O.tp_attention({k: v.detach() for k, v in Pg.items()}, "transformer.0.self_attn", x, mask, 2)
+        _cmp(got, want, "self_attn")
+        got = layer.feed_forward(xin)
+        Pd = {k: v.detach() for k, v in Pg.items()}
+        want = O.linear(Pd, "transformer.0.feed_forward.linear_2", O.gelu_erf(O.linear(Pd, "transformer.0.feed_forward.linear_1", x)))
+        _cmp(got, want, "feed_forward")
+    causal = torch.triu(torch.full((40, 40), -10000.0), 1).view(1, 1, 40, 40).repeat(2, 1, 1, 1)
+    with pytest.raises(NotImplementedError):
+        layer(xd, causal.to(dev))
+    with pytest.raises(RuntimeError):
+        layer.self_attn(xd, xd, xd, mask.to(dev))          # grad-enabled call of the inference-only forward: loud
+
+
+def test_uint8_frames_patchify_matches_loader_normalisation(dev):
+    """uint8 frames -> (x / 255 - mean) / std -> patch rows, fused (dataloader.py:559-561 + patch_embedding.py:27): the
+    planes written by the kernel equal the split of the torch expression bit for bit, for ps = 16, 8 and 14 (padded K)."""
+    from lr2ppo_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    for ps, H, W in ((16, 64, 48), (8, 32, 48), (14, 28, 56)):
+        frames = torch.randint(0, 256, (3, 3, H, W), generator=gen, dtype=torch.uint8)
+        x = frames.float().div(255)
+        mean, std = torch.tensor(ops.CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(ops.CLIP_STD).view(1, 3, 1, 1)
+        x = (x - mean) / std
+        P = (H // ps) * (W // ps)
+        Kd = 3 * ps * ps
+        Kp = (Kd + 63) // 64 * 64
+        rows = x.view(3, 3, H // ps, ps, W // ps, ps).permute(0, 2, 4, 1, 3, 5).reshape(3 * P, Kd)
+        want = torch.zeros(3 * P, Kp)
+        want[:, :Kd] = rows
+        pl = ops.Planes.empty(3 * P, Kp, dev)
+        ops.patchify_planes(frames.to(dev), pl, B=3, Cc=3, H=H, W=W, ps=ps, mean=ops.CLIP_MEAN, std=ops.CLIP_STD)
+        ref = ops.split_planes(want.to(dev), ops.Planes.empty(3 * P, Kp, dev))
+        assert torch.equal(pl.buf, ref.buf), ps
+        pl2 = ops.Planes.empty(3 * P, Kp, dev)                 # fp32 images take the same route
+        ops.patchify_planes(x.contiguous().to(dev), pl2, B=3, Cc=3, H=H, W=W, ps=ps)
+        assert torch.equal(pl2.buf, ref.buf), ps
+
+
+def test_vit_embedding_accepts_uint8_frames(dev):
+    from lr2ppo_amd import ops
+    from lr2ppo_amd.tencentpretrain.embeddings import Embedding, str2embedding
+    a = _args(**VIT)
+    emb = Embedding(a)
+    for n in a.embedding:
+        emb.update(str2embedding[n](a, 10), n)
+    emb.load_state_dict(O.seeded_params(O.vit_embedding_spec(768, 3, 16, 197), seed=61), strict=True)
+    emb = emb.to(dev).eval()
+    gen = torch.Generator().manual_seed(4)
+    frames = torch.randint(0, 256, (2, 3, 224, 224), generator=gen, dtype=torch.uint8)
+    x = (frames.float().div(255) - torch.tensor(ops.CLIP_MEAN).view(1, 3, 1, 1)) / torch.tensor(ops.CLIP_STD).view(1, 3, 1, 1)
+    seg = torch.ones(2, 197, dtype=torch.long, device=dev)
+    assert torch.equal(emb(frames.to(dev), seg), emb(x.to(dev), seg))
+    P = O.seeded_params(O.vit_embedding_spec(768, 3, 16, 197), seed=61)
+    _cmp(emb(frames.to(dev), seg), O.vit_embedding(P, x, 16), "vit embedding of uint8 frames")
+
+
+def test_out_of_range_ids_raise_like_nn_embedding(dev):
+    from lr2ppo_amd.tencentpretrain.embeddings import Embedding, str2embedding
+    a = _args(**{**ROBERTA, "emb_size": 32, "max_seq_length": 20, "dropout": 0.0})
+    emb = Embedding(a)
+    for n in a.embedding:
+        emb.update(str2embedding[n](a, 100), n)
+    emb = emb.to(dev).eval()
+    src = torch.randint(0, 100, (2, 8), device=dev)
+    seg = torch.ones(2, 8, dtype=torch.long, device=dev)
+    emb(src, seg)
+    bad = src.clone()
+    bad[1, 3] = 100
+    with pytest.raises(IndexError, match="token id"):
+        emb(bad, seg)
+    emb(src, seg)                                           # the error word was cleared
+    bad_seg = seg.clone()
+    bad_seg[0, 0] = 3
+    with pytest.raises(IndexError, match="segment id"):
+        emb(src, bad_seg)
+    with pytest.raises(IndexError):
+        emb(torch.zeros(1, 21, dtype=torch.long, device=dev), torch.ones(1, 21, dtype=torch.long, device=dev))   # > max_seq_length
+    emb.defer_id_check = True
+    emb(bad, seg)                                           # deferred: no raise here ...
+    with pytest.raises(IndexError):
+        emb.check_ids()                                     # ... but at the caller's synchronisation point
+
+
+def test_text_embedding_backward_is_deterministic_and_exact(dev):
+    """Word / segment table gradients without float atomics: identical bits run to run, equal to an index_add in fp64."""
+    from lr2ppo_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    rows, D, vocab = 1500, 768, 50
+    dx = torch.randn(rows, D, generator=gen)
+    ids = torch.randint(0, vocab, (rows,), generator=gen)
+    ids[:400] = 7                                           # one very frequent token
+    seg = torch.randint(0, 3, (rows,), generator=gen)
+    outs = []
+    for _ in range(3):
+        dword, dseg = torch.zeros(vocab + 5, D, device=dev), torch.zeros(3, D, device=dev)
+        ops.text_embed_bwd(dx.to(dev), ids.to(dev), seg.to(dev), dword, dseg, rows=rows, D=D)
+        outs.append((dword.cpu(), dseg.cpu()))
+    assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
+    want_w = torch.zeros(vocab + 5, D, dtype=torch.float64).index_add_(0, ids, dx.double())
+    want_s = torch.zeros(3, D, dtype=torch.float64).index_add_(0, seg, dx.double())
+    assert (outs[0][0].double() - want_w).abs().max() < 1e-4
+    assert (outs[0][1].double() - want_s).abs().max() < 2e-3
+    assert outs[0][0][vocab:].abs().max() == 0
+
+
+def test_ndcg_on_device_matches_reference_vectors_bit_for_bit(dev):
+    """f-4: lr2_ndcg against the fixtures frozen from the reference's AverageNDCGMeter (ndcg.npz), against the host meter on
+    256 ragged synthetic items, and the all-zero-gold branch."""
+    from lr2ppo_amd import ops
+    from lr2ppo_amd.ndcg import AverageNDCGMeter
+    g = load_golden("ndcg.npz")
+    n = int(g["n_cases"])
+    scores, gold, offs = [], [], [0]
+    for c in range(n):
+        scores.append(g[f"scores_{c}"].float().view(-1))
+        gold.append(g[f"gold_{c}"].long().view(-1))
+        offs.append(offs[-1] + scores[-1].numel())
+    out = ops.ndcg(torch.cat(scores).to(dev), torch.cat(gold).to(dev), torch.tensor(offs, dtype=torch.int64, device=dev)).cpu()
+    for c in range(n):
+        assert torch.equal(out[c], g[f"ndcg_{c}"].float()), (c, out[c], g[f"ndcg_{c}"])
+    gen = torch.Generator().manual_seed(12)
+    meter = AverageNDCGMeter()
+    scores, gold, offs, want = [], [], [0], []
+    for i in range(256):
+        T = int(torch.randint(1, 21, (1,), generator=gen))
+        s = torch.randn(T, generator=gen)
+        t = torch.randint(0, 3, (T,), generator=gen) if i % 17 else torch.zeros(T, dtype=torch.long)
+        scores.append(s), gold.append(t), offs.append(offs[-1] + T)
+        want.append(meter.return_ndcg_at_k_from_scores(s, t))
+    out = ops.ndcg(torch.cat(scores).to(dev), torch.cat(gold).to(dev), torch.tensor(offs, dtype=torch.int64, device=dev)).cpu()
+    assert (out - torch.stack(want)).abs().max() < 1e-6
+    assert torch.equal(out[0], torch.ones(6))              # item 0 has all-zero gold: ideal DCG 0 -> NDCG := 1
