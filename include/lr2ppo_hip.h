@@ -197,12 +197,17 @@ int lr2_period_rows_grad(const void* dy, void* dtable, int rows, int D, int peri
  * Outputs fp32:
  *   scalars[0]=policy loss, [1]=value loss, [2]=rank loss, [3]=positive-hinge count;
  *   per_item[4][B] = kl, entropy, rewards (r - w_kl*kl), advantages; dscores[B,T]; dvalue[B].
+ * Data-parallel form (RankLoss is one scalar over the GLOBAL batch): call once with stats_out (fp32[3]) set -- only
+ * {hinge sum, positive-hinge count, sum |A|} of this rank are written -- all-reduce(sum) those three floats over the
+ * `world` ranks, then call again with global_stats = the reduced sums: R, 1/count and mean |A| are then global and
+ * dscores is scaled so that the rank AVERAGE of the parameter gradients equals the gradient of the global-batch loss.
+ * stats_out == NULL and global_stats == NULL: the single-rank form.
  * replaces: finetune/ppo.py:544-584 (KL, entropy, advantage, flipped order, RankLoss :43-55, clipped value
  * loss :494-498) and their autograd backward. */
 int lr2_ppo_loss(const void* scores, const void* old_scores, const void* rewards, const void* old_value,
                  const void* value, const int64_t* next_state, int ns_len, int rank_len, int B, int T, float kl_w,
                  float ent_w, float value_clip, float margin, float adv_eps, void* scalars, void* per_item,
-                 void* dscores, void* dvalue, void* stream);
+                 void* dscores, void* dvalue, void* stats_out, const void* global_stats, int world, void* stream);
 
 /* SmoothL1(beta) mean loss + gradient (dpred may be NULL).  replaces: nn.SmoothL1Loss(beta=0.3) (finetune/ppo.py:236). */
 int lr2_smooth_l1(const void* pred, const void* target, int n, float beta, void* loss, void* dpred, void* stream);

@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "liblr2ppo_hip.so")
-SOURCES = ["gemm.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
+SOURCES = ["gemm.hip", "gemm256.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
 
 ABI_VERSION = 10     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
 
@@ -107,7 +107,7 @@ SIGNATURES = {
     "lr2_head_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lr2_add_period_rows": [_P, _P, _P, _I, _I, _I, _P],
     "lr2_period_rows_grad": [_P, _P, _I, _I, _I, _P],
-    "lr2_ppo_loss": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P],
+    "lr2_ppo_loss": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
     "lr2_smooth_l1": [_P, _P, _I, _F, _P, _P, _P],
     "lr2_pair_hinge": [_P, _I, _F, _P, _P, _P],
     "lr2_adamw_multi": [_P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _P],

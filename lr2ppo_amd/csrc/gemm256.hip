@@ -1,0 +1,251 @@
+// 256 x 256 "ping-pong" GEMM for large NT products of bf16 hi/lo planes:  C[M,N] = A[M,K] . B[N,K]^T  (fp32-grade,
+// three v_mfma_f32_16x16x32_bf16 products per tile pair: lo*hi + hi*lo + hi*hi, fp32 accumulate).
+//
+// Replaces, for the token GEMMs of the encoders and heads (M >= a few thousand rows), the cuBLAS sgemm calls reached
+// through nn.Linear in the reference (tencentpretrain/layers/multi_headed_attn.py:55-76, position_ffn.py:12-15,
+// finetune/ppo.py:164-170) -- same contract as gemm.hip's NT form, same fused epilogue (gemm_common.h).
+//
+// Structure (CDNA4, one workgroup of 8 waves per CU, 128 KiB of LDS):
+//   * tile 256 x 256, 32-deep K steps; wave (wr, wc) of a 2 x 4 grid owns a 128 x 64 block = 8 x 4 accumulator tiles
+//     (128 accumulator VGPRs).  A K step is 96 MFMAs per wave (32 tiles x 3 products) against 64 KiB of operands staged
+//     for the whole workgroup: 1.5x the matrix work per staged byte of a plain-bf16 256 x 256 x 64 step.
+//   * operands travel HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane) into a ring of 2 stages x 4 parts
+//     (A rows of accumulator half 0 / 1, B columns of half 0 / 1; hi and lo plane of a part are adjacent).  A part is
+//     refilled for K step t+2 as soon as its last reader of step t has passed, so 6-7 parts (12-14 KiB per wave) are in
+//     flight at any time; waits are COUNTED (s_waitcnt vmcnt(12) / (6)), never vmcnt(0), and barriers are bare s_barrier
+//     (a __syncthreads() would drain every in-flight DMA).  Past the last K step the refills become out-of-range
+//     requests (the buffer descriptor's range check writes zeros) so the counts stay uniform.
+//   * a K step is four phases, one accumulator quadrant each (A half x B half, 24 MFMAs): phase = LOAD section (issue 2
+//     DMA pieces, ds_read_b128 the fragments this phase is missing: 12 / 4 / 8 / 4 reads) + MFMA section.  The two wave
+//     groups (waves 0-3 and 4-7 = one wave per SIMD each) run ONE SECTION APART: while a group issues its 24 MFMAs its
+//     SIMD partner loads, so every SIMD's matrix pipe always has exactly one wave feeding it and the LDS / DMA work of
+//     the other hides underneath.  Two s_barrier per phase keep the groups in that lock step.
+//   * LDS image of a part: [128 rows][4 units of 16 B], unit u of row r at u ^ swz(r) (four 64-B rows share a 256-B
+//     bank row: conflict-free ds_read_b128); LDS-DMA writes lane-linearly, so the swizzle is applied to the SOURCE address.
+//   * hazards: a fragment read happens at least one barrier after every wave's counted wait for that part (RAW); a part is
+//     refilled one barrier after both groups' reads of it were retired by lgkmcnt(0) (WAR).
+#include "gemm_common.h"
+
+namespace lr2gemm {
+namespace g256 {
+
+constexpr int BM = 256, BN = 256, BK = 32;
+constexpr int NWAVES = 8;
+constexpr int PLANE = 128 * BK * 2;   // one plane of one part: 128 rows x 32 k x 2 B = 8 KiB
+constexpr int PART = 2 * PLANE;       // hi + lo
+constexpr int STAGE = 4 * PART;       // parts A0, B0, B1, A1
+constexpr int LDS_BYTES = 2 * STAGE;  // 128 KiB
+constexpr int SLOT_A0 = 0, SLOT_B0 = 1, SLOT_B1 = 2, SLOT_A1 = 3;
+constexpr uint32_t OOB = 0xFFFFFF00u;  // voffset beyond any descriptor this library builds (operands are < 4 GiB - 512 B)
+
+__device__ __forceinline__ int swz(int r) { return (4 - ((r >> 2) & 3)) & 3; }
+
+template <int IMM>
+__device__ __forceinline__ bf16x8_t lds_read16(uint32_t addr) {
+  u32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(IMM));
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+struct Ctx {
+  __amdgpu_buffer_rsrc_t a_hi, a_lo, b_hi, b_lo;
+  uint32_t voff_a[2], voff_b[2];   // per-lane source byte offsets of this wave's piece of part A(ah) / B(bh) at K step 0
+  uint32_t rd_a[2], rd_b[2];       // per-lane LDS read bases for stage 0 / 1
+  char* smem;
+  int wave, nt;
+};
+
+// Two DMA pieces (hi + lo plane) of one part for K step `tile` into stage `stage`.
+template <int SLOT, bool IS_A, int HALF>
+__device__ __forceinline__ void issue_part(const Ctx& c, int tile, int stage) {
+  const uint32_t base = IS_A ? c.voff_a[HALF] : c.voff_b[HALF];
+  const uint32_t v = (tile < c.nt) ? base + (uint32_t)tile * (BK * 2) : OOB;
+  char* dst = c.smem + stage * STAGE + SLOT * PART + c.wave * 1024;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_A ? c.a_hi : c.b_hi, LDS_PTR(dst), 16, v, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_A ? c.a_lo : c.b_lo, LDS_PTR(dst + PLANE), 16, v, 0, 0, 0);
+}
+
+template <int SLOT>
+__device__ __forceinline__ void read_a_half(uint32_t base, bf16x8_t (&hi)[4], bf16x8_t (&lo)[4]) {
+  hi[0] = lds_read16<SLOT * PART + 0 * 1024>(base);
+  hi[1] = lds_read16<SLOT * PART + 1 * 1024>(base);
+  hi[2] = lds_read16<SLOT * PART + 2 * 1024>(base);
+  hi[3] = lds_read16<SLOT * PART + 3 * 1024>(base);
+  lo[0] = lds_read16<SLOT * PART + PLANE + 0 * 1024>(base);
+  lo[1] = lds_read16<SLOT * PART + PLANE + 1 * 1024>(base);
+  lo[2] = lds_read16<SLOT * PART + PLANE + 2 * 1024>(base);
+  lo[3] = lds_read16<SLOT * PART + PLANE + 3 * 1024>(base);
+}
+template <int SLOT>
+__device__ __forceinline__ void read_b_half(uint32_t base, bf16x8_t (&hi)[2], bf16x8_t (&lo)[2]) {
+  hi[0] = lds_read16<SLOT * PART + 0 * 1024>(base);
+  hi[1] = lds_read16<SLOT * PART + 1 * 1024>(base);
+  lo[0] = lds_read16<SLOT * PART + PLANE + 0 * 1024>(base);
+  lo[1] = lds_read16<SLOT * PART + PLANE + 1 * 1024>(base);
+}
+
+// End of a LOAD section: retire the DMA parts the NEXT load section reads (counted), retire this section's fragment
+// reads, meet the other group.  s_waitcnt immediates (gfx9 encoding): vmcnt[3:0] in bits 3:0, vmcnt[5:4] in bits 15:14,
+// expcnt 7 (no wait) in bits 6:4, lgkmcnt in bits 11:8.
+template <int VM>
+__device__ __forceinline__ void end_load_section() {
+  constexpr int imm = (VM & 15) | ((VM >> 4) << 14) | (7 << 4) | (0 << 8);
+  __builtin_amdgcn_s_waitcnt(imm);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// 24 MFMAs of one accumulator quadrant: products lo*hi, hi*lo, hi*hi, eight independent accumulators between two
+// updates of the same one.
+template <int AH, int BH>
+__device__ __forceinline__ void mfma_section(f32x4_t (&acc)[8][4], const bf16x8_t (&ahi)[4], const bf16x8_t (&alo)[4],
+                                             const bf16x8_t (&bhi)[2], const bf16x8_t (&blo)[2]) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[AH * 4 + i][BH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi[j], acc[AH * 4 + i][BH * 2 + j], 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[AH * 4 + i][BH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo[j], acc[AH * 4 + i][BH * 2 + j], 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[AH * 4 + i][BH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi[j], acc[AH * 4 + i][BH * 2 + j], 0, 0, 0);
+  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// One K step (tile t, compile-time stage S).  Refill schedule (a part is refilled right after its last reader):
+//   load section 0 issues B0(t+1) [other stage], 1 issues A0(t+2), 2 issues B1(t+2), 3 issues A1(t+2) [this stage].
+template <int S>
+__device__ __forceinline__ void k_step(const Ctx& c, int t, f32x4_t (&acc)[8][4]) {
+  bf16x8_t ahi[4], alo[4], bhi[2], blo[2];
+  // phase 0: quadrant (A0, B0)
+  issue_part<SLOT_B0, false, 0>(c, t + 1, S ^ 1);
+  read_a_half<SLOT_A0>(c.rd_a[S], ahi, alo);
+  read_b_half<SLOT_B0>(c.rd_b[S], bhi, blo);
+  end_load_section<12>();
+  mfma_section<0, 0>(acc, ahi, alo, bhi, blo);
+  // phase 1: (A0, B1)
+  issue_part<SLOT_A0, true, 0>(c, t + 2, S);
+  read_b_half<SLOT_B1>(c.rd_b[S], bhi, blo);
+  end_load_section<12>();
+  mfma_section<0, 1>(acc, ahi, alo, bhi, blo);
+  // phase 2: (A1, B1)
+  issue_part<SLOT_B1, false, 1>(c, t + 2, S);
+  read_a_half<SLOT_A1>(c.rd_a[S], ahi, alo);
+  end_load_section<12>();
+  mfma_section<1, 1>(acc, ahi, alo, bhi, blo);
+  // phase 3: (A1, B0)
+  issue_part<SLOT_A1, true, 1>(c, t + 2, S);
+  read_b_half<SLOT_B0>(c.rd_b[S], bhi, blo);
+  end_load_section<6>();
+  mfma_section<1, 0>(acc, ahi, alo, bhi, blo);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  int tm, tn;
+  tile_coords(g.tiles_m, g.tiles_n, blockIdx.x, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  Ctx c;
+  c.smem = smem;
+  c.wave = wave;
+  c.nt = g.K / BK;
+  c.a_hi = uniform_rsrc(g.A, g.a_bytes);
+  c.a_lo = uniform_rsrc((const char*)g.A + g.a_lo_off, g.a_bytes);
+  c.b_hi = uniform_rsrc(g.B, g.b_bytes);
+  c.b_lo = uniform_rsrc((const char*)g.B + g.b_lo_off, g.b_bytes);
+  {
+    // this wave's 1-KiB piece of a part = local rows wave*16 .. +16; lane l fills unit (l & 3) of row (l >> 2), which holds
+    // K chunk (l & 3) ^ swz(row)
+    const int lr = wave * 16 + (lane >> 2);
+    const uint32_t ku = (uint32_t)((lane & 3) ^ swz(lr)) * 16u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int arow = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);   // part A(h): rows wr*128 + h*64 + [0, 64) of both wr
+      const int bcol = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);    // part B(h): cols wc*64 + h*32 + [0, 32) of all wc
+      const uint64_t oa = (uint64_t)arow * (uint64_t)g.lda * 2u + ku;
+      const uint64_t ob = (uint64_t)bcol * (uint64_t)g.ldb * 2u + ku;
+      c.voff_a[h] = oa < (uint64_t)OOB ? (uint32_t)oa : OOB;
+      c.voff_b[h] = ob < (uint64_t)OOB ? (uint32_t)ob : OOB;
+    }
+    const int r16 = lane & 15;
+    const uint32_t lane_off = (uint32_t)(r16 * 64 + (((lane >> 4) ^ swz(r16)) * 16));
+    const uint32_t sm = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      c.rd_a[s] = sm + s * STAGE + wr * 4096 + lane_off;     // A part: local row wr*64 + i*16 + r16
+      c.rd_b[s] = sm + s * STAGE + wc * 2048 + lane_off;     // B part: local row wc*32 + j*16 + r16
+    }
+  }
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: everything of K steps 0 and 1 except B0(1), in ring order
+  issue_part<SLOT_A0, true, 0>(c, 0, 0);
+  issue_part<SLOT_B1, false, 1>(c, 0, 0);
+  issue_part<SLOT_A1, true, 1>(c, 0, 0);
+  issue_part<SLOT_B0, false, 0>(c, 0, 0);
+  issue_part<SLOT_A0, true, 0>(c, 1, 1);
+  issue_part<SLOT_B1, false, 1>(c, 1, 1);
+  issue_part<SLOT_A1, true, 1>(c, 1, 1);
+  end_load_section<6>();                        // A0(0), B1(0), A1(0), B0(0) have landed, everyone's
+  if (wr == 1) {                                // waves 4-7 run one section behind waves 0-3 (wr is wave-uniform)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int t = 0; t < c.nt; t += 2) {
+    k_step<0>(c, t, acc);
+    if (t + 1 < c.nt) k_step<1>(c, t + 1, acc);
+  }
+  if (wr == 0) {                                // same number of barriers for every wave
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range tail refills have landed (zeros): LDS is reusable
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  float* slab = reinterpret_cast<float*>(smem) + wave * (32 * (64 + 4));
+  epilogue_wave<128, 64, 8, 4>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, nullptr);
+}
+
+}  // namespace g256
+
+// Host entry for gemm.hip's dispatcher.  Requirements (checked by the caller): planes x planes, NT, passes == 3,
+// K % 32 == 0, no split-K, operand extents < 4 GiB - 512 B.
+int launch_gemm256_nt(const GemmParams& p_in, hipStream_t stream) {
+  using namespace g256;
+  GemmParams p = p_in;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.partial = nullptr;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lr2_allow_dynamic_lds(gemm256_nt_kernel, LDS_BYTES, "gemm256")) return LR2_ERR_LAUNCH;
+    attr_set = true;
+  }
+  LR2_LAUNCH(gemm256_nt_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS_BYTES, stream, p);
+  return lr2_launch_status(__func__);
+}
+
+}  // namespace lr2gemm

@@ -271,7 +271,8 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(const float* __restrict_
                                                         int ns_len, int rank_len, int B, int T, float kl_w, float ent_w, float clip,
                                                         float margin, float adv_eps, float* __restrict__ scalars,
                                                         float* __restrict__ per_item, float* __restrict__ dscores,
-                                                        float* __restrict__ dvalue) {
+                                                        float* __restrict__ dvalue, float* __restrict__ stats_out,
+                                                        const float* __restrict__ global_stats, int world) {
   __shared__ float red[16];
   const int i = threadIdx.x;
   const bool act = i < B;
@@ -357,12 +358,22 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(const float* __restrict_
   const float ENT = block_sum_1024(ent, red);
   const float VL = block_sum_1024(vl, red);
   const float invB = 1.0f / (float)B;
-  const float R = (CNT > 0.f) ? HS / CNT : 0.f;
+  if (stats_out) {          // pass 1 of the data-parallel form: this rank's hinge sum / positive count / sum |A|, nothing else
+    if (threadIdx.x == 0) { stats_out[0] = HS; stats_out[1] = CNT; stats_out[2] = ABS; }
+    return;
+  }
+  // Data parallel (global_stats = the three sums all-reduced over `world` ranks): RankLoss is ONE scalar over the whole
+  // global batch (finetune/ppo.py:43-55), so R, its 1/count and mean |A| use the global sums; with the per-rank gradients
+  // averaged afterwards, d(loss_global)/d(score) x world is what this rank must emit, and world / (world * B) = 1 / B.
+  const float HSg = global_stats ? global_stats[0] : HS;
+  const float CNTg = global_stats ? global_stats[1] : CNT;
+  const float ABSm = global_stats ? global_stats[2] / (float)world : ABS;   // x invB below = global mean |A|
+  const float R = (CNTg > 0.f) ? HSg / CNTg : 0.f;
   if (threadIdx.x == 0) {
-    scalars[0] = R * ABS * invB - ent_w * ENT * invB;
+    scalars[0] = R * ABSm * invB - ent_w * ENT * invB;
     scalars[1] = VL * invB;
     scalars[2] = R;
-    scalars[3] = CNT;
+    scalars[3] = CNTg;
   }
   if (act) {
     per_item[0 * (size_t)B + i] = kl;
@@ -370,11 +381,11 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(const float* __restrict_
     per_item[2 * (size_t)B + i] = r;
     per_item[3 * (size_t)B + i] = adv;
     const float sgn = (adv > 0.f) ? 1.f : ((adv < 0.f) ? -1.f : 0.f);
-    const float invC = (CNT > 0.f) ? 1.0f / CNT : 0.f;
+    const float invC = (CNTg > 0.f) ? (global_stats ? (float)world : 1.0f) / CNTg : 0.f;
 #pragma unroll
     for (int t = 0; t < PPO_MAX_T; ++t)
       if (t < T) {
-        float gsc = ABS * invB * invC * dR[t];
+        float gsc = ABSm * invB * invC * dR[t];
         if (kl_w > 0.f) gsc += R * invB * sgn * (-kl_w) * (p[t] - qo[t]);
         if (ent_w > 0.f) gsc += ent_w * invB * p[t] * (clamped_log(p[t]) + ent);
         dscores[(size_t)i * T + t] = gsc;
@@ -796,16 +807,17 @@ extern "C" int lr2_period_rows_grad(const void* dy, void* dtable, int rows, int 
 extern "C" int lr2_ppo_loss(const void* scores, const void* old_scores, const void* rewards, const void* old_value,
                             const void* value, const int64_t* next_state, int ns_len, int rank_len, int B, int T,
                             float kl_w, float ent_w, float value_clip, float margin, float adv_eps, void* scalars,
-                            void* per_item, void* dscores, void* dvalue, void* stream) {
-  if (!scores || !old_scores || !rewards || !old_value || !value || !next_state || !scalars || !per_item || !dscores ||
-      !dvalue)
-    return LR2_ERR_ARG;
+                            void* per_item, void* dscores, void* dvalue, void* stats_out, const void* global_stats, int world,
+                            void* stream) {
+  if (!scores || !old_scores || !rewards || !old_value || !value || !next_state) return LR2_ERR_ARG;
+  if (!stats_out && (!scalars || !per_item || !dscores || !dvalue)) return LR2_ERR_ARG;
+  if (global_stats && world < 1) return LR2_ERR_ARG;
   if (B < 1 || B > 1024 || T < 1 || T > PPO_MAX_T || rank_len < 1 || rank_len > T || ns_len < rank_len) return LR2_ERR_SHAPE;
   const int threads = ((B + 63) / 64) * 64;
   LR2_LAUNCH(ppo_loss_kernel, dim3(1), dim3(threads), 0, (hipStream_t)stream, (const float*)scores,
                      (const float*)old_scores, (const float*)rewards, (const float*)old_value, (const float*)value,
                      next_state, ns_len, rank_len, B, T, kl_w, ent_w, value_clip, margin, adv_eps, (float*)scalars,
-                     (float*)per_item, (float*)dscores, (float*)dvalue);
+                     (float*)per_item, (float*)dscores, (float*)dvalue, (float*)stats_out, (const float*)global_stats, world);
   CHECK_LAUNCH();
 }
 

@@ -596,9 +596,20 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
     dscores, dvalue = torch.empty(bs, tags, device=dev), torch.empty(bs, device=dev)
     logits = actor.engine_forward(text, img, save=True)
     value = critic.engine_forward(text, img, state, save=True)
-    ops.ppo_loss(logits.view(bs, tags), old_scores.contiguous(), rewards.contiguous(), old_value.contiguous(), value,
-                 next_state.contiguous(), scal, per, dscores, dvalue, B=bs, T=tags, kl_w=args.kl_div_loss_weight,
-                 ent_w=args.entropy_weight, value_clip=args.value_clip, margin=0.01, adv_eps=-0.1)
+    loss_kw = dict(B=bs, T=tags, kl_w=args.kl_div_loss_weight, ent_w=args.entropy_weight, value_clip=args.value_clip,
+                   margin=0.01, adv_eps=-0.1)
+    loss_in = (logits.view(bs, tags), old_scores.contiguous(), rewards.contiguous(), old_value.contiguous(), value,
+               next_state.contiguous())
+    if dp.world > 1 and getattr(args, "global_rank_loss", True):
+        # RankLoss is one scalar over the whole batch (finetune/ppo.py:43-55): with the batch sharded over ranks its hinge
+        # sum / positive count (and mean |A|, which multiplies it) must be global before R is formed, or the rank-averaged
+        # gradient is not the gradient of the global-batch loss (SURVEY.md 8e caveat).  Three floats, one all-reduce.
+        stats = torch.empty(3, device=dev)
+        ops.ppo_loss(*loss_in, None, None, None, None, stats_out=stats, **loss_kw)
+        dist.all_reduce(stats)
+        ops.ppo_loss(*loss_in, scal, per, dscores, dvalue, global_stats=stats, world=dp.world, **loss_kw)
+    else:
+        ops.ppo_loss(*loss_in, scal, per, dscores, dvalue, **loss_kw)
     # out_layer.fc1.weight (96 % of each model): gradient GEMM and AdamW step in one kernel, the 2 GB gradient is never
     # materialised (args.fuse_fc1_update=False restores the separate wgrad + optimizer passes; same bits either way)
     fuse = getattr(args, "fuse_fc1_update", True) and hasattr(optimizer, "external_update") \

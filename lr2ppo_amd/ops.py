@@ -477,14 +477,16 @@ def period_rows_grad(dy, dtable, *, rows, D, period):
 
 
 def ppo_loss(scores, old_scores, rewards, old_value, value, next_state, scalars, per_item, dscores, dvalue, *, B, T,
-             kl_w, ent_w, value_clip, margin=0.01, adv_eps=-0.1, rank_len=2):
-    _chk_f32(scores, old_scores, rewards, old_value, value, scalars, per_item, dscores, dvalue)
+             kl_w, ent_w, value_clip, margin=0.01, adv_eps=-0.1, rank_len=2, stats_out=None, global_stats=None, world=1):
+    """stats_out (fp32[3]): write only this rank's {hinge sum, positive count, sum |A|} (pass 1 of the data-parallel form);
+    global_stats (fp32[3], all-reduced) + world: use the global RankLoss statistics (pass 2); see lr2_ppo_loss."""
+    _chk_f32(scores, old_scores, rewards, old_value, value, scalars, per_item, dscores, dvalue, stats_out, global_stats)
     if next_state.dtype != torch.int64 or not next_state.is_contiguous():
         raise TypeError("next_state must be contiguous int64")
     _nat.check(_nat.lib().lr2_ppo_loss(scores.data_ptr(), old_scores.data_ptr(), rewards.data_ptr(), old_value.data_ptr(),
                                  value.data_ptr(), next_state.data_ptr(), next_state.shape[1], rank_len, B, T, kl_w, ent_w,
-                                 value_clip, margin, adv_eps, scalars.data_ptr(), per_item.data_ptr(), dscores.data_ptr(),
-                                 dvalue.data_ptr(), _stream()), "lr2_ppo_loss")
+                                 value_clip, margin, adv_eps, _ptr(scalars), _ptr(per_item), _ptr(dscores), _ptr(dvalue),
+                                 _ptr(stats_out), _ptr(global_stats), world, _stream()), "lr2_ppo_loss")
 
 
 def smooth_l1(pred, target, loss, dpred=None, *, n, beta=0.3):

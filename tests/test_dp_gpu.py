@@ -18,3 +18,6 @@ def test_two_rank_update_keeps_replicas_identical(dev, fuse):
            "--master-port", "29611", os.path.join(REPO, "tests", "workers", "dp_gpu_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "DP_REHEARSAL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    # the exchanged gradient equals the mean of the two ranks' independently computed gradients (distinct data per rank),
+    # also through the fused out_layer.fc1 update; RankLoss statistics are global
+    assert "DP_GRADIENT_IS_RANK_MEAN_OK" in out.stdout and "GLOBAL_RANK_LOSS_OK" in out.stdout, out.stdout[-2000:]

@@ -233,41 +233,63 @@ def test_single_bf16_pass_is_not_good_enough(dev):
     assert 2e-4 < err < 2e-2, err
 
 
-def test_dp_factor_gather_path_equals_local_gradient(dev):
-    """Data-parallel schedule on one GPU with a mock 2-rank exchange that returns this rank's factors twice: the
-    averaged out_layer.fc1 gradient (one K = 2N wgrad GEMM with alpha = 1/2) must reproduce the local gradient."""
+def test_dp_factor_gather_path_equals_mean_of_distinct_rank_gradients(dev):
+    """Data-parallel schedule on one GPU with a mock 2-rank exchange over DISTINCT per-rank data: rank 0's factors come
+    from batch A (the live run), rank 1's from batch B (captured from a separate run).  The out_layer.fc1 gradient of the
+    K = 2N wgrad GEMM with alpha = 1/2 must equal (G_A + G_B) / 2 computed from two independent local backwards, in this
+    rank order (swapping the gathered blocks must give the same sum: the contraction runs over the stacked rows)."""
     from lr2ppo_amd import ops
     from lr2ppo_amd.finetune import ppo
+
+    bs, tags = 2, 2
+    actor = ppo.Actor(_ns(**ARGS), None)
+    actor.load_state_dict(O.seeded_params(O.head_param_spec("actor"), seed=7), strict=True)
+    actor = actor.to(dev).eval()
+    cases = []
+    for seed in (91, 92):
+        text, img, _ = O.seeded_head_inputs(seed, bs, tags)
+        w = torch.randn(bs * tags, generator=torch.Generator().manual_seed(seed)).to(dev)
+        cases.append((text.to(dev), img.to(dev), w))
+    local, factors = [], []
+    for text, img, w in cases:
+        actor.engine_forward(text, img, save=True)
+        actor.engine_backward(w)
+        local.append({n: g.clone() for n, g in actor.grad_buffers().items()})
+        ws = actor._ws
+        N, F, Wflat = bs * tags, 3072, (196 + 16) * 768
+        factors.append({"dzo_all": ws.planes("dzo", N, F).buf.clone(), "flat_all": ws.planes("flat", N, Wflat).buf.clone()})
+    assert _maxerr(local[0]["out_layer.fc1.weight"], local[1]["out_layer.fc1.weight"].cpu()) > 1e-4     # really distinct
 
     class MockDP:
         world = 2
 
+        def __init__(self, order):
+            self.order = order
+
         def gather_planes_start(self, pl, ws, name):
             n = pl.rows * pl.cols
             out = ws.planes(name, pl.rows * 2, pl.cols)
-            for r in range(2):
-                out.buf[r * n:(r + 1) * n].copy_(pl.buf[:n])
-                out.buf[out.lo_off + r * n:out.lo_off + (r + 1) * n].copy_(pl.buf[pl.lo_off:pl.lo_off + n])
+            for slot, r in enumerate(self.order):       # r == 0: this rank's live factors; r == 1: the other rank's
+                src = pl.buf if r == 0 else factors[1][name]
+                src_lo = pl.lo_off if r == 0 else n
+                out.buf[slot * n:(slot + 1) * n].copy_(src[:n])
+                out.buf[out.lo_off + slot * n:out.lo_off + (slot + 1) * n].copy_(src[src_lo:src_lo + n])
             return out, []
 
         def gather_planes_finish(self, pending):
             return pending[0]
 
-    bs, tags = 2, 2
-    text, img, _ = O.seeded_head_inputs(91, bs, tags)
-    actor = ppo.Actor(_ns(**ARGS), None)
-    actor.load_state_dict(O.seeded_params(O.head_param_spec("actor"), seed=7), strict=True)
-    actor = actor.to(dev).eval()
-    w = torch.randn(bs * tags, generator=torch.Generator().manual_seed(3)).to(dev)
-    actor.engine_forward(text.to(dev), img.to(dev), save=True)
-    actor.engine_backward(w)
-    ref = {n: g.clone() for n, g in actor.grad_buffers().items()}
-    actor.engine_forward(text.to(dev), img.to(dev), save=True)
-    actor.engine_backward(w, MockDP())
-    G = actor.grad_buffers()
-    for n in ref:
-        scale = float(ref[n].abs().max())
-        assert _maxerr(G[n], ref[n]) <= 1e-9 + 1e-4 * scale, n
+    want = (local[0]["out_layer.fc1.weight"] + local[1]["out_layer.fc1.weight"]) / 2
+    scale = float(want.abs().max())
+    for order in ((0, 1), (1, 0)):
+        text, img, w = cases[0]
+        actor.engine_forward(text, img, save=True)
+        actor.engine_backward(w, MockDP(order))
+        G = actor.grad_buffers()
+        assert _maxerr(G["out_layer.fc1.weight"], want.cpu()) <= 1e-9 + 2e-5 * scale, order
+        for n in local[0]:
+            if n != "out_layer.fc1.weight":        # everything else is this rank's local gradient until the all-reduce
+                assert _maxerr(G[n], local[0][n].cpu()) <= 1e-9 + 1e-4 * float(local[0][n].abs().max()), n
 
 
 def test_evaluate_ndcg_matches_oracle_scores(dev):
@@ -289,6 +311,51 @@ def test_evaluate_ndcg_matches_oracle_scores(dev):
             scores = O.actor_forward(P, text.unsqueeze(0), img.unsqueeze(0).unsqueeze(1).repeat(1, 20, 1, 1), None).view(-1)
             rows.append(O.ndcg_vector(scores, tgts))
     ref = torch.stack(rows).mean(0)                  # NDCG@{1,3,5,10,20,all}
+    got = args.last_ndcg
+    for j, k in enumerate((1, 3, 5, 10, 20, 100000000)):
+        assert abs(got[k] - float(ref[j])) <= 0.002, (k, got[k], float(ref[j]))
+    assert abs(float(vals) - float(ref[5])) <= 0.002
+
+
+def test_ndcg_gate_256_items_after_two_update_cycles(dev):
+    """BASELINE.md section 3's gate: NDCG@k of 256 synthetic validation items x 20 tags within +-0.002 of the CPU oracle
+    on identical seeds, AFTER two PPO update cycles (the cycles of the reference fixture train_step.npz, whose post-update
+    weights test_train_model_two_cycles_match_reference_golden pins to the reference).  evaluate() = HIP actor + the
+    device NDCG kernel; the checker scores the same items with the oracle on the host using the updated weights."""
+    from lr2ppo_amd.finetune import ppo
+    from torch.utils.data import DataLoader
+    g = load_golden("train_step.npz")
+    bs, tags = int(g["bs"]), int(g["tags"])
+    args = _ns(**ARGS, is_master=True, kl_div_loss_weight=0.001, entropy_weight=0.001, value_clip=0.5, optimizer="adamw",
+               scheduler="linear", learning_rate=1e-3, critic_learning_rate=1e-3, train_steps=41, warmup=0.1, device=dev)
+    model = ppo.ActorCritic(args, None)
+    _load(model.actor, "actor", 7, dev)
+    _load(model.critic, "critic", 8, dev)
+    model = model.to(dev)
+    reward = _load(ppo.Reward(args, None).eval(), "reward", 9, dev)
+    opt, copt, sch, csch = ppo.build_optimizer(args, model)
+    model.eval()
+    before = model.actor.head.weight.detach().clone()
+    for cycle in range(2):
+        memories = []
+        for mb in range(2):
+            text, img, tgts = O.seeded_head_inputs(1000 + 10 * cycle + mb, bs, tags)
+            memories.append(ppo.rollout_step(model, reward, text.to(dev), img.to(dev), tgts.to(dev)))
+        ppo.train_model(args, model, opt, copt, sch, csch, memories, 1)
+    assert not torch.equal(before, model.actor.head.weight.detach())
+    args.model = model
+    ds = ppo.SyntheticMovieNet(256, 20, 16, seed=5)
+    vals = ppo.evaluate(args, DataLoader(ds, batch_size=1), 0, split="val", num_tasks=1)
+    P = {k: v.detach().cpu() for k, v in model.actor.state_dict().items()}
+    rows = []
+    with torch.no_grad():
+        for i0 in range(0, len(ds), 8):
+            items = [ds[i] for i in range(i0, min(i0 + 8, len(ds)))]
+            text = torch.stack([it[0] for it in items])
+            img = torch.stack([it[1] for it in items]).unsqueeze(1).repeat(1, 20, 1, 1)
+            scores = O.actor_forward(P, text, img, None).view(len(items), 20)
+            rows += [O.ndcg_vector(scores[j], items[j][2]) for j in range(len(items))]
+    ref = torch.stack(rows).mean(0)
     got = args.last_ndcg
     for j, k in enumerate((1, 3, 5, 10, 20, 100000000)):
         assert abs(got[k] - float(ref[j])) <= 0.002, (k, got[k], float(ref[j]))

@@ -294,3 +294,66 @@ def test_ndcg_on_device_matches_reference_vectors_bit_for_bit(dev):
     out = ops.ndcg(torch.cat(scores).to(dev), torch.cat(gold).to(dev), torch.tensor(offs, dtype=torch.int64, device=dev)).cpu()
     assert (out - torch.stack(want)).abs().max() < 1e-6
     assert torch.equal(out[0], torch.ones(6))              # item 0 has all-zero gold: ideal DCG 0 -> NDCG := 1
+
+
+# ---- the 256 x 256 ping-pong NT kernel (csrc/gemm256.hip) ---------------------------------------------------------------------
+def _planes(ops, x, dev):
+    return ops.split_planes(x.to(dev).contiguous(), ops.Planes.empty(x.shape[0], x.shape[1], dev))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (256, 256, 64), (512, 768, 768), (700, 520, 96), (1000, 3072, 160), (130, 260, 3072)])
+def test_gemm256_nt_matches_fp64(dev, M, N, K):
+    """Every K-step parity (1, 2, odd, even counts), ragged M and N, several tiles per workgroup column: against fp64, and
+    against the general kernel (same split-bf16 arithmetic, different summation order)."""
+    import math
+    from lr2ppo_amd import ops
+    from test_kernels_gpu import _close
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    ref = a.double() @ b.double().t()
+    ap, bp = _planes(ops, a, dev), _planes(ops, b, dev)
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(ap, bp, out, M, N, K, block_m=256, splits=1)
+    _close(out, ref, atol=6e-5 * math.sqrt(K), rtol=5e-5, what="gemm256")
+    out128 = torch.empty((M, N), device=dev)
+    ops.gemm(ap, bp, out128, M, N, K, block_m=128, splits=1)
+    _close(out, out128.double().cpu(), atol=2e-5 * math.sqrt(K), rtol=2e-5, what="gemm256 vs general kernel")
+
+
+def test_gemm256_exact_on_integers_and_asymmetric(dev):
+    """Small-integer operands make every product and sum exact in the split-bf16 arithmetic: the tile / wave / quadrant /
+    fragment index maps are checked bit for bit (an asymmetric B catches a transposed output; distinct values per row and
+    column catch a swapped half or plane)."""
+    from lr2ppo_amd import ops
+    M, N, K = 512, 512, 128
+    g = torch.Generator().manual_seed(1)
+    a = torch.randint(-3, 4, (M, K), generator=g).float() + torch.arange(M).float().view(-1, 1) % 5
+    b = torch.randint(-3, 4, (N, K), generator=g).float() + (torch.arange(N).float().view(-1, 1) % 7) * 2
+    ref = (a.double() @ b.double().t()).float()
+    out = torch.empty(M, N, device=dev)
+    ops.gemm(_planes(ops, a, dev), _planes(ops, b, dev), out, M, N, K, block_m=256, splits=1)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_gemm256_fused_epilogues(dev):
+    """bias + GELU (+ saved z) + planes output, dropout + residual, strided planes output (the QKV / FFN epilogues of the
+    encoder forward), on the 256 kernel."""
+    from lr2ppo_amd import ops
+    from test_kernels_gpu import _close
+    g = torch.Generator().manual_seed(19)
+    M, N, K = 600, 512, 256
+    a, w, bias, resid = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g), \
+        torch.randn(M, N, generator=g)
+    ap, wp = _planes(ops, a, dev), _planes(ops, w, dev)
+    z_ref = a.double() @ w.double().t() + bias.double()
+    out, z, pl = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev), ops.Planes.empty(M, N, dev)
+    ops.gemm(ap, wp, out, M, N, K, bias=bias.to(dev), act=1, out_z=z, out_planes=pl, block_m=256, splits=1)
+    _close(z, z_ref, 1e-4, 5e-5, "z")
+    _close(out, O.gelu_erf(z_ref), 1e-4, 5e-5, "gelu")
+    assert torch.equal(pl.to_float(), out)                                  # hi + lo reproduces the fp32 result to 17 bits ...
+    ref_pl = ops.split_planes(out, ops.Planes.empty(M, N, dev))
+    assert torch.equal(pl.buf, ref_pl.buf)                                  # ... and is the split of it bit for bit
+    drop = ops.Drop(0.1, seed=77, site=3)
+    ops.gemm(ap, wp, out, M, N, K, bias=bias.to(dev), drop=drop, resid=resid.to(dev), block_m=256, splits=1)
+    keep = torch.from_numpy(O.dropout_keep_mask(77, 3, M * N, 0.1)).view(M, N)
+    _close(out, z_ref * keep.double() / 0.9 + resid.double(), 1e-4, 5e-5, "dropout+resid")

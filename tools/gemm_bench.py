@@ -23,6 +23,9 @@ SHAPES = [  # (form, M, N, K) as ops.gemm sees them
     # small GEMMs of the PPO step (image tokens, tail, out_layer.fc2): where split-K + its reduce launch compete with one pass
     ("NT", 1024, 768, 768), ("NN", 1024, 3072, 768), ("NT", 1024, 768, 3072), ("NT", 64, 768, 3072), ("NT", 256, 768, 768),
     ("TN", 768, 768, 1024), ("TN", 3072, 768, 1024), ("NN", 1024, 768, 3072),
+    # 31..: ViT-B/16 forward over 512 frames (M = 512 * 197) and the pointwise head at 20 tags (M = 640 * 196)
+    ("NT", 100864, 768, 768), ("NT", 100864, 768, 3072), ("NT", 125440, 3072, 768), ("NT", 125440, 768, 3072),
+    ("NT", 8192, 8192, 8192),
 ]
 
 
