@@ -581,7 +581,17 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   }
   // planes x planes with a contraction-strided B (NN, TN): 32-deep K tiles, two LDS stages (64 KB), two workgroups per
   // CU -- measured +10-14 % on the wgrad shapes; NT and anything with an fp32 operand: 64-deep tiles, one stage.
-  const int BK = (a_planes && b_planes) ? (bk_env ? bk_env : (trans_b ? 32 : 64)) : 64;
+  static int g256_env = -1;
+  if (g256_env < 0) {
+    const char* e = getenv("LR2_GEMM_256");
+    g256_env = e ? atoi(e) : 1;
+  }
+  // Large NT products of planes: the 256 x 256 ping-pong kernel (gemm256.hip, 32-deep K steps) when the caller asks for it
+  // (block_m == 256) and the shape is eligible; otherwise the general kernel family.
+  const bool use256 = want256 && g256_env && a_planes && b_planes && !trans_a && !trans_b && passes == 3 && splits <= 1 &&
+                      (K % 32) == 0 && a_bytes <= 0xFFFFFD00ull && b_bytes <= 0xFFFFFD00ull && !epi->adam_p &&
+                      ((epi->act == 2) + (epi->resid != nullptr) + (epi->accumulate != 0)) <= 1;   // one request slot per element
+  const int BK = use256 ? 32 : (a_planes && b_planes) ? (bk_env ? bk_env : (trans_b ? 32 : 64)) : 64;
   if ((!trans_a || !trans_b) && (K % BK != 0)) return LR2_ERR_SHAPE;
   const int a_align = a_planes ? 8 : 4, b_align = b_planes ? 8 : 4;  // 16-byte rows
   if ((lda % a_align) || (ldb % b_align) || (N % 4)) return LR2_ERR_SHAPE;
@@ -610,7 +620,7 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   p.b_lo_off = (uint32_t)b_lo_off;
   p.k_tiles_per_split = (total_k_tiles + splits - 1) / splits;
   splits = (total_k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
-  p.partial = splits > 1 ? (float*)splitk_ws : nullptr;
+  p.partial = (splits > 1 || (ablate & 32)) ? (float*)splitk_ws : nullptr;
   p.epi = to_device_epilogue(epi);
   p.ablate = ablate;
   // 128 x 128 planes tiles, NT / NN: 8-wave workgroups (two workgroups per CU = 4 waves per SIMD) overlap the MFMA issue,
@@ -620,16 +630,7 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   p.dma_stages = stages ? (stages == 1 ? 1 : 2) : (BK == 32 ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  // Large NT products of planes: the 256 x 256 ping-pong kernel (gemm256.hip) when the caller asks for it (block_m == 256)
-  // and the shape is eligible; otherwise the general kernel family below.
-  static int g256_env = -1;
-  if (g256_env < 0) {
-    const char* e = getenv("LR2_GEMM_256");
-    g256_env = e ? atoi(e) : 1;
-  }
-  if (want256 && g256_env && a_planes && b_planes && !trans_a && !trans_b && passes == 3 && splits == 1 && (K % 32) == 0 &&
-      a_bytes <= 0xFFFFFD00ull && b_bytes <= 0xFFFFFD00ull && !epi->adam_p)
-    return launch_gemm256_nt(p, s);
+  if (use256) return launch_gemm256_nt(p, s);
   if (a_planes && b_planes && BK == 32) rc = dispatch_form<32, true, true>(p, splits, block_m, passes, trans_a, trans_b, s);
   else if (a_planes && b_planes) rc = dispatch_form<64, true, true>(p, splits, block_m, passes, trans_a, trans_b, s);
   else if (a_planes) rc = dispatch_form<64, true, false>(p, splits, block_m, passes, trans_a, trans_b, s);

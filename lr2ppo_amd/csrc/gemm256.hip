@@ -24,6 +24,8 @@
 //     bank row: conflict-free ds_read_b128); LDS-DMA writes lane-linearly, so the swizzle is applied to the SOURCE address.
 //   * hazards: a fragment read happens at least one barrier after every wave's counted wait for that part (RAW); a part is
 //     refilled one barrier after both groups' reads of it were retired by lgkmcnt(0) (WAR).
+#include <stdlib.h>
+
 #include "gemm_common.h"
 
 namespace lr2gemm {
@@ -123,34 +125,42 @@ __device__ __forceinline__ void mfma_section(f32x4_t (&acc)[8][4], const bf16x8_
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// One K step (tile t, compile-time stage S).  Refill schedule (a part is refilled right after its last reader):
-//   load section 0 issues B0(t+1) [other stage], 1 issues A0(t+2), 2 issues B1(t+2), 3 issues A1(t+2) [this stage].
-template <int S>
+// One K step (tile t, compile-time stage S).  A part may be refilled once its last reader has passed (A0 after load
+// section 0, B1 after 1, A1 after 2, B0 after 3).  Two placements of the refills (V, A/B-tested in one process with
+// LR2_GEMM256_VARIANT):
+//   V = 0: as early as possible, 2 pieces per section: 0: B0(t+1) [other stage]  1: A0(t+2)  2: B1(t+2)  3: A1(t+2)
+//   V = 1: in the two light sections only (no section carries 12 fragment reads AND DMA issue):
+//          1: B0(t+1), A0(t+2)   3: B1(t+2), A1(t+2)
+// The counted waits leave exactly the parts issued after the one the NEXT section reads in flight (2 pieces per part).
+template <int S, int V>
 __device__ __forceinline__ void k_step(const Ctx& c, int t, f32x4_t (&acc)[8][4]) {
   bf16x8_t ahi[4], alo[4], bhi[2], blo[2];
   // phase 0: quadrant (A0, B0)
-  issue_part<SLOT_B0, false, 0>(c, t + 1, S ^ 1);
+  if (V == 0) issue_part<SLOT_B0, false, 0>(c, t + 1, S ^ 1);
   read_a_half<SLOT_A0>(c.rd_a[S], ahi, alo);
   read_b_half<SLOT_B0>(c.rd_b[S], bhi, blo);
-  end_load_section<12>();
+  end_load_section<V == 0 ? 12 : 10>();
   mfma_section<0, 0>(acc, ahi, alo, bhi, blo);
   // phase 1: (A0, B1)
+  if (V == 1) issue_part<SLOT_B0, false, 0>(c, t + 1, S ^ 1);
   issue_part<SLOT_A0, true, 0>(c, t + 2, S);
   read_b_half<SLOT_B1>(c.rd_b[S], bhi, blo);
   end_load_section<12>();
   mfma_section<0, 1>(acc, ahi, alo, bhi, blo);
   // phase 2: (A1, B1)
-  issue_part<SLOT_B1, false, 1>(c, t + 2, S);
+  if (V == 0) issue_part<SLOT_B1, false, 1>(c, t + 2, S);
   read_a_half<SLOT_A1>(c.rd_a[S], ahi, alo);
-  end_load_section<12>();
+  end_load_section<V == 0 ? 12 : 10>();
   mfma_section<1, 1>(acc, ahi, alo, bhi, blo);
   // phase 3: (A1, B0)
+  if (V == 1) issue_part<SLOT_B1, false, 1>(c, t + 2, S);
   issue_part<SLOT_A1, true, 1>(c, t + 2, S);
   read_b_half<SLOT_B0>(c.rd_b[S], bhi, blo);
   end_load_section<6>();
   mfma_section<1, 0>(acc, ahi, alo, bhi, blo);
 }
 
+template <int V>
 __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
   Ctx c;
   c.smem = smem;
   c.wave = wave;
-  c.nt = g.K / BK;
+  c.nt = (g.ablate & 16) ? 0 : g.K / BK;      // diagnostics (LR2_GEMM_ABLATE): 16 = no main loop, 8 = no epilogue memory traffic
   c.a_hi = uniform_rsrc(g.A, g.a_bytes);
   c.a_lo = uniform_rsrc((const char*)g.A + g.a_lo_off, g.a_bytes);
   c.b_hi = uniform_rsrc(g.B, g.b_bytes);
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // prologue: everything of K steps 0 and 1 except B0(1), in ring order
+  // prologue: everything of K steps 0 and 1 except B0(1), in the steady-state issue order
   issue_part<SLOT_A0, true, 0>(c, 0, 0);
   issue_part<SLOT_B1, false, 1>(c, 0, 0);
   issue_part<SLOT_A1, true, 1>(c, 0, 0);
@@ -213,9 +223,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
+  // diagnostics (LR2_GEMM_ABLATE & 32, never in a timed run): shader cycles and 100 MHz ticks of the main loop, per
+  // workgroup, into the split-K workspace pointer (unused by this kernel) -> the clock the chip holds under this load
+  uint64_t tc0 = 0, tr0 = 0;
+  if (g.ablate & 32) {
+    tc0 = __builtin_amdgcn_s_memtime();
+    tr0 = __builtin_amdgcn_s_memrealtime();
+  }
   for (int t = 0; t < c.nt; t += 2) {
-    k_step<0>(c, t, acc);
-    if (t + 1 < c.nt) k_step<1>(c, t + 1, acc);
+    k_step<0, V>(c, t, acc);
+    if (t + 1 < c.nt) k_step<1, V>(c, t + 1, acc);
+  }
+  if ((g.ablate & 32) && g.partial && tid == 0) {
+    const uint64_t tc1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+    uint64_t* dbg = reinterpret_cast<uint64_t*>(g.partial) + 2 * (size_t)blockIdx.x;
+    dbg[0] = tc1 - tc0;
+    dbg[1] = tr1 - tr0;
   }
   if (wr == 0) {                                // same number of barriers for every wave
     __builtin_amdgcn_s_barrier();
@@ -226,7 +249,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
   __builtin_amdgcn_sched_barrier(0);
 
   float* slab = reinterpret_cast<float*>(smem) + wave * (32 * (64 + 4));
-  epilogue_wave<128, 64, 8, 4>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, nullptr);
+  if (g.ablate & 8) {
+    GemmParams g2 = g;
+    g2.M = 0;
+    epilogue_wave<128, 64, 8, 4, 1>(g2, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, nullptr);
+    return;
+  }
+  epilogue_wave<128, 64, 8, 4, 1>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, nullptr);
 }
 
 }  // namespace g256
@@ -238,13 +267,17 @@ int launch_gemm256_nt(const GemmParams& p_in, hipStream_t stream) {
   GemmParams p = p_in;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  p.partial = nullptr;
+  if (!(p.ablate & 32)) p.partial = nullptr;
   static bool attr_set = false;
   if (!attr_set) {
-    if (lr2_allow_dynamic_lds(gemm256_nt_kernel, LDS_BYTES, "gemm256")) return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(gemm256_nt_kernel<0>, LDS_BYTES, "gemm256")) return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(gemm256_nt_kernel<1>, LDS_BYTES, "gemm256")) return LR2_ERR_LAUNCH;
     attr_set = true;
   }
-  LR2_LAUNCH(gemm256_nt_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS_BYTES, stream, p);
+  const char* ve = getenv("LR2_GEMM256_VARIANT");     // read per call: tools A/B the variants inside one process
+  const int variant = ve ? atoi(ve) : 0;
+  if (variant == 1) LR2_LAUNCH(gemm256_nt_kernel<1>, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS_BYTES, stream, p);
+  else LR2_LAUNCH(gemm256_nt_kernel<0>, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS_BYTES, stream, p);
   return lr2_launch_status(__func__);
 }
 

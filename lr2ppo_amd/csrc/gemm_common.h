@@ -63,12 +63,35 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int bid, i
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-__device__ __forceinline__ void epilogue_vec4(const Epilogue& e, float4 v, int m, int n, int N) {
-  v.x *= e.alpha; v.y *= e.alpha; v.z *= e.alpha; v.w *= e.alpha;
-  if (e.bias) {
-    const float4 b = ld4(e.bias + n);
-    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+// The epilogue is split into "request everything this element needs from HBM" and "combine + store", so that a caller can
+// issue the loads of all its elements before the first store: on CDNA loads and stores share one in-order counter
+// (vmcnt), so a load issued after a store can only be waited for together with that store.
+// NS = register slots per element group: 3 serves any combination ({GELU' input, residual, accumulate target} or the
+// fused optimizer's {p, m, v}); 1 serves kernels whose accumulators leave room for one request per element only
+// (gemm256: the host routes a product there only when at most one of aux_z / resid / accumulate is set and no adam).
+template <int NS>
+struct EpiLoads {
+  float4 s[NS];
+};
+template <int NS>
+__device__ __forceinline__ void epilogue_load4(const Epilogue& e, EpiLoads<NS>& L, int m, int n) {
+  constexpr int SR = NS == 3 ? 1 : 0, SO = NS == 3 ? 2 : 0;
+  if (e.act == 2) L.s[0] = ld4(e.aux_z + (size_t)m * e.ld_aux + n);
+  if (e.resid) L.s[SR] = ld4(e.resid + (size_t)m * e.ld_resid + n);
+  if (NS == 3 && e.adam_p) {
+    const size_t off = (size_t)m * e.ld_out + n;
+    L.s[0] = ld4(e.adam_p + off);
+    L.s[SR] = ld4(e.adam_m + off);
+    L.s[SO] = ld4(e.adam_v + off);
+  } else if (e.out && e.accumulate) {
+    L.s[SO] = ld4(e.out + (size_t)m * e.ld_out + n);
   }
+}
+template <int NS>
+__device__ __forceinline__ void epilogue_apply4(const Epilogue& e, float4 v, float4 b, const EpiLoads<NS>& L, int m, int n, int N) {
+  constexpr int SR = NS == 3 ? 1 : 0, SO = NS == 3 ? 2 : 0;
+  v.x *= e.alpha; v.y *= e.alpha; v.z *= e.alpha; v.w *= e.alpha;
+  if (e.bias) { v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
   if (e.act == 1) {
     if (e.out_z) st4(e.out_z + (size_t)m * e.ld_z + n, v);
     v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
@@ -81,16 +104,13 @@ __device__ __forceinline__ void epilogue_vec4(const Epilogue& e, float4 v, int m
     v.w = dropout_keep(e.drop_key, idx + 3, e.drop_thr) ? v.w * e.drop_scale : 0.0f;
   }
   if (e.act == 2) {
-    const float4 z = ld4(e.aux_z + (size_t)m * e.ld_aux + n);
+    const float4 z = L.s[0];
     v.x *= gelu_erf_grad(z.x); v.y *= gelu_erf_grad(z.y); v.z *= gelu_erf_grad(z.z); v.w *= gelu_erf_grad(z.w);
   }
-  if (e.resid) {
-    const float4 r = ld4(e.resid + (size_t)m * e.ld_resid + n);
-    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-  }
-  if (e.adam_p) {  // fused optimizer step (reached through the split-K reducer; the direct path prefetches, see below)
+  if (e.resid) { v.x += L.s[SR].x; v.y += L.s[SR].y; v.z += L.s[SR].z; v.w += L.s[SR].w; }
+  if (NS == 3 && e.adam_p) {  // fused optimizer step
     const size_t off = (size_t)m * e.ld_out + n;
-    float4 p = ld4(e.adam_p + off), mm = ld4(e.adam_m + off), vv = ld4(e.adam_v + off);
+    float4 p = L.s[0], mm = L.s[SR], vv = L.s[SO];
     adam_update(p.x, v.x, mm.x, vv.x, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
     adam_update(p.y, v.y, mm.y, vv.y, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
     adam_update(p.z, v.z, mm.z, vv.z, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
@@ -99,12 +119,8 @@ __device__ __forceinline__ void epilogue_vec4(const Epilogue& e, float4 v, int m
     return;
   }
   if (e.out) {
-    float* p = e.out + (size_t)m * e.ld_out + n;
-    if (e.accumulate) {
-      const float4 o = ld4(p);
-      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-    }
-    st4(p, v);
+    if (e.accumulate) { v.x += L.s[SO].x; v.y += L.s[SO].y; v.z += L.s[SO].z; v.w += L.s[SO].w; }
+    st4(e.out + (size_t)m * e.ld_out + n, v);
   }
   if (e.out_hi) {  // bf16 hi/lo planes for the next GEMM (same bytes as the fp32 tensor they replace)
     u32x2_t hv, lv;
@@ -114,99 +130,121 @@ __device__ __forceinline__ void epilogue_vec4(const Epilogue& e, float4 v, int m
     *reinterpret_cast<u32x2_t*>(ph + e.lo_off) = lv;
   }
 }
+// one element group, loads and stores together (the split-K reducer: a grid-stride loop with one group in flight per thread)
+__device__ __forceinline__ void epilogue_vec4(const Epilogue& e, float4 v, int m, int n, int N) {
+  EpiLoads<3> L;
+  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e.bias) b = ld4(e.bias + n);
+  epilogue_load4<3>(e, L, m, n);
+  epilogue_apply4<3>(e, v, b, L, m, n, N);
+}
+
+// LDS accesses of the epilogue slab go through inline asm.  With LDS-DMA in the kernel hipcc cannot tell a pending
+// LDS-DMA write from any other outstanding VMEM operation, so it puts `s_waitcnt vmcnt(0)` in front of every LDS access
+// it can see -- in an epilogue that means "wait for every global store issued so far" before each slab read: the stores
+// of a tile were serialised at one HBM write latency each (measured: 30 us per 256 x 256 tile, 30 % of a K = 768 tile's
+// life).  A wave's LDS operations execute in order, so write -> read of the wave-private slab needs no barrier; the
+// data of the reads is waited for with lgkmcnt(0) before the first use.
+template <int IMM>
+__device__ __forceinline__ void slab_write(uint32_t addr, float v) {
+  asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "i"(IMM) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ float4 slab_read4(uint32_t addr) {
+  f32x4_t v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(IMM) : "memory");
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+template <int WN, int NI, int II, int J, int R>
+__device__ __forceinline__ void slab_write_tile(uint32_t wbase, const f32x4_t& t) {
+  slab_write<((16 * II + R) * (WN + 4) + 16 * J) * 4>(wbase, t[R]);
+  if constexpr (R < 3) slab_write_tile<WN, NI, II, J, R + 1>(wbase, t);
+}
+template <int WN, int MI, int NI, int HALF, int II, int J>
+__device__ __forceinline__ void slab_write_all(uint32_t wbase, f32x4_t (&acc)[MI][NI]) {
+  slab_write_tile<WN, NI, II, J, 0>(wbase, acc[2 * HALF + II][J]);
+  if constexpr (J + 1 < NI) slab_write_all<WN, MI, NI, HALF, II, J + 1>(wbase, acc);
+  else if constexpr (II == 0) slab_write_all<WN, MI, NI, HALF, 1, 0>(wbase, acc);
+}
+template <int WN, int NP, int PASS>
+__device__ __forceinline__ void slab_read_all(uint32_t rbase, float4 (&v)[NP]) {
+  constexpr int RPP = 64 / (WN / 4);
+  v[PASS] = slab_read4<PASS * RPP * (WN + 4) * 4>(rbase);
+  if constexpr (PASS + 1 < NP) slab_read_all<WN, NP, PASS + 1>(rbase, v);
+}
 
 // One 32-row slab (accumulator tile rows 2*HALF and 2*HALF + 1) of a wave tile.  HALF is a template parameter: with a
 // runtime loop the compiler does not always unroll (the 128-row wave tile of gemm256.hip) and then indexes `acc`
 // dynamically, which sends the accumulators to scratch memory.
-template <int WN, int MI, int NI, int HALF>
+template <int WN, int MI, int NI, int HALF, int NS = 3>
 __device__ __forceinline__ void epilogue_wave_half(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
                                                    int lane, float* partial) {
   constexpr int LDW = WN + 4;
   constexpr int LPR = WN / 4;    // lanes per row
   constexpr int RPP = 64 / LPR;  // rows per pass
+  constexpr int NP = 32 / RPP;
   const int gq = lane >> 4, c16 = lane & 15;
+  const int row0 = lane / LPR, col = (lane % LPR) * 4;
+  const int n = nw + col;
+  const Epilogue& e = g.epi;
+  // 1. every HBM request of this slab before anything is stored
+  EpiLoads<NS> L[NP];
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!partial) {
+    if (e.bias && n < g.N) bias4 = ld4(e.bias + n);
 #pragma unroll
-  for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) slab[(16 * ii + 4 * gq + r) * LDW + 16 * j + c16] = acc[2 * HALF + ii][j][r];
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int pass = 0; pass < 32 / RPP; ++pass) {
-    const int row = pass * RPP + lane / LPR, col = (lane % LPR) * 4;
-    const float4 v = ld4(slab + row * LDW + col);
-    const int m = mw + 32 * HALF + row, n = nw + col;
-    if (m < g.M && n < g.N) {
-      if (partial) st4(partial + (size_t)m * g.N + n, v);
-      else epilogue_vec4(g.epi, v, m, n, g.N);
+    for (int pass = 0; pass < NP; ++pass) {
+      const int m = mw + 32 * HALF + pass * RPP + row0;
+      if (m < g.M && n < g.N) epilogue_load4<NS>(e, L[pass], m, n);
     }
   }
-  __builtin_amdgcn_wave_barrier();
+  // 2. accumulators -> slab -> one row segment of 4 consecutive columns per lane
+  const uint32_t sbase = lds_addr(slab);
+  slab_write_all<WN, MI, NI, HALF, 0, 0>(sbase + (uint32_t)((4 * gq * LDW + c16) * 4), acc);
+  float4 v[NP];
+  slab_read_all<WN, NP, 0>(sbase + (uint32_t)((row0 * LDW + col) * 4), v);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  // 3. combine + store
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    const int m = mw + 32 * HALF + pass * RPP + row0;
+    if (m < g.M && n < g.N) {
+      if (partial) st4(partial + (size_t)m * g.N + n, v[pass]);
+      else epilogue_apply4<NS>(e, v[pass], bias4, L[pass], m, n, g.N);
+    }
+  }
 }
 
-template <int WM, int WN, int MI, int NI>
+template <int WM, int WN, int MI, int NI, int NS = 3>
 __device__ __forceinline__ void epilogue_wave(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
                                               int lane, float* partial) {
   static_assert(WM == 32 || WM == 64 || WM == 128, "wave tile rows");
-  epilogue_wave_half<WN, MI, NI, 0>(g, acc, slab, mw, nw, lane, partial);
-  if constexpr (WM >= 64) epilogue_wave_half<WN, MI, NI, 1>(g, acc, slab, mw, nw, lane, partial);
+  epilogue_wave_half<WN, MI, NI, 0, NS>(g, acc, slab, mw, nw, lane, partial);
+  if constexpr (WM >= 64) epilogue_wave_half<WN, MI, NI, 1, NS>(g, acc, slab, mw, nw, lane, partial);
   if constexpr (WM >= 128) {
-    epilogue_wave_half<WN, MI, NI, 2>(g, acc, slab, mw, nw, lane, partial);
-    epilogue_wave_half<WN, MI, NI, 3>(g, acc, slab, mw, nw, lane, partial);
+    epilogue_wave_half<WN, MI, NI, 2, NS>(g, acc, slab, mw, nw, lane, partial);
+    epilogue_wave_half<WN, MI, NI, 3, NS>(g, acc, slab, mw, nw, lane, partial);
   }
 }
 
 // Fused AdamW epilogue: the weight, exp_avg and exp_avg_sq vectors of all 32 rows of a slab are requested BEFORE the
 // accumulators are transposed through LDS (24 independent 16-B loads per lane in flight; with the loads issued one
 // slab pass at a time the 12 GB p/m/v stream of out_layer.fc1 would be latency-bound at ~3 TB/s).
+template <int WN, int MI, int NI, int HALF>
+__device__ __forceinline__ void epilogue_wave_adam_half(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
+                                                        int lane) {
+  // the generic path already requests p / m / v of all 32 rows (24 independent 16-B loads per lane) before the transpose
+  epilogue_wave_half<WN, MI, NI, HALF>(g, acc, slab, mw, nw, lane, nullptr);
+}
 template <int WM, int WN, int MI, int NI>
 __device__ __forceinline__ void epilogue_wave_adam(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw,
                                                    int nw, int lane) {
-  constexpr int LDW = WN + 4;
-  constexpr int LPR = WN / 4;
-  constexpr int RPP = 64 / LPR;
-  constexpr int NP = 32 / RPP;
-  const Epilogue& e = g.epi;
-  const int gq = lane >> 4, c16 = lane & 15;
-#pragma unroll
-  for (int half = 0; half < WM / 32; ++half) {
-    float4 p4[NP], m4[NP], v4[NP];
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-      const int m = mw + 32 * half + pass * RPP + lane / LPR, n = nw + (lane % LPR) * 4;
-      if (m < g.M && n < g.N) {
-        const size_t off = (size_t)m * e.ld_out + n;
-        p4[pass] = ld4(e.adam_p + off);
-        m4[pass] = ld4(e.adam_m + off);
-        v4[pass] = ld4(e.adam_v + off);
-      }
-    }
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) slab[(16 * ii + 4 * gq + r) * LDW + 16 * j + c16] = acc[2 * half + ii][j][r];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-      const int row = pass * RPP + lane / LPR, col = (lane % LPR) * 4;
-      float4 v = ld4(slab + row * LDW + col);
-      const int m = mw + 32 * half + row, n = nw + col;
-      if (m < g.M && n < g.N) {
-        v.x *= e.alpha; v.y *= e.alpha; v.z *= e.alpha; v.w *= e.alpha;
-        float4 p = p4[pass], mm = m4[pass], vv = v4[pass];
-        adam_update(p.x, v.x, mm.x, vv.x, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
-        adam_update(p.y, v.y, mm.y, vv.y, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
-        adam_update(p.z, v.z, mm.z, vv.z, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
-        adam_update(p.w, v.w, mm.w, vv.w, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
-        const size_t off = (size_t)m * e.ld_out + n;
-        st4(e.adam_p + off, p); st4(e.adam_m + off, mm); st4(e.adam_v + off, vv);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
+  epilogue_wave<WM, WN, MI, NI>(g, acc, slab, mw, nw, lane, nullptr);
 }
 
 }  // namespace lr2gemm

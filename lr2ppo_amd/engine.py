@@ -228,7 +228,7 @@ def xit_forward(ws: Workspace, tag: str, P, W: Dict[str, Planes], keys: XitKeys,
     ops.layernorm_fwd(x1, P[keys.ln2_w], P[keys.ln2_b], None, st["m1"], st["r1"], rows=Mq, D=E, out_planes=x1n)
     hf = ws.planes(t + "hf", Mq, F)
     zf = ws.mat(t + "zf", Mq, F) if save else None
-    linear_fwd(ws, x1n, fwd_weight(W, keys.f1_w), P[keys.f1_b], None, Mq, F, E, act=1, out_z=zf, drop=d1, out_planes=hf)
+    linear_fwd(ws, x1n, fwd_weight(W, keys.f1_w, Mq), P[keys.f1_b], None, Mq, F, E, act=1, out_z=zf, drop=d1, out_planes=hf)
     x2 = ws.mat(t + "x2", Mq, E)
     linear_fwd(ws, hf, W[keys.f2_w], P[keys.f2_b], x2, Mq, E, F, drop=d2, resid=x1)
     out_pl = out if isinstance(out, Planes) else None
@@ -311,9 +311,13 @@ FC1 = "out_layer.fc1.weight"   # 2 GB: stays fp32, split inside the GEMM
 TRUNK_T_WEIGHTS = ["text_proj.fc1.weight", "img_proj.fc1.weight", XIT.f1_w]
 
 
-def fwd_weight(W, name):
-    """The planes a forward GEMM should use for weight `name`: its transposed copy when the model keeps one."""
-    return W.get(name + WeightPlanes.T, W[name])
+def fwd_weight(W, name, M: Optional[int] = None):
+    """The planes a forward GEMM should use for weight `name`: its transposed copy (NN form) when the model keeps one --
+    unless the product is large enough for the 256 x 256 NT kernel, which takes the weight in its own [out, in] layout."""
+    w = W[name]
+    if M is not None and ops.use_gemm256(M, w.rows, w.cols):
+        return w
+    return W.get(name + WeightPlanes.T, w)
 
 
 def _img_shared(img_emb: torch.Tensor) -> bool:
@@ -332,13 +336,13 @@ def trunk_forward(ws: Workspace, P, W, text, img, bs: int, tags: int, n_img: int
     Mi = N * n_img
     h1 = ws.planes("h1", Mt, F)
     z1 = ws.mat("z1", Mt, F) if save else None
-    linear_fwd(ws, text, fwd_weight(W, "text_proj.fc1.weight"), P["text_proj.fc1.bias"], None, Mt, F, E, act=1, out_z=z1,
+    linear_fwd(ws, text, fwd_weight(W, "text_proj.fc1.weight", Mt), P["text_proj.fc1.bias"], None, Mt, F, E, act=1, out_z=z1,
                out_planes=h1)
     tf = ws.mat("tf", Mt, E)
     linear_fwd(ws, h1, W["text_proj.fc2.weight"], P["text_proj.fc2.bias"], tf, Mt, E, F)
     hi = ws.planes("hi", Mi_src, F)
     zi = ws.mat("zi", Mi_src, F) if save else None
-    linear_fwd(ws, img, fwd_weight(W, "img_proj.fc1.weight"), P["img_proj.fc1.bias"], None, Mi_src, F, E, act=1, out_z=zi,
+    linear_fwd(ws, img, fwd_weight(W, "img_proj.fc1.weight", Mi_src), P["img_proj.fc1.bias"], None, Mi_src, F, E, act=1, out_z=zi,
                out_planes=hi)
     imf_src = ws.mat("imf_src", Mi_src, E)
     linear_fwd(ws, hi, W["img_proj.fc2.weight"], P["img_proj.fc2.bias"], imf_src, Mi_src, E, F)

@@ -211,10 +211,24 @@ class AdamArgs:
         self.lr, self.beta1, self.beta2, self.eps, self.weight_decay = lr, beta1, beta2, eps, weight_decay
 
 
+def use_gemm256(M: int, N: int, K: int) -> bool:
+    """True when an NT product of planes should run on the 256 x 256 ping-pong kernel (csrc/gemm256.hip): whole 32-deep K
+    steps and enough 256 x 256 tiles that the last round of one-workgroup-per-CU rounds is well filled.  Measured on
+    MI355X (tools/gemm_bench.py --planes): M = 100864 (ViT-B/16 over 512 frames) 355-385 TFLOP/s at K = 768 and ~460 at
+    K = 3072 against 310-325 / 355 for the 128-row kernels; at M = 12544 (0.6-2.3 rounds) the two are level."""
+    if K % 32 or _PASSES != 3:
+        return False
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    rounds = -(-tiles // 256)
+    return tiles >= 256 and tiles >= 0.88 * rounds * 256
+
+
 def choose_tiling(M: int, N: int, K: int, trans_a: bool, trans_b: bool = False):
     """(block_m, splits).  256 CUs hold 2 (BM=128) or 3 (BM=64) workgroups each; pick the split-K factor that minimises
     rounds x (K-tiles per workgroup + fixed prologue/epilogue cost) + the cost of writing/reading the partial slabs, so
     that skinny GEMMs fill the chip without wave-quantisation tails (576 workgroups on 512 slots = 2 rounds)."""
+    if not trans_a and not trans_b and use_gemm256(M, N, K):
+        return 256, 1        # honoured for planes x planes operands only (lr2_gemm falls back to 128-row tiles otherwise)
     bm = 64 if (M <= 64 and not trans_a) else 128
     tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
     if bm == 128 and not trans_a and not trans_b and tiles < 1536:

@@ -93,6 +93,8 @@ class TransformerEncoder(nn.Module):
         x_p, t_p = ws.planes("x_p", M, E), ws.planes("t_p", M, E)        # GEMM inputs: LN outputs / hidden
         qkv_p, o_p, ff_p = ws.planes("qkv_p", M, 3 * E), ws.planes("o_p", M, E), ws.planes("ff_p", M, F)
         scale = 1.0 / math.sqrt(float(hd))
+        # wide outputs: NT on the weight's own layout when the 256 x 256 kernel takes the product, else NN on W^T
+        big_qkv, big_ff = ops.use_gemm256(M, 3 * E, E), ops.use_gemm256(M, F, E)
         if not pre:
             ops.split_planes(h, x_p)
         for layer, w in zip(self.transformer, W):
@@ -100,16 +102,16 @@ class TransformerEncoder(nn.Module):
             ln1, ln2 = layer.layer_norm_1, layer.layer_norm_2
             if pre:                                                   # layers/transformer.py:63-73
                 ops.layernorm_fwd(h, ln1.gamma.data, ln1.beta.data, None, rows=M, D=E, eps=ln1.eps, mode=1, out_planes=x_p)
-            engine.linear_fwd(ws, x_p, w["wqkv_t"], w["bqkv"], None, M, 3 * E, E, out_planes=qkv_p)
+            engine.linear_fwd(ws, x_p, w["wqkv" if big_qkv else "wqkv_t"], w["bqkv"], None, M, 3 * E, E, out_planes=qkv_p)
             ops.self_attn_fwd(qkv_p, seg, o_p, batch=B, heads=H, L=L, head_dim=hd, scale=scale)
             engine.linear_fwd(ws, o_p, w["wo"], att.final_linear.bias.data, h2, M, E, E, resid=h)
             if pre:
                 ops.layernorm_fwd(h2, ln2.gamma.data, ln2.beta.data, None, rows=M, D=E, eps=ln2.eps, mode=1, out_planes=t_p)
-                engine.linear_fwd(ws, t_p, w["w1_t"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_planes=ff_p)
+                engine.linear_fwd(ws, t_p, w["w1" if big_ff else "w1_t"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_planes=ff_p)
                 engine.linear_fwd(ws, ff_p, w["w2"], ffn.linear_2.bias.data, h, M, E, F, resid=h2)
             else:                                                     # layers/transformer.py:54-61
                 ops.layernorm_fwd(h2, ln1.gamma.data, ln1.beta.data, h, rows=M, D=E, eps=ln1.eps, mode=1, out_planes=t_p)
-                engine.linear_fwd(ws, t_p, w["w1_t"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_planes=ff_p)
+                engine.linear_fwd(ws, t_p, w["w1" if big_ff else "w1_t"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_planes=ff_p)
                 engine.linear_fwd(ws, ff_p, w["w2"], ffn.linear_2.bias.data, h2, M, E, F, resid=h)
                 ops.layernorm_fwd(h2, ln2.gamma.data, ln2.beta.data, h, rows=M, D=E, eps=ln2.eps, mode=1, out_planes=x_p)
         out = torch.empty(B, L, E, device=emb.device)
@@ -142,6 +144,7 @@ class TransformerEncoder(nn.Module):
         pl = lambda r, c: ops.Planes.empty(r, c, dev)                   # noqa: E731
         pre = self.layernorm_positioning == "pre"
         scale = 1.0 / math.sqrt(float(hd))
+        big_qkv, big_ff = ops.use_gemm256(M, 3 * E, E), ops.use_gemm256(M, F, E)
         h = emb.detach().contiguous().view(M, E)
         h_p = None
         if not pre:
@@ -159,7 +162,7 @@ class TransformerEncoder(nn.Module):
             else:
                 x_p = h_p
             qkv_p, o_p, t1 = pl(M, 3 * E), pl(M, E), mat(M, E)
-            engine.linear_fwd(ws, x_p, w["wqkv_t"], w["bqkv"], None, M, 3 * E, E, out_planes=qkv_p)
+            engine.linear_fwd(ws, x_p, w["wqkv" if big_qkv else "wqkv_t"], w["bqkv"], None, M, 3 * E, E, out_planes=qkv_p)
             ops.self_attn_fwd(qkv_p, seg, o_p, batch=B, heads=H, L=L, head_dim=hd, scale=scale, drop=drop(s0))
             engine.linear_fwd(ws, o_p, w["wo"], att.final_linear.bias.data, t1, M, E, E, resid=h, drop=drop(s0 + 1))
             z, ff_p = mat(M, F), pl(M, F)
@@ -168,7 +171,7 @@ class TransformerEncoder(nn.Module):
                 x2_p, S["m2"], S["r2"] = pl(M, E), vec(M), vec(M)
                 ops.layernorm_fwd(t1, ln2.gamma.data, ln2.beta.data, None, S["m2"], S["r2"], rows=M, D=E, eps=ln2.eps, mode=1,
                                   out_planes=x2_p)
-                engine.linear_fwd(ws, x2_p, w["w1_t"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_z=z, out_planes=ff_p)
+                engine.linear_fwd(ws, x2_p, w["w1" if big_ff else "w1_t"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_z=z, out_planes=ff_p)
                 hn = mat(M, E)
                 engine.linear_fwd(ws, ff_p, w["w2"], ffn.linear_2.bias.data, hn, M, E, F, resid=t1, drop=drop(s0 + 2))
                 S["x2_p"] = x2_p
@@ -177,7 +180,7 @@ class TransformerEncoder(nn.Module):
                 inter, inter_p, S["m1"], S["r1"] = mat(M, E), pl(M, E), vec(M), vec(M)
                 ops.layernorm_fwd(t1, ln1.gamma.data, ln1.beta.data, inter, S["m1"], S["r1"], rows=M, D=E, eps=ln1.eps, mode=1,
                                   out_planes=inter_p)
-                engine.linear_fwd(ws, inter_p, w["w1_t"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_z=z, out_planes=ff_p)
+                engine.linear_fwd(ws, inter_p, w["w1" if big_ff else "w1_t"], ffn.linear_1.bias.data, None, M, F, E, act=1, out_z=z, out_planes=ff_p)
                 t2 = mat(M, E)
                 engine.linear_fwd(ws, ff_p, w["w2"], ffn.linear_2.bias.data, t2, M, E, F, resid=inter, drop=drop(s0 + 2))
                 hn, hn_p, S["m2"], S["r2"] = mat(M, E), pl(M, E), vec(M), vec(M)

@@ -315,9 +315,10 @@ def test_gemm256_nt_matches_fp64(dev, M, N, K):
     out = torch.full((M, N), float("nan"), device=dev)
     ops.gemm(ap, bp, out, M, N, K, block_m=256, splits=1)
     _close(out, ref, atol=6e-5 * math.sqrt(K), rtol=5e-5, what="gemm256")
-    out128 = torch.empty((M, N), device=dev)
-    ops.gemm(ap, bp, out128, M, N, K, block_m=128, splits=1)
-    _close(out, out128.double().cpu(), atol=2e-5 * math.sqrt(K), rtol=2e-5, what="gemm256 vs general kernel")
+    if K % 64 == 0:                         # the general NT kernel steps K by 64
+        out128 = torch.empty((M, N), device=dev)
+        ops.gemm(ap, bp, out128, M, N, K, block_m=128, splits=1)
+        _close(out, out128.double().cpu(), atol=2e-5 * math.sqrt(K), rtol=2e-5, what="gemm256 vs general kernel")
 
 
 def test_gemm256_exact_on_integers_and_asymmetric(dev):
@@ -350,9 +351,8 @@ def test_gemm256_fused_epilogues(dev):
     ops.gemm(ap, wp, out, M, N, K, bias=bias.to(dev), act=1, out_z=z, out_planes=pl, block_m=256, splits=1)
     _close(z, z_ref, 1e-4, 5e-5, "z")
     _close(out, O.gelu_erf(z_ref), 1e-4, 5e-5, "gelu")
-    assert torch.equal(pl.to_float(), out)                                  # hi + lo reproduces the fp32 result to 17 bits ...
     ref_pl = ops.split_planes(out, ops.Planes.empty(M, N, dev))
-    assert torch.equal(pl.buf, ref_pl.buf)                                  # ... and is the split of it bit for bit
+    assert torch.equal(pl.buf, ref_pl.buf)                                  # the planes output is the split of the fp32 one
     drop = ops.Drop(0.1, seed=77, site=3)
     ops.gemm(ap, wp, out, M, N, K, bias=bias.to(dev), drop=drop, resid=resid.to(dev), block_m=256, splits=1)
     keep = torch.from_numpy(O.dropout_keep_mask(77, 3, M * N, 0.1)).view(M, N)
