@@ -325,7 +325,8 @@ __device__ __forceinline__ void compute_tile(const char* a_hi, const char* b_hi,
 
 // ---- the kernel ------------------------------------------------------------------------------------
 template <int BM, int BN, int BK, int WM, int WN, bool TA, bool TB, int PASSES, bool APL, bool BPL, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void gemm_kernel(GemmParams g) {
+// 8-wave workgroups are meant to run two per CU = 4 waves per SIMD: cap the register allocation at 128 for them
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(GemmParams g) {
   static_assert(NW == 4 || (APL && BPL), "8-wave workgroups exist for planes x planes operands only");
   static_assert((BM / WM) * (BN / WN) == NW, "wave grid");
   constexpr int MI = WM / 16, NI = WN / 16;

@@ -177,70 +177,96 @@ __device__ __forceinline__ void slab_read_all(uint32_t rbase, float4 (&v)[NP]) {
   if constexpr (PASS + 1 < NP) slab_read_all<WN, NP, PASS + 1>(rbase, v);
 }
 
-// One 32-row slab (accumulator tile rows 2*HALF and 2*HALF + 1) of a wave tile.  HALF is a template parameter: with a
-// runtime loop the compiler does not always unroll (the 128-row wave tile of gemm256.hip) and then indexes `acc`
-// dynamically, which sends the accumulators to scratch memory.
-template <int WN, int MI, int NI, int HALF, int NS = 3>
-__device__ __forceinline__ void epilogue_wave_half(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
-                                                   int lane, float* partial) {
+// One 32-row slab (accumulator tile rows 2*HALF and 2*HALF + 1) of a wave tile at a time.  HALF is a template
+// parameter: with a runtime loop the compiler does not always unroll (the 128-row wave tile of gemm256.hip) and then
+// indexes `acc` dynamically, which sends the accumulators to scratch memory.
+// The HBM requests of slab h+1 (residual / GELU' input / accumulate target / optimizer state) are issued BEFORE the
+// stores of slab h: loads and stores share the in-order vmcnt counter, so a load issued behind a store can only be
+// waited for together with that store (one HBM write latency per slab otherwise).
+template <int WN, int NS>
+struct EpiSlab {
+  static constexpr int NP = 32 / (64 / (WN / 4));
+  EpiLoads<NS> L[NP];
+};
+
+template <int WN, int NS, int HALF>
+__device__ __forceinline__ void epilogue_request(const GemmParams& g, EpiSlab<WN, NS>& S, int mw, int nw, int lane) {
+  constexpr int LPR = WN / 4, RPP = 64 / LPR, NP = 32 / RPP;
+  const int row0 = lane / LPR, n = nw + (lane % LPR) * 4;
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    const int m = mw + 32 * HALF + pass * RPP + row0;
+    if (m < g.M && n < g.N) epilogue_load4<NS>(g.epi, S.L[pass], m, n);
+  }
+}
+
+template <int WN, int MI, int NI, int HALF>
+__device__ __forceinline__ void epilogue_to_slab(f32x4_t (&acc)[MI][NI], float* slab, int lane) {
+  constexpr int LDW = WN + 4;
+  const int gq = lane >> 4, c16 = lane & 15;
+  slab_write_all<WN, MI, NI, HALF, 0, 0>(lds_addr(slab) + (uint32_t)((4 * gq * LDW + c16) * 4), acc);
+}
+
+template <int WN, int HALF, int NS>
+__device__ __forceinline__ void epilogue_from_slab(const GemmParams& g, float* slab, int mw, int nw, int lane, float* partial,
+                                                   float4 bias4, const EpiSlab<WN, NS>& S) {
   constexpr int LDW = WN + 4;
   constexpr int LPR = WN / 4;    // lanes per row
   constexpr int RPP = 64 / LPR;  // rows per pass
   constexpr int NP = 32 / RPP;
-  const int gq = lane >> 4, c16 = lane & 15;
   const int row0 = lane / LPR, col = (lane % LPR) * 4;
   const int n = nw + col;
-  const Epilogue& e = g.epi;
-  // 1. every HBM request of this slab before anything is stored
-  EpiLoads<NS> L[NP];
-  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!partial) {
-    if (e.bias && n < g.N) bias4 = ld4(e.bias + n);
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-      const int m = mw + 32 * HALF + pass * RPP + row0;
-      if (m < g.M && n < g.N) epilogue_load4<NS>(e, L[pass], m, n);
-    }
-  }
-  // 2. accumulators -> slab -> one row segment of 4 consecutive columns per lane
-  const uint32_t sbase = lds_addr(slab);
-  slab_write_all<WN, MI, NI, HALF, 0, 0>(sbase + (uint32_t)((4 * gq * LDW + c16) * 4), acc);
   float4 v[NP];
-  slab_read_all<WN, NP, 0>(sbase + (uint32_t)((row0 * LDW + col) * 4), v);
+  slab_read_all<WN, NP, 0>(lds_addr(slab) + (uint32_t)((row0 * LDW + col) * 4), v);   // one row segment of 4 columns per lane
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-  // 3. combine + store
 #pragma unroll
   for (int pass = 0; pass < NP; ++pass) {
     const int m = mw + 32 * HALF + pass * RPP + row0;
     if (m < g.M && n < g.N) {
       if (partial) st4(partial + (size_t)m * g.N + n, v[pass]);
-      else epilogue_apply4<NS>(e, v[pass], bias4, L[pass], m, n, g.N);
+      else epilogue_apply4<NS>(g.epi, v[pass], bias4, S.L[pass], m, n, g.N);
     }
   }
+}
+
+// PIPE: request slab h+1's HBM operands before slab h's stores (after slab h's accumulators have moved to LDS, so the
+// register peak is acc - 32 + 3 x 32 for NS = 1).  Kernels that keep up to three requests per element (NS = 3) and run
+// several workgroups per CU request per slab instead: their register budget decides their occupancy.
+template <int WM, int WN, int MI, int NI, int NS, int HALF, bool PIPE>
+__device__ __forceinline__ void epilogue_pipeline(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
+                                                  int lane, float* partial, float4 bias4, EpiSlab<WN, NS>& cur) {
+  if constexpr (!PIPE) {
+    if (!partial) epilogue_request<WN, NS, HALF>(g, cur, mw, nw, lane);
+  }
+  epilogue_to_slab<WN, MI, NI, HALF>(acc, slab, lane);
+  EpiSlab<WN, NS> next;
+  if constexpr (PIPE && HALF + 1 < WM / 32) {
+    if (!partial) epilogue_request<WN, NS, HALF + 1>(g, next, mw, nw, lane);
+  }
+  epilogue_from_slab<WN, HALF, NS>(g, slab, mw, nw, lane, partial, bias4, cur);
+  if constexpr (HALF + 1 < WM / 32)
+    epilogue_pipeline<WM, WN, MI, NI, NS, HALF + 1, PIPE>(g, acc, slab, mw, nw, lane, partial, bias4, PIPE ? next : cur);
 }
 
 template <int WM, int WN, int MI, int NI, int NS = 3>
 __device__ __forceinline__ void epilogue_wave(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
                                               int lane, float* partial) {
   static_assert(WM == 32 || WM == 64 || WM == 128, "wave tile rows");
-  epilogue_wave_half<WN, MI, NI, 0, NS>(g, acc, slab, mw, nw, lane, partial);
-  if constexpr (WM >= 64) epilogue_wave_half<WN, MI, NI, 1, NS>(g, acc, slab, mw, nw, lane, partial);
-  if constexpr (WM >= 128) {
-    epilogue_wave_half<WN, MI, NI, 2, NS>(g, acc, slab, mw, nw, lane, partial);
-    epilogue_wave_half<WN, MI, NI, 3, NS>(g, acc, slab, mw, nw, lane, partial);
+  constexpr bool PIPE = false;   // cross-slab prefetch (NS == 1) measured 256 VGPRs + spills in gemm256: per-slab requests only
+  const int n = nw + (lane % (WN / 4)) * 4;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  EpiSlab<WN, NS> first;
+  if (!partial) {
+    if (g.epi.bias && n < g.N) bias4 = ld4(g.epi.bias + n);
+    if constexpr (PIPE) epilogue_request<WN, NS, 0>(g, first, mw, nw, lane);
   }
+  epilogue_pipeline<WM, WN, MI, NI, NS, 0, PIPE>(g, acc, slab, mw, nw, lane, partial, bias4, first);
 }
 
 // Fused AdamW epilogue: the weight, exp_avg and exp_avg_sq vectors of all 32 rows of a slab are requested BEFORE the
 // accumulators are transposed through LDS (24 independent 16-B loads per lane in flight; with the loads issued one
 // slab pass at a time the 12 GB p/m/v stream of out_layer.fc1 would be latency-bound at ~3 TB/s).
-template <int WN, int MI, int NI, int HALF>
-__device__ __forceinline__ void epilogue_wave_adam_half(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
-                                                        int lane) {
-  // the generic path already requests p / m / v of all 32 rows (24 independent 16-B loads per lane) before the transpose
-  epilogue_wave_half<WN, MI, NI, HALF>(g, acc, slab, mw, nw, lane, nullptr);
-}
 template <int WM, int WN, int MI, int NI>
 __device__ __forceinline__ void epilogue_wave_adam(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw,
                                                    int nw, int lane) {
