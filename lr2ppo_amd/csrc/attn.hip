@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
   float sum = 0.f;
 #pragma unroll
   for (int j = 0; j < MAX_LK; ++j) {
-    s[j] = (j < Lk) ? expf(s[j] - mx) : 0.f;
+    s[j] = (j < Lk) ? exp_fast(s[j] - mx) : 0.f;
     sum += s[j];
   }
   const float inv = post_scale / sum;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const float* __restrict_
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < MAX_LK; ++j) {
-      s[j] = (j < Lk) ? expf(s[j] - mx) : 0.f;
+      s[j] = (j < Lk) ? exp_fast(s[j] - mx) : 0.f;
       sum += s[j];
     }
     const float inv = 1.0f / sum;

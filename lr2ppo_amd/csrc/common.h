@@ -54,6 +54,11 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// exp(x) as one multiply + v_exp_f32 (2^x, ~1 ulp): relative error <= 1e-7 + 6e-8 * |x| * log2(e) -- 1e-6 at x = -10, far
+// inside the fp32-parity budget of a softmax.  libm's expf is ~12 instructions per element; in the attention kernels the
+// softmax's vector work, not the matrix work, was the critical path (measured: 17 % MFMA busy).
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 // Counter-based dropout mask: keep(idx) is a pure function of (seed, site, flat element index).
 // The reference uses torch's Philox stream (nn.Dropout in finetune/xit.py:34,40,108), which cannot be
 // reproduced across backends; oracle/lr2ppo_oracle.py::dropout_keep_mask restates THIS function.

@@ -64,35 +64,15 @@ __global__ __launch_bounds__(64 * NW) void self_attn_mfma_kernel(const bf16_t* _
   const size_t row0 = (size_t)b * L;
   const int col0 = h * HD;
 
-  // ---- stage K, V (both planes) and the additive key mask ----
-  for (int i = tid; i < LP * 8; i += 64 * NW) {
-    const int r = i >> 3, u = i & 7;
-    u32x4_t kh = {0, 0, 0, 0}, kl = kh, vh = kh, vl = kh;
-    if (r < L) {
-      const size_t o = (row0 + r) * (size_t)ld + col0 + u * 8;
-      kh = *reinterpret_cast<const u32x4_t*>(Kh + o);
-      kl = *reinterpret_cast<const u32x4_t*>(Kh + o + lo_off);
-      vh = *reinterpret_cast<const u32x4_t*>(Vh + o);
-      vl = *reinterpret_cast<const u32x4_t*>(Vh + o + lo_off);
-    }
-    *reinterpret_cast<u32x4_t*>(sK + k_off(r, u)) = kh;
-    *reinterpret_cast<u32x4_t*>(sK + PLANE + k_off(r, u)) = kl;
-    *reinterpret_cast<u32x4_t*>(sV + v_off(r, u)) = vh;
-    *reinterpret_cast<u32x4_t*>(sV + PLANE + v_off(r, u)) = vl;
-  }
-  for (int j = tid; j < LP; j += 64 * NW) sMask[j] = j < L ? ((seg[row0 + j] > 0) ? 0.f : -10000.0f) : -INFINITY;
-
-  __syncthreads();
-  // K / V stay resident; each wave walks over 16-query sub-tiles (blockIdx.x strides them when the grid splits the queries)
   const int qn = lane & 15, g = lane >> 4;
   const int n_sub = (L + 15) >> 4;
-  for (int sub = blockIdx.x * NW + wave; sub < n_sub; sub += gridDim.x * NW) {
-  // ---- this sub-tile's 16 query rows as B fragments of S^T = K Q^T (lane: query l & 15, hd 8*(l >> 4) + 32*ks ..) ----
-  const int q_row = sub * 16 + qn;
-  bf16x8_t qh[2], ql[2];
-  {
-    const bool ok = q_row < L;
-    const size_t o = (row0 + (ok ? q_row : 0)) * (size_t)ld + col0 + 8 * g;
+  // Query fragments of a 16-row sub-tile: B operand of S^T = K Q^T (lane: query l & 15, hd 8*(l >> 4) + 32*ks ..).
+  // Requested one sub-tile ahead -- the first one before K / V are staged -- so that the HBM latency of the 64 x 4 x 16 B
+  // never sits between two MFMA phases.
+  auto load_q = [&](int sub_, bf16x8_t (&fh)[2], bf16x8_t (&fl)[2]) {
+    const int q_row_ = sub_ * 16 + qn;
+    const bool ok = sub_ < n_sub && q_row_ < L;
+    const size_t o = (row0 + (ok ? q_row_ : 0)) * (size_t)ld + col0 + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       u32x4_t a = {0, 0, 0, 0}, c = a;
@@ -100,10 +80,54 @@ __global__ __launch_bounds__(64 * NW) void self_attn_mfma_kernel(const bf16_t* _
         a = *reinterpret_cast<const u32x4_t*>(Qh + o + 32 * ks);
         c = *reinterpret_cast<const u32x4_t*>(Qh + o + 32 * ks + lo_off);
       }
-      qh[ks] = __builtin_bit_cast(bf16x8_t, a);
-      ql[ks] = __builtin_bit_cast(bf16x8_t, c);
+      fh[ks] = __builtin_bit_cast(bf16x8_t, a);
+      fl[ks] = __builtin_bit_cast(bf16x8_t, c);
+    }
+  };
+  const int sub_first = blockIdx.x * NW + wave, sub_step = gridDim.x * NW;
+  bf16x8_t qh[2], ql[2], qh_next[2], ql_next[2];
+  load_q(sub_first, qh_next, ql_next);
+
+  // ---- stage K, V (both planes) and the additive key mask: every request first, then the LDS writes (one HBM latency
+  // for the whole 4 x LP x 128 B instead of one per loop trip) ----
+  {
+    constexpr int TRIPS = (LP * 8 + 64 * NW - 1) / (64 * NW);
+    u32x4_t kh[TRIPS], kl[TRIPS], vh[TRIPS], vl[TRIPS];
+#pragma unroll
+    for (int it = 0; it < TRIPS; ++it) {
+      const int i = tid + it * 64 * NW;
+      const int r = i >> 3, u = i & 7;
+      kh[it] = u32x4_t{0, 0, 0, 0};
+      kl[it] = kh[it]; vh[it] = kh[it]; vl[it] = kh[it];
+      if (i < LP * 8 && r < L) {
+        const size_t o = (row0 + r) * (size_t)ld + col0 + u * 8;
+        kh[it] = *reinterpret_cast<const u32x4_t*>(Kh + o);
+        kl[it] = *reinterpret_cast<const u32x4_t*>(Kh + o + lo_off);
+        vh[it] = *reinterpret_cast<const u32x4_t*>(Vh + o);
+        vl[it] = *reinterpret_cast<const u32x4_t*>(Vh + o + lo_off);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < TRIPS; ++it) {
+      const int i = tid + it * 64 * NW;
+      const int r = i >> 3, u = i & 7;
+      if (i < LP * 8) {
+        *reinterpret_cast<u32x4_t*>(sK + k_off(r, u)) = kh[it];
+        *reinterpret_cast<u32x4_t*>(sK + PLANE + k_off(r, u)) = kl[it];
+        *reinterpret_cast<u32x4_t*>(sV + v_off(r, u)) = vh[it];
+        *reinterpret_cast<u32x4_t*>(sV + PLANE + v_off(r, u)) = vl[it];
+      }
     }
   }
+  for (int j = tid; j < LP; j += 64 * NW) sMask[j] = j < L ? ((seg[row0 + j] > 0) ? 0.f : -10000.0f) : -INFINITY;
+
+  __syncthreads();
+  // K / V stay resident; each wave walks over 16-query sub-tiles (blockIdx.x strides them when the grid splits the queries)
+  for (int sub = sub_first; sub < n_sub; sub += sub_step) {
+  const int q_row = sub * 16 + qn;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) { qh[ks] = qh_next[ks]; ql[ks] = ql_next[ks]; }
+  load_q(sub + sub_step, qh_next, ql_next);     // next sub-tile's queries travel while this one is computed
 
   // ---- S^T tiles: acc[t][r] = S[query qn][key 16t + 4g + r] ----
   f32x4_t s[NT];
@@ -140,7 +164,7 @@ __global__ __launch_bounds__(64 * NW) void self_attn_mfma_kernel(const bf16_t* _
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      s[t][r] = expf(s[t][r] - mx);     // padded keys: exp(-inf) = 0
+      s[t][r] = exp_fast(s[t][r] - mx);     // padded keys: exp(-inf) = 0
       sum += s[t][r];
     }
   }
@@ -359,7 +383,7 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dq_kernel(const bf16_t* __r
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      s[t][r] = expf(s[t][r] - mx);
+      s[t][r] = exp_fast(s[t][r] - mx);
       sum += s[t][r];
     }
   sum += __shfl_xor(sum, 16, 64);
@@ -492,7 +516,7 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dkv_kernel(const bf16_t* __
       const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, ddv[4] = {dd.x, dd.y, dd.z, dd.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = expf(a[r] * scale + kmask - lsv[r]);
+        const float p = exp_fast(a[r] * scale + kmask - lsv[r]);
         float m = 1.0f;
         if (dr.thr) {
           const int q = 16 * t + 4 * g + r;
