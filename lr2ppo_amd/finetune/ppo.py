@@ -175,6 +175,7 @@ class _Head(nn.Module):
             self.xitt = XiT(feat_size=FEAT, attention_mask="causal")
         self.out_layer = Mlp((args.seq_length + args.max_imgs) * args.visual_feat_dim, FEAT * 4, FEAT, nn.GELU, 0)
         self.head = nn.Linear(FEAT, 1)
+        self._P_cache: Optional[Dict[str, torch.Tensor]] = None
         self._ws: Optional[engine.Workspace] = None
         self._wp: Optional[engine.WeightPlanes] = None
         self._G: Optional[Dict[str, torch.Tensor]] = None
@@ -188,7 +189,19 @@ class _Head(nn.Module):
         return self._ws
 
     def _P(self) -> Dict[str, torch.Tensor]:
-        return {n: p.data for n, p in self.named_parameters()}
+        """name -> parameter storage.  Cached: walking named_parameters() costs ~1 ms per call and a PPO step makes seven;
+        nn.Module._apply (.to / .cuda / .float) is the only thing that re-seats parameter storage, and it clears the cache."""
+        c = self._P_cache
+        if c is None or c["head.weight"].data_ptr() != self.head.weight.data_ptr() \
+                or c["out_layer.fc1.weight"].data_ptr() != self.out_layer.fc1.weight.data_ptr():
+            c = self._P_cache = {n: p.data for n, p in self.named_parameters()}
+        return c
+
+    def _apply(self, fn, *a, **kw):
+        self._P_cache = None
+        out = super()._apply(fn, *a, **kw)
+        self._P_cache = None
+        return out
 
     def _weights(self, P, refresh: bool = True) -> Dict[str, ops.Planes]:
         """bf16 hi/lo planes of the token-GEMM weights (everything but the 2 GB out_layer.fc1), re-split from the

@@ -6,6 +6,7 @@ current HIP stream to the native library.  All tensors are fp32, contiguous, on 
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import Optional
 
 import torch
@@ -89,7 +90,9 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # torch.cuda.current_stream() builds a Stream object through several Python layers (~8 us, 300 launches per PPO
+    # step); the raw handle of the same stream comes straight from the C++ side in ~0.3 us
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _chk_f32(*ts):
@@ -212,17 +215,23 @@ class AdamArgs:
 
 
 def use_gemm256(M: int, N: int, K: int) -> bool:
+    return _use_gemm256(M, N, K, _PASSES)
+
+
+@functools.lru_cache(maxsize=4096)
+def _use_gemm256(M: int, N: int, K: int, passes: int) -> bool:
     """True when an NT product of planes should run on the 256 x 256 ping-pong kernel (csrc/gemm256.hip): whole 32-deep K
     steps and enough 256 x 256 tiles that the last round of one-workgroup-per-CU rounds is well filled.  Measured on
     MI355X (tools/gemm_bench.py --planes): M = 100864 (ViT-B/16 over 512 frames) 355-385 TFLOP/s at K = 768 and ~460 at
     K = 3072 against 310-325 / 355 for the 128-row kernels; at M = 12544 (0.6-2.3 rounds) the two are level."""
-    if K % 32 or _PASSES != 3:
+    if K % 32 or passes != 3:
         return False
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
     rounds = -(-tiles // 256)
     return tiles >= 256 and tiles >= 0.88 * rounds * 256
 
 
+@functools.lru_cache(maxsize=4096)
 def choose_tiling(M: int, N: int, K: int, trans_a: bool, trans_b: bool = False):
     """(block_m, splits).  256 CUs hold 2 (BM=128) or 3 (BM=64) workgroups each; pick the split-K factor that minimises
     rounds x (K-tiles per workgroup + fixed prologue/epilogue cost) + the cost of writing/reading the partial slabs, so
@@ -259,6 +268,13 @@ def choose_tiling(M: int, N: int, K: int, trans_a: bool, trans_b: bool = False):
     return bm, best
 
 
+def _LIB_GEMM(*args):
+    """Bound on first use (the library is loaded lazily so that importing ops never needs the GPU)."""
+    global _LIB_GEMM
+    _LIB_GEMM = _nat.lib().lr2_gemm
+    return _LIB_GEMM(*args)
+
+
 def gemm(a, b, out: Optional[torch.Tensor], M: int, N: int, K: int, *, trans_a=False, trans_b=False,
          lda: Optional[int] = None, ldb: Optional[int] = None, ld_out: Optional[int] = None,
          bias: Optional[torch.Tensor] = None, act: int = 0, out_z: Optional[torch.Tensor] = None,
@@ -277,7 +293,8 @@ def gemm(a, b, out: Optional[torch.Tensor], M: int, N: int, K: int, *, trans_a=F
         ldb = N if trans_b else K
     if ld_out is None:
         ld_out = N
-    bm, sp = choose_tiling(M, N, K, trans_a, trans_b)
+    if block_m is None or splits is None:
+        bm, sp = choose_tiling(M, N, K, trans_a, trans_b)
     if block_m is not None:
         bm = block_m
     if splits is not None:
@@ -302,16 +319,20 @@ def gemm(a, b, out: Optional[torch.Tensor], M: int, N: int, K: int, *, trans_a=F
         e.adam_eps, e.adam_weight_decay = adam.eps, adam.weight_decay
     a_bytes = a.plane_bytes() if a_pl else a.numel() * 4
     b_bytes = b.plane_bytes() if b_pl else b.numel() * 4
-    form = "TN" if trans_a else ("NN" if trans_b else "NT")
-    src = ("p" if a_pl else "f") + ("p" if b_pl else "f")
-    label = f"gemm_{form}_{src}_M{M}_N{N}_K{K}" + ("_adamw" if adam is not None else "")
-    alg_bytes = 4.0 * (M * K + N * K) + (24.0 if adam is not None else 4.0) * M * N
-    with _Timed(label, 2.0 * M * N * K, alg_bytes):
-        rc = _nat.lib().lr2_gemm(a.data_ptr(), b.data_ptr(), M, N, K, lda, ldb, 1 if trans_a else 0, 1 if trans_b else 0,
-                                 a_bytes, b_bytes, 1 if a_pl else 0, a.lo_off * 2 if a_pl else 0, 1 if b_pl else 0,
-                                 b.lo_off * 2 if b_pl else 0, C.byref(e), _ptr(splitk_ws), sp, bm, passes or _PASSES,
-                                 _stream())
-    _nat.check(rc, f"lr2_gemm(M={M},N={N},K={K},ta={trans_a},tb={trans_b},planes={src})")
+    args = (a.data_ptr(), b.data_ptr(), M, N, K, lda, ldb, 1 if trans_a else 0, 1 if trans_b else 0, a_bytes, b_bytes,
+            1 if a_pl else 0, a.lo_off * 2 if a_pl else 0, 1 if b_pl else 0, b.lo_off * 2 if b_pl else 0, C.byref(e),
+            _ptr(splitk_ws), sp, bm, passes or _PASSES, _stream())
+    if _PROF is None:               # the steady-state path: no label formatting, no event objects
+        rc = _LIB_GEMM(*args)
+    else:
+        form = "TN" if trans_a else ("NN" if trans_b else "NT")
+        src = ("p" if a_pl else "f") + ("p" if b_pl else "f")
+        label = f"gemm_{form}_{src}_M{M}_N{N}_K{K}" + ("_adamw" if adam is not None else "")
+        alg_bytes = 4.0 * (M * K + N * K) + (24.0 if adam is not None else 4.0) * M * N
+        with _Timed(label, 2.0 * M * N * K, alg_bytes):
+            rc = _LIB_GEMM(*args)
+    if rc:
+        _nat.check(rc, f"lr2_gemm(M={M},N={N},K={K},ta={trans_a},tb={trans_b},planes a={a_pl} b={b_pl})")
     return out if out is not None else out_planes
 
 
