@@ -19,6 +19,7 @@ struct GemmParams {
   uint32_t a_lo_off, b_lo_off;  // byte offset from the hi plane to the lo plane (planes operands)
   int k_tiles_per_split;        // in units of BK
   int tiles_m, tiles_n;         // output tile grid
+  int splits;                   // split-K factor (grid = tiles_m * tiles_n * splits workgroups, 1-D)
   float* partial;               // split-K workspace [splits][M][N] or nullptr
   int dma_stages;               // LDS images per planes operand: 2 = double buffered (1 workgroup/CU at BM=128), 1 = single
   int waves8;                   // planes x planes, 128 x 128 tiles: 8-wave workgroups (wave tile 64 x 32)
@@ -39,10 +40,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, ui
 // inside a strip), so any 64 consecutive tiles form an 8 x 8 patch sharing 8 A panels and 8 B panels; that sequence is
 // cut into 8 equal contiguous chunks, one per XCD (workgroups are dealt round-robin to the XCDs: blockIdx % 8 labels
 // the XCD group, blockIdx / 8 is the dispatch order inside it).  Speed only -- the map is a bijection.
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int bid, int& tm, int& tn) {
-  const int T = tiles_m * tiles_n;
+// position of workgroup `bid` in a sequence of T work units cut into 8 contiguous chunks, one per XCD group (bid % 8)
+__device__ __forceinline__ int xcd_chunk_index(int T, int bid) {
   const int q = T >> 3, r = T & 7, xcd = bid & 7, local = bid >> 3;
-  const int i = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int bid, int& tm, int& tn) {
+  const int i = xcd_chunk_index(tiles_m * tiles_n, bid);
   const int SN = tiles_n < 8 ? tiles_n : 8;
   const int full = (tiles_n / SN) * tiles_m * SN;  // tiles inside full-width strips
   if (i < full) {
