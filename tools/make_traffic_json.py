@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the two PMC summaries of tools/profile_round.sh (FETCH_SIZE pass + WRITE_SIZE pass):
+HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (counters are KiB; on gfx950 FETCH_SIZE reports half of the bytes of a
+16-B-per-lane streaming read, MI355X_MICROARCH.md 'HBM'), keyed by bench.py's kernel signature where the dispatch
+signature (kernel template + grid) identifies it, with the kernel-trace average duration of the same box next to it.
+    python tools/make_traffic_json.py gpurun_out/prof_r02 r02 > profiles/pmc_traffic.json"""
+import json
+import os
+import sys
+
+d, tag = sys.argv[1], sys.argv[2]
+f = json.load(open(os.path.join(d, f"{tag}_bench_pmc_fetch.json")))
+w = json.load(open(os.path.join(d, f"{tag}_bench_pmc_write.json")))
+kt = json.load(open(os.path.join(d, f"{tag}_bench_kernel_trace.json")))
+key = lambda r: (r["kernel"], r["workgroups"], r["workgroup_size"])  # noqa: E731
+W, K = {key(r): r for r in w}, {key(r): r for r in kt}
+by_label, by_sig = {}, {}
+for r in f:
+    k = key(r)
+    if k not in W:
+        continue
+    fetch = r["counters_per_launch"].get("FETCH_SIZE", 0.0) * 1024
+    write = W[k]["counters_per_launch"].get("WRITE_SIZE", 0.0) * 1024
+    rec = {"read_bytes": int(2 * fetch), "write_bytes": int(write), "hbm_bytes": int(2 * fetch + write), "launches": r["launches"],
+           "kernel_trace_avg_us": round(K[k]["avg_us"], 1) if k in K else None,
+           "kernel_trace_min_us": round(K[k]["min_us"], 1) if k in K else None,
+           "kernel_trace_max_us": round(K[k]["max_us"], 1) if k in K else None,
+           "kernel_trace_calls": K[k]["calls"] if k in K else None}
+    if r["bench_signature"]:
+        by_label[r["bench_signature"]] = rec
+    by_sig[f"{r['kernel']} [{r['workgroups']} x {r['workgroup_size']}]"] = rec
+print(json.dumps({
+    "_method": "tools/profile_round.sh " + tag + ": rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) on "
+               "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile`, summarised per dispatch signature by "
+               "tools/rocprof_summary.py; counters are KiB; read bytes = 2 x FETCH_SIZE (gfx950, 16-B/lane streaming reads), WRITE_SIZE as "
+               "is.  kernel_trace_* come from the kernel-trace pass of the SAME gpurun call (same box), 10 PPO steps.",
+    "by_bench_label": by_label, "by_dispatch_signature": by_sig}, indent=1))

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence bench.py's roofline object refers to (run on the GPU box: gpurun -- bash tools/profile_round.sh r02).
+# Separate passes: kernel trace (+stats) of the bench, FETCH_SIZE pass, WRITE_SIZE pass, encoder kernel trace, encoder MFMA
+# counters.  Raw CSVs (kernel names run to kilobytes per row) are summarised per dispatch signature by tools/rocprof_summary.py
+# and removed; only the summaries are kept under gpurun_out/ (copy the ones to be judged into profiles/).
+set -o pipefail
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/prof_$TAG
+mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+S="python3 $R/tools/rocprof_summary.py"
+echo "== kernel trace of the bench (10 PPO steps)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online > $O/bench_under_kernel_trace.json 2> $O/kt.err || exit 1
+$S kernel-trace $O/kt --steps 10 --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online ($TAG)" --md $O/${TAG}_bench_kernel_trace.md --json $O/${TAG}_bench_kernel_trace.json || exit 1
+rm -rf $O/kt
+echo "== FETCH_SIZE pass"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile > /dev/null 2> $O/fetch.err || exit 1
+$S pmc $O/fetch --title "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile ($TAG)" --md $O/${TAG}_bench_pmc_fetch.md --json $O/${TAG}_bench_pmc_fetch.json || exit 1
+rm -rf $O/fetch
+echo "== WRITE_SIZE pass"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile > /dev/null 2> $O/write.err || exit 1
+$S pmc $O/write --title "rocprofv3 --kernel-trace --pmc WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile ($TAG)" --md $O/${TAG}_bench_pmc_write.md --json $O/${TAG}_bench_pmc_write.json || exit 1
+rm -rf $O/write
+echo "== encoder forward: kernel trace"
+rocprofv3 --kernel-trace --output-format csv -d $O/enc_kt -- python3 $R/tools/encoder_bench.py --ppo-shapes --iters 3 > $O/encoder_under_kernel_trace.txt 2> $O/enc_kt.err || exit 1
+$S kernel-trace $O/enc_kt --title "rocprofv3 --kernel-trace -- python3 tools/encoder_bench.py --ppo-shapes --iters 3 ($TAG; 1 warm-up + 3 timed forwards of each encoder)" --md $O/${TAG}_encoder_kernel_trace.md --json $O/${TAG}_encoder_kernel_trace.json || exit 1
+rm -rf $O/enc_kt
+echo "== encoder forward: MFMA counters"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/enc_pmc -- python3 $R/tools/encoder_bench.py --ppo-shapes --iters 1 > /dev/null 2> $O/enc_pmc.err || exit 1
+$S pmc $O/enc_pmc --title "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python3 tools/encoder_bench.py --ppo-shapes --iters 1 ($TAG)" --md $O/${TAG}_encoder_pmc_mfma.md --json $O/${TAG}_encoder_pmc_mfma.json || exit 1
+rm -rf $O/enc_pmc
+echo "== plain bench on the same box"
+python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_same_box.json 2> $O/bench.err
+ls -la $O
