@@ -237,6 +237,238 @@ __global__ __launch_bounds__(64 * NW) void self_attn_mfma_kernel(const bf16_t* _
   }  // sub-tile loop
 }
 
+// ---- forward for sequences longer than one LDS-resident key block (L > 256: ViT-L/14's 257 tokens, RoBERTa's 514) ----
+// Same arithmetic and fragment layout as self_attn_mfma_kernel, with the keys walked in blocks of LP = 16 * NT: K / V of
+// ONE block live in LDS; every wave keeps, for each of its (up to SLOTS) 16-query sub-tiles, the running row maximum m,
+// the running sum l and the un-normalised output accumulator across the blocks (online softmax):
+//     m' = max(m, max_j s_j);  a = exp(m - m');  l = a l + sum_j exp(s_j - m');  O = a O + exp(s - m') V_block
+// and normalises by l at the end.  Probability dropout multiplies exp(s - m') by mask / keep before the P V product; l is
+// the sum WITHOUT the mask, so O / l equals dropout(softmax(S)) V exactly as in the one-block kernel.
+// Padding keys (index >= L) carry -inf; every block holds at least one real key (real keys masked by seg get -10000,
+// as upstream), so m' is finite from the first block on.
+template <int SLOTS>
+struct AttnState {
+  f32x4_t o[SLOTS][4];
+  float m[SLOTS], l[SLOTS];
+};
+
+template <int NT, int NW, int SLOTS, int J>
+__device__ __forceinline__ void blocked_subtiles(AttnState<SLOTS>& st, const bf16_t* __restrict__ Qh, size_t lo_off, int ld,
+                                                 size_t row0, int col0, const char* sK, const char* sV, const float* sMask,
+                                                 int sub_first, int sub_step, int n_sub, int L, int k0, float scale, int heads,
+                                                 int b, int h, const DropP& dr, int lane) {
+  constexpr int LP = 16 * NT;
+  constexpr int PLANE = LP * ROW_B;
+  const int qn = lane & 15, g = lane >> 4;
+  const int sub = sub_first + J * sub_step;
+  if (sub < n_sub) {            // wave-uniform
+    const int q_row = sub * 16 + qn;
+    bf16x8_t qh[2], ql[2];
+    {
+      const bool ok = q_row < L;
+      const size_t o = (row0 + (ok ? q_row : 0)) * (size_t)ld + col0 + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4_t a = {0, 0, 0, 0}, c = a;
+        if (ok) {
+          a = *reinterpret_cast<const u32x4_t*>(Qh + o + 32 * ks);
+          c = *reinterpret_cast<const u32x4_t*>(Qh + o + 32 * ks + lo_off);
+        }
+        qh[ks] = __builtin_bit_cast(bf16x8_t, a);
+        ql[ks] = __builtin_bit_cast(bf16x8_t, c);
+      }
+    }
+    f32x4_t s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int r = 16 * t + qn;
+        const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(sK + k_off(r, g + 4 * ks));
+        const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(sK + PLANE + k_off(r, g + 4 * ks));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], acc, 0, 0, 0);
+      }
+      s[t] = acc;
+    }
+    float mx = st.m[J];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 mk = *reinterpret_cast<const float4*>(sMask + 16 * t + 4 * g);
+      s[t][0] = s[t][0] * scale + mk.x;
+      s[t][1] = s[t][1] * scale + mk.y;
+      s[t][2] = s[t][2] * scale + mk.z;
+      s[t][3] = s[t][3] * scale + mk.w;
+      mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float alpha = exp_fast(st.m[J] - mx);     // first block: exp(-inf) = 0
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[t][r] = exp_fast(s[t][r] - mx);
+        sum += s[t][r];
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    st.m[J] = mx;
+    st.l[J] = st.l[J] * alpha + sum;
+    // the output accumulator holds O[query 4g + r][..] in register r, the statistics belong to query (l & 15): fetch the
+    // rescale factor of query 4g + r from the lane that owns it
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a_r = __shfl(alpha, 4 * g + r, 64);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) st.o[J][n][r] *= a_r;
+    }
+    const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_row < L ? q_row : 0)) * (uint64_t)L + (uint64_t)k0;
+    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+#pragma unroll
+    for (int u = 0; u < NT / 2; ++u) {
+      float p[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r] = s[2 * u][r];
+        p[4 + r] = s[2 * u + 1][r];
+      }
+      if (dr.thr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[r] *= drop_mul(dr, drow + 32 * u + 4 * g + r);
+          p[4 + r] *= drop_mul(dr, drow + 32 * u + 16 + 4 * g + r);
+        }
+      }
+      const uint32_t h01 = cvt_pk_bf16(p[0], p[1]), h23 = cvt_pk_bf16(p[2], p[3]);
+      const uint32_t h45 = cvt_pk_bf16(p[4], p[5]), h67 = cvt_pk_bf16(p[6], p[7]);
+      const uint32_t l01 = cvt_pk_bf16(p[0] - __uint_as_float(h01 << 16), p[1] - __uint_as_float(h01 & 0xffff0000u));
+      const uint32_t l23 = cvt_pk_bf16(p[2] - __uint_as_float(h23 << 16), p[3] - __uint_as_float(h23 & 0xffff0000u));
+      const uint32_t l45 = cvt_pk_bf16(p[4] - __uint_as_float(h45 << 16), p[5] - __uint_as_float(h45 & 0xffff0000u));
+      const uint32_t l67 = cvt_pk_bf16(p[6] - __uint_as_float(h67 << 16), p[7] - __uint_as_float(h67 & 0xffff0000u));
+      const bf16x8_t ph = __builtin_bit_cast(bf16x8_t, (u32x4_t{h01, h23, h45, h67}));
+      const bf16x8_t pl = __builtin_bit_cast(bf16x8_t, (u32x4_t{l01, l23, l45, l67}));
+      const int ra = 32 * u + 4 * g + tq, rb = ra + 16;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int unit = 2 * n + (tp >> 1), half8 = 8 * (tp & 1);
+        const bf16x8_t vh = tr_pair(sV, ra, rb, unit, half8);
+        const bf16x8_t vl = tr_pair(sV + PLANE, ra, rb, unit, half8);
+        st.o[J][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh, st.o[J][n], 0, 0, 0);
+        st.o[J][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl, st.o[J][n], 0, 0, 0);
+        st.o[J][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh, st.o[J][n], 0, 0, 0);
+      }
+    }
+  }
+  if constexpr (J + 1 < SLOTS)
+    blocked_subtiles<NT, NW, SLOTS, J + 1>(st, Qh, lo_off, ld, row0, col0, sK, sV, sMask, sub_first, sub_step, n_sub, L, k0, scale,
+                                           heads, b, h, dr, lane);
+}
+
+template <int SLOTS, int J>
+__device__ __forceinline__ void blocked_finish(AttnState<SLOTS>& st, float* slab, int sub_first, int sub_step, int n_sub, int L,
+                                               size_t row0, int col0, float* __restrict__ O, bf16_t* __restrict__ Oh,
+                                               size_t o_lo_off, int ld_o, float* __restrict__ lse, int heads, int b, int h, int lane) {
+  const int qn = lane & 15, g = lane >> 4;
+  const int sub = sub_first + J * sub_step;
+  if (sub < n_sub) {
+    const float inv = 1.0f / st.l[J];
+    const int q_row = sub * 16 + qn;
+    if (lse && g == 0 && q_row < L) lse[((size_t)b * heads + h) * L + q_row] = st.m[J] + logf(st.l[J]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float inv_r = __shfl(inv, 4 * g + r, 64);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) slab[(4 * g + r) * (HD + 4) + 16 * n + qn] = st.o[J][n][r] * inv_r;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = pass * 4 + (lane >> 4), c = (lane & 15) * 4;
+      const int qr = sub * 16 + r;
+      if (qr < L) {
+        const float4 v = *reinterpret_cast<const float4*>(slab + r * (HD + 4) + c);
+        const size_t off = (row0 + qr) * (size_t)ld_o + col0 + c;
+        if (O) *reinterpret_cast<float4*>(O + off) = v;
+        if (Oh) store_planes4(Oh + off, o_lo_off, v);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if constexpr (J + 1 < SLOTS)
+    blocked_finish<SLOTS, J + 1>(st, slab, sub_first, sub_step, n_sub, L, row0, col0, O, Oh, o_lo_off, ld_o, lse, heads, b, h, lane);
+}
+
+template <int NT, int NW, int SLOTS>
+__global__ __launch_bounds__(64 * NW) void self_attn_blocked_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
+                                                                const bf16_t* __restrict__ Vh, size_t lo_off, int ld,
+                                                                const int64_t* __restrict__ seg, float* __restrict__ O,
+                                                                bf16_t* __restrict__ Oh, size_t o_lo_off, int ld_o, int heads,
+                                                                int L, float scale, float* __restrict__ lse, DropP dr,
+                                                                int n_blocks) {
+  constexpr int LP = 16 * NT;
+  constexpr int PLANE = LP * ROW_B;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + 2 * PLANE;
+  float* sMask = reinterpret_cast<float*>(smem + 4 * PLANE);
+  float* sOut = sMask + LP;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row0 = (size_t)b * L;
+  const int col0 = h * HD;
+  const int n_sub = (L + 15) >> 4;
+  const int sub_first = blockIdx.x * NW + wave, sub_step = gridDim.x * NW;   // host: sub_first + SLOTS * sub_step >= n_sub
+  AttnState<SLOTS> st;
+#pragma unroll
+  for (int j = 0; j < SLOTS; ++j) {
+    st.m[j] = -INFINITY;
+    st.l[j] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) st.o[j][n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int blk = 0; blk < n_blocks; ++blk) {
+    const int k0 = blk * LP;
+    if (blk) __syncthreads();                       // every wave is done reading the previous block
+    constexpr int TRIPS = (LP * 8 + 64 * NW - 1) / (64 * NW);
+    u32x4_t kh[TRIPS], kl[TRIPS], vh[TRIPS], vl[TRIPS];
+#pragma unroll
+    for (int it = 0; it < TRIPS; ++it) {
+      const int i = tid + it * 64 * NW;
+      const int r = i >> 3, u = i & 7;
+      kh[it] = u32x4_t{0, 0, 0, 0};
+      kl[it] = kh[it]; vh[it] = kh[it]; vl[it] = kh[it];
+      if (i < LP * 8 && k0 + r < L) {
+        const size_t o = (row0 + k0 + r) * (size_t)ld + col0 + u * 8;
+        kh[it] = *reinterpret_cast<const u32x4_t*>(Kh + o);
+        kl[it] = *reinterpret_cast<const u32x4_t*>(Kh + o + lo_off);
+        vh[it] = *reinterpret_cast<const u32x4_t*>(Vh + o);
+        vl[it] = *reinterpret_cast<const u32x4_t*>(Vh + o + lo_off);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < TRIPS; ++it) {
+      const int i = tid + it * 64 * NW;
+      const int r = i >> 3, u = i & 7;
+      if (i < LP * 8) {
+        *reinterpret_cast<u32x4_t*>(sK + k_off(r, u)) = kh[it];
+        *reinterpret_cast<u32x4_t*>(sK + PLANE + k_off(r, u)) = kl[it];
+        *reinterpret_cast<u32x4_t*>(sV + v_off(r, u)) = vh[it];
+        *reinterpret_cast<u32x4_t*>(sV + PLANE + v_off(r, u)) = vl[it];
+      }
+    }
+    for (int j = tid; j < LP; j += 64 * NW) sMask[j] = (k0 + j < L) ? ((seg[row0 + k0 + j] > 0) ? 0.f : -10000.0f) : -INFINITY;
+    __syncthreads();
+    blocked_subtiles<NT, NW, SLOTS, 0>(st, Qh, lo_off, ld, row0, col0, sK, sV, sMask, sub_first, sub_step, n_sub, L, k0, scale, heads,
+                                       b, h, dr, lane);
+  }
+  blocked_finish<SLOTS, 0>(st, sOut + wave * 16 * (HD + 4), sub_first, sub_step, n_sub, L, row0, col0, O, Oh, o_lo_off, ld_o, lse,
+                           heads, b, h, lane);
+}
+
 // fp32 x 8 -> A fragment pair (hi, lo) of the split product
 __device__ __forceinline__ void split8(const float (&p)[8], bf16x8_t& hi, bf16x8_t& lo) {
   uint32_t h[4], l[4];
@@ -599,6 +831,35 @@ int launch_fwd(const AttnArgs& a, float* o, bf16_t* oh, size_t o_lo_off, int ld_
   return lr2_launch_status("lr2_self_attn_fwd");
 }
 
+// L > 256: key blocks of 16 * NT keys, nb = ceil(L / 224) blocks of equal (rounded) size; SLOTS sub-tiles of 16 queries per
+// wave, the query range split over gridDim.x workgroups when a sequence has more than 8 * SLOTS sub-tiles.
+template <int NT, int SLOTS>
+int launch_fwd_blocked(const AttnArgs& a, float* o, bf16_t* oh, size_t o_lo_off, int ld_o, float* lse, int n_blocks) {
+  constexpr int LP = 16 * NT, NW = 8;
+  const size_t lds = (size_t)4 * LP * ROW_B + (size_t)LP * 4 + (size_t)NW * 16 * (HD + 4) * 4;
+  static bool done = false;
+  if (allow_lds_once(self_attn_blocked_kernel<NT, NW, SLOTS>, lds, done, "self_attn_fwd(blocked)")) return LR2_ERR_LAUNCH;
+  const int n_sub = (a.L + 15) / 16;
+  const int chunks = (n_sub + NW * SLOTS - 1) / (NW * SLOTS);
+  LR2_LAUNCH((self_attn_blocked_kernel<NT, NW, SLOTS>), dim3(chunks, a.heads, a.batch), dim3(64 * NW), lds, a.stream, a.q, a.k, a.v,
+             a.lo_off, a.ld, a.seg, o, oh, o_lo_off, ld_o, a.heads, a.L, a.scale, lse, a.dr, n_blocks);
+  return lr2_launch_status("lr2_self_attn_fwd(blocked)");
+}
+
+static int fwd_blocked_dispatch(const AttnArgs& a, float* o, bf16_t* oh, size_t o_lo_off, int ld_o, float* lse) {
+  const int nb = (a.L + 223) / 224;
+  const int tiles = (((a.L + nb - 1) / nb) + 15) / 16;       // key tiles per block
+  const int n_sub = (a.L + 15) / 16;
+  const bool few = n_sub <= 8 * 3;                           // 3 sub-tile slots per wave are enough (L <= 384); else 4 (+ query chunks)
+#define BLK(NT)                                                                                        \
+  return few ? launch_fwd_blocked<NT, 3>(a, o, oh, o_lo_off, ld_o, lse, (a.L + 16 * NT - 1) / (16 * NT)) \
+             : launch_fwd_blocked<NT, 4>(a, o, oh, o_lo_off, ld_o, lse, (a.L + 16 * NT - 1) / (16 * NT));
+  if (tiles <= 10) { BLK(10) }
+  if (tiles <= 12) { BLK(12) }
+  BLK(14)
+#undef BLK
+}
+
 template <int NT>
 int launch_bwd(const AttnArgs& a, const bf16_t* go, size_t do_lo_off, int ld_do, bf16_t* dq, bf16_t* dk, bf16_t* dv,
                size_t d_lo_off, int ld_d, float* lse, float* dsum) {
@@ -645,10 +906,11 @@ extern "C" int lr2_self_attn_fwd(const void* q_hi, const void* k_hi, const void*
                                  uint64_t drop_seed, uint32_t drop_site, int batch, int heads, int L, int head_dim, float scale,
                                  void* stream) {
   if (!q_hi || !k_hi || !v_hi || !seg || (!o && !o_hi) || batch <= 0 || heads <= 0) return LR2_ERR_ARG;
-  if (head_dim != HD || L < 1 || L > 256 || ld % 8 || ld_o % 4 || lo_off % 8 || o_lo_off % 4) return LR2_ERR_SHAPE;
+  if (head_dim != HD || L < 1 || ld % 8 || ld_o % 4 || lo_off % 8 || o_lo_off % 4) return LR2_ERR_SHAPE;
   if (drop_p < 0.f || drop_p >= 1.f) return LR2_ERR_ARG;
   const AttnArgs a{(const bf16_t*)q_hi, (const bf16_t*)k_hi, (const bf16_t*)v_hi, (size_t)lo_off, ld, seg, batch, heads, L,
                    scale, make_drop(drop_p, drop_seed, drop_site), (hipStream_t)stream};
+  if (L > 256) return fwd_blocked_dispatch(a, (float*)o, (bf16_t*)o_hi, (size_t)o_lo_off, ld_o, (float*)lse);
 #define CALL(NT) launch_fwd<NT>(a, (float*)o, (bf16_t*)o_hi, (size_t)o_lo_off, ld_o, (float*)lse)
   LR2_SA_DISPATCH(L, CALL)
 #undef CALL

@@ -357,3 +357,70 @@ def test_gemm256_fused_epilogues(dev):
     ops.gemm(ap, wp, out, M, N, K, bias=bias.to(dev), drop=drop, resid=resid.to(dev), block_m=256, splits=1)
     keep = torch.from_numpy(O.dropout_keep_mask(77, 3, M * N, 0.1)).view(M, N)
     _close(out, z_ref * keep.double() / 0.9 + resid.double(), 1e-4, 5e-5, "dropout+resid")
+
+
+# ---- self-attention beyond one LDS-resident key block (L > 256) --------------------------------------------------------------
+@pytest.mark.parametrize("batch,heads,L,drop_p", [(2, 16, 257, 0.0), (1, 3, 514, 0.0), (2, 2, 300, 0.1), (1, 2, 449, 0.0),
+                                                    (1, 1, 700, 0.0)])
+def test_self_attn_forward_blocked_keys(dev, batch, heads, L, drop_p):
+    """ViT-L/14 (257 tokens), RoBERTa's max_seq_length (514) and beyond: the key-block loop with running max / sum against
+    the fp64 reference formula -- key mask on the last sequence, probability dropout with the global key index, fp32 and
+    planes outputs, log-sum-exp."""
+    import numpy as np
+    from lr2ppo_amd import ops
+    from test_kernels_gpu import _close
+    g = torch.Generator().manual_seed(L + heads)
+    E = heads * 64
+    qkv = torch.cat([torch.randn(batch * L, E, generator=g) * 0.3, torch.randn(batch * L, E, generator=g) * 0.3,
+                     torch.randn(batch * L, E, generator=g)], dim=1)
+    seg = torch.ones(batch, L, dtype=torch.long)
+    seg[-1, (2 * L) // 3:] = 0
+    mask = (1.0 - (seg > 0).double()).view(batch, 1, 1, L) * -10000.0
+    mult = torch.ones(batch, heads, L, L, dtype=torch.float64)
+    seed, site = 42, 7
+    if drop_p > 0:
+        keep = O.dropout_keep_mask(seed, site, batch * heads * L * L, drop_p)
+        mult = torch.from_numpy(np.asarray(keep, dtype=np.float64)).view(batch, heads, L, L) / (1.0 - drop_p)
+    qh, kh, vh = (t.double().reshape(batch, L, heads, 64).transpose(1, 2) for t in qkv.split(E, dim=1))
+    sc = qh @ kh.transpose(-2, -1) / 8.0 + mask
+    ref = ((torch.softmax(sc, dim=-1) * mult) @ vh).transpose(1, 2).reshape(batch * L, E)
+    qkv_p = ops.split_planes(qkv.to(dev), ops.Planes.empty(batch * L, 3 * E, dev))
+    o = torch.full((batch * L, E), float("nan"), device=dev)
+    lse = torch.empty(batch * heads * L, device=dev)
+    drop = ops.Drop(drop_p, seed, site) if drop_p > 0 else None
+    ops.self_attn_fwd(qkv_p, seg.to(dev).view(-1), o, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, lse=lse, drop=drop)
+    _close(o, ref, 3e-5, 3e-5, "blocked self-attn")
+    _close(lse.view(batch, heads, L), torch.logsumexp(sc, dim=-1), 1e-5, 1e-5, "lse")
+    op = ops.Planes.empty(batch * L, E, dev)
+    ops.self_attn_fwd(qkv_p, seg.to(dev).view(-1), op, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, drop=drop)
+    assert torch.equal(op.buf, ops.split_planes(o, ops.Planes.empty(batch * L, E, dev)).buf)
+
+
+def test_vit_l14_config_forward_matches_oracle(dev):
+    """BASELINE config 5 groundwork: the ViT-L/14 encoder swap (lr2ppo_amd/configs/vit_large_14_224.json: hidden 1024, 24
+    layers, 16 heads, patch 14 -> 257 tokens, patch rows padded 588 -> 640 for whole K tiles): embedding + the first two
+    layers against the oracle on the host."""
+    import json
+    import os
+    from lr2ppo_amd.finetune.features import EncoderStack, encoder_args
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lr2ppo_amd", "configs", "vit_large_14_224.json")
+    full = json.load(open(cfg))
+    assert (full["hidden_size"], full["layers_num"], full["heads_num"], full["patch_size"], full["max_seq_length"]) == (1024, 24, 16, 14, 257)
+    a = encoder_args(cfg, layers_num=2)
+    stack = EncoderStack(a, 10)
+    pe = O.seeded_params(O.vit_embedding_spec(1024, 3, 14, 257), seed=91)
+    pn = O.seeded_params(O.encoder_param_spec(2, 1024, 4096, True), seed=92)
+    stack.embedding.load_state_dict(pe, strict=True)
+    stack.encoder.load_state_dict(pn, strict=True)
+    stack = stack.to(dev).eval()
+    gen = torch.Generator().manual_seed(93)
+    img = torch.randn(2, 3, 224, 224, generator=gen)
+    seg = torch.ones(2, 257, dtype=torch.long)
+    with torch.no_grad():
+        got = stack(img.to(dev), seg.to(dev))
+        want = O.transformer_encoder(pn, O.vit_embedding(pe, img, 14), seg, 2, 16, True)
+    assert got.shape == (2, 257, 1024)
+    _cmp(got, want, "ViT-L/14, 2 layers")
+    with pytest.raises(Exception, match="256"):                 # the training path still needs one LDS-resident key block
+        stack.train()
+        stack(img.to(dev).requires_grad_(True), seg.to(dev)).sum().backward()
