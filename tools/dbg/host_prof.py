@@ -27,11 +27,13 @@ def step():
     return ppo.update_minibatch(margs, model, opt, copt, rec, dp)
 for _ in range(3): step()
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(10): step()
-t_host = time.perf_counter() - t0
-torch.cuda.synchronize()
-print("host enqueue ms/step", t_host / 10 * 1e3, "total", (time.perf_counter() - t0) / 10 * 1e3)
+for n in (1, 2, 5, 10, 20, 40):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); c0 = time.thread_time()
+    for _ in range(n): step()
+    t_host = time.perf_counter() - t0; c_host = time.thread_time() - c0
+    torch.cuda.synchronize()
+    print(f"n={n}: host wall {t_host / n * 1e3:.2f} ms/step, host cpu {c_host / n * 1e3:.2f} ms/step, total {(time.perf_counter() - t0) / n * 1e3:.2f}")
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): step()
 pr.disable(); torch.cuda.synchronize()
