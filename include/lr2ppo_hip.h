@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 10
+#define LR2_ABI_VERSION 11
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -208,6 +208,22 @@ int lr2_ppo_loss(const void* scores, const void* old_scores, const void* rewards
                  const void* value, const int64_t* next_state, int ns_len, int rank_len, int B, int T, float kl_w,
                  float ent_w, float value_clip, float margin, float adv_eps, void* scalars, void* per_item,
                  void* dscores, void* dvalue, void* stats_out, const void* global_stats, int world, void* stream);
+
+/* mode = 'cls' (C classes, C <= 8): the 768 -> C head, y[r, c] = x[r, :] . w[c, :] + b[c], and its backward
+ * (dx[r, :] = sum_c dy[r, c] w[c, :]; dw[c, :] = sum_r dy[r, c] x[r, :]; db[c] = sum_r dy[r, c]; dx or dw/db may be NULL).
+ * replaces: nn.Linear(768, labels_num) of finetune/ppo.py:209-210,228-230 and its autograd. */
+int lr2_cls_head_fwd(const void* x, const void* w, const void* b, void* y, int rows, int D, int C, void* stream);
+int lr2_cls_head_bwd(const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, int rows, int D, int C,
+                     void* stream);
+/* probs[r, :] = softmax(logits[r, :]) (use_softmax = 1) or logits[r, :] (0: evaluate(), ppo.py:641-643); scores[r] =
+ * sum_k k * probs[r, k] (the expected label the PPO loop ranks by); probs may be NULL.
+ * replaces: finetune/ppo.py:532-537 / :859-863 / :641-643. */
+int lr2_cls_scores(const void* logits, void* probs, void* scores, int rows, int C, int use_softmax, void* stream);
+/* dlogits[r, c] = dscores[r] * probs[r, c] * (c - scores[r]): autograd of the softmax form of lr2_cls_scores. */
+int lr2_cls_scores_bwd(const void* probs, const void* scores, const void* dscores, void* dlogits, int rows, int C, void* stream);
+/* loss[0] = mean_r (logsumexp(logits[r, :]) - logits[r, tgts[r]]); dlogits (may be NULL) = its gradient.
+ * replaces: nn.NLLLoss()(nn.LogSoftmax(dim=-1)(logits), tgts) of finetune/ppo.py:239-241 and its autograd. */
+int lr2_nll_loss(const void* logits, const int64_t* tgts, int rows, int C, void* loss, void* dlogits, void* stream);
 
 /* SmoothL1(beta) mean loss + gradient (dpred may be NULL).  replaces: nn.SmoothL1Loss(beta=0.3) (finetune/ppo.py:236). */
 int lr2_smooth_l1(const void* pred, const void* target, int n, float beta, void* loss, void* dpred, void* stream);

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(CSRC, "liblr2ppo_hip.so")
 SOURCES = ["gemm.hip", "gemm256.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
 
-ABI_VERSION = 10     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
+ABI_VERSION = 11     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
 
 _lock = threading.Lock()
 _lib = None
@@ -109,6 +109,11 @@ SIGNATURES = {
     "lr2_period_rows_grad": [_P, _P, _I, _I, _I, _P],
     "lr2_ppo_loss": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _I, _P],
     "lr2_smooth_l1": [_P, _P, _I, _F, _P, _P, _P],
+    "lr2_cls_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "lr2_cls_head_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "lr2_cls_scores": [_P, _P, _P, _I, _I, _I, _P],
+    "lr2_cls_scores_bwd": [_P, _P, _P, _P, _I, _I, _P],
+    "lr2_nll_loss": [_P, _P, _I, _I, _P, _P, _P],
     "lr2_pair_hinge": [_P, _I, _F, _P, _P, _P],
     "lr2_adamw_multi": [_P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _P],
     "lr2_text_embed": [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.c_int64, _I, _P, _P],

@@ -394,6 +394,128 @@ __global__ __launch_bounds__(1024) void ppo_loss_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// mode = 'cls' (finetune/ppo.py:209-210,229-230,239-242): a 768 -> C classification head, NLL of log-softmax, and the
+// "expected label" score sum_k k * softmax(z)_k the PPO loop ranks by (ppo.py:532-537,859-863); C <= 8.
+constexpr int CLS_MAX_C = 8;
+// y[r, c] = x[r, :] . w[c, :] + b[c]; one wave per row
+__global__ __launch_bounds__(256) void cls_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ y, int rows, int D,
+                                                           int C) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float acc[CLS_MAX_C];
+#pragma unroll
+  for (int c = 0; c < CLS_MAX_C; ++c) acc[c] = 0.f;
+  for (int d = lane * 4; d < D; d += 256) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)r * D + d);
+#pragma unroll
+    for (int c = 0; c < CLS_MAX_C; ++c)
+      if (c < C) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)c * D + d);
+        acc[c] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < CLS_MAX_C; ++c)
+    if (c < C) {
+      const float s = wave_sum(acc[c]);
+      if (lane == 0) y[(size_t)r * C + c] = s + b[c];
+    }
+}
+// dx[r, :] = sum_c dy[r, c] w[c, :]
+__global__ __launch_bounds__(256) void cls_head_bwd_dx_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, int rows, int D, int C) {
+  const int d4 = D / 4;
+  const size_t total = (size_t)rows * d4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / d4), d = (int)(i % d4) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < C; ++c) {
+      const float g = dy[(size_t)r * C + c];
+      const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)c * D + d);
+      a.x += g * wv.x; a.y += g * wv.y; a.z += g * wv.z; a.w += g * wv.w;
+    }
+    *reinterpret_cast<float4*>(dx + (size_t)r * D + d) = a;
+  }
+}
+// dw[c, d] = sum_r dy[r, c] x[r, d]; db[c] = sum_r dy[r, c]   (rows is a few hundred at most: one thread per (c, d))
+__global__ __launch_bounds__(256) void cls_head_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                              float* __restrict__ dw, float* __restrict__ db, int rows, int D,
+                                                              int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * D) return;
+  const int c = i / D, d = i % D;
+  float a = 0.f, bsum = 0.f;
+  for (int r = 0; r < rows; ++r) {
+    const float g = dy[(size_t)r * C + c];
+    a += g * x[(size_t)r * D + d];
+    bsum += g;
+  }
+  dw[i] = a;
+  if (d == 0) db[c] = bsum;
+}
+// probs = softmax(logits) (or, with use_softmax == 0, the raw logits as evaluate() uses them, ppo.py:641-643);
+// scores[r] = sum_k k * probs[r, k]
+__global__ __launch_bounds__(256) void cls_scores_kernel(const float* __restrict__ logits, float* __restrict__ probs,
+                                                         float* __restrict__ scores, int rows, int C, int use_softmax) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float z[CLS_MAX_C], mx = -INFINITY, sum = 0.f, e = 0.f;
+#pragma unroll
+  for (int c = 0; c < CLS_MAX_C; ++c) {
+    z[c] = c < C ? logits[(size_t)r * C + c] : -INFINITY;
+    mx = fmaxf(mx, z[c]);
+  }
+  if (use_softmax) {
+#pragma unroll
+    for (int c = 0; c < CLS_MAX_C; ++c) {
+      z[c] = c < C ? expf(z[c] - mx) : 0.f;
+      sum += z[c];
+    }
+  } else {
+    sum = 1.f;
+  }
+#pragma unroll
+  for (int c = 0; c < CLS_MAX_C; ++c)
+    if (c < C) {
+      const float p = z[c] / sum;
+      if (probs) probs[(size_t)r * C + c] = p;
+      e += (float)c * p;
+    }
+  scores[r] = e;
+}
+// d scores / d logits through the softmax: dlogits[r, c] = dscores[r] * p_c * (c - scores[r])
+__global__ __launch_bounds__(256) void cls_scores_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ scores,
+                                                             const float* __restrict__ dscores, float* __restrict__ dlogits,
+                                                             int rows, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * C) return;
+  const int r = i / C, c = i % C;
+  dlogits[i] = dscores[r] * probs[i] * ((float)c - scores[r]);
+}
+// mean NLL of log-softmax (nn.NLLLoss()(nn.LogSoftmax(-1)(logits), tgts), ppo.py:240) and its gradient
+__global__ __launch_bounds__(1024) void nll_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ tgts, int rows,
+                                                        int C, float* __restrict__ loss, float* __restrict__ dlogits) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+    float mx = -INFINITY, sum = 0.f;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, logits[(size_t)r * C + c]);
+    for (int c = 0; c < C; ++c) sum += expf(logits[(size_t)r * C + c] - mx);
+    const float lz = mx + logf(sum);
+    int t = (int)tgts[r];
+    t = t < 0 ? 0 : (t >= C ? C - 1 : t);
+    acc += lz - logits[(size_t)r * C + t];
+    if (dlogits)
+      for (int c = 0; c < C; ++c)
+        dlogits[(size_t)r * C + c] = (expf(logits[(size_t)r * C + c] - lz) - (c == t ? 1.f : 0.f)) / (float)rows;
+  }
+  const float s = block_sum_1024(acc, red);
+  if (threadIdx.x == 0) loss[0] = s / (float)rows;
+}
+
 __global__ __launch_bounds__(1024) void smooth_l1_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, int n,
                                                          float beta, float* __restrict__ loss, float* __restrict__ dpred) {
   __shared__ float red[16];
@@ -818,6 +940,55 @@ extern "C" int lr2_ppo_loss(const void* scores, const void* old_scores, const vo
                      (const float*)old_scores, (const float*)rewards, (const float*)old_value, (const float*)value,
                      next_state, ns_len, rank_len, B, T, kl_w, ent_w, value_clip, margin, adv_eps, (float*)scalars,
                      (float*)per_item, (float*)dscores, (float*)dvalue, (float*)stats_out, (const float*)global_stats, world);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_cls_head_fwd(const void* x, const void* w, const void* b, void* y, int rows, int D, int C, void* stream) {
+  if (!x || !w || !b || !y || rows <= 0) return LR2_ERR_ARG;
+  if (D % 4 || C < 1 || C > CLS_MAX_C) return LR2_ERR_SHAPE;
+  LR2_LAUNCH(cls_head_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)w,
+             (const float*)b, (float*)y, rows, D, C);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_cls_head_bwd(const void* x, const void* w, const void* dy, void* dx, void* dw, void* db, int rows, int D, int C,
+                                void* stream) {
+  if (!x || !w || !dy || rows <= 0) return LR2_ERR_ARG;
+  if (D % 4 || C < 1 || C > CLS_MAX_C) return LR2_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dx) {
+    LR2_LAUNCH(cls_head_bwd_dx_kernel, dim3(grid_for((size_t)rows * D / 4)), dim3(256), 0, s, (const float*)w, (const float*)dy,
+               (float*)dx, rows, D, C);
+    if (lr2_launch_status(__func__)) return LR2_ERR_LAUNCH;
+  }
+  if (dw && db)
+    LR2_LAUNCH(cls_head_bwd_dw_kernel, dim3((C * D + 255) / 256), dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)dw,
+               (float*)db, rows, D, C);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_cls_scores(const void* logits, void* probs, void* scores, int rows, int C, int use_softmax, void* stream) {
+  if (!logits || !scores || rows <= 0) return LR2_ERR_ARG;
+  if (C < 1 || C > CLS_MAX_C) return LR2_ERR_SHAPE;
+  LR2_LAUNCH(cls_scores_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)logits, (float*)probs,
+             (float*)scores, rows, C, use_softmax);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_cls_scores_bwd(const void* probs, const void* scores, const void* dscores, void* dlogits, int rows, int C,
+                                  void* stream) {
+  if (!probs || !scores || !dscores || !dlogits || rows <= 0) return LR2_ERR_ARG;
+  if (C < 1 || C > CLS_MAX_C) return LR2_ERR_SHAPE;
+  LR2_LAUNCH(cls_scores_bwd_kernel, dim3((rows * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)probs,
+             (const float*)scores, (const float*)dscores, (float*)dlogits, rows, C);
+  CHECK_LAUNCH();
+}
+
+extern "C" int lr2_nll_loss(const void* logits, const int64_t* tgts, int rows, int C, void* loss, void* dlogits, void* stream) {
+  if (!logits || !tgts || !loss || rows <= 0) return LR2_ERR_ARG;
+  if (C < 1 || C > CLS_MAX_C) return LR2_ERR_SHAPE;
+  LR2_LAUNCH(nll_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)logits, tgts, rows, C, (float*)loss,
+             (float*)dlogits);
   CHECK_LAUNCH();
 }
 

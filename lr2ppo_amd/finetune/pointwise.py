@@ -5,7 +5,7 @@ build_optimizer, train_model, evaluate, get_dataloader, main`.  `Classifier` is 
 state_dict keys, finetune/pointwise.py:189-236 == finetune/ppo.py:196-244), trained with SmoothL1(beta=0.3) on the tag
 relevance labels, one optimizer + scheduler step per batch (pointwise.py:300-313).  The model forward / backward, the
 loss and AdamW run on the gfx950 kernels through lr2ppo_amd.engine exactly as in stage 3; only this host loop is new.
-mode='reg' only (the mode of every LR2PPO launcher); there is no CPU fallback.
+mode 'reg' (every LR2PPO launcher) and 'cls'; there is no CPU fallback.
 """
 from __future__ import annotations
 
@@ -147,10 +147,14 @@ def train_model(args, model, optimizer, scheduler, text_emb_batch, img_emb_batch
     dev = text_emb_batch.device
     model.bind_grads()
     dp = _DataParallel()
-    logits = model.engine_forward(text_emb_batch, img_emb_batch, save=True).view(-1)
-    target = tgts_batch.to(device=dev, dtype=torch.float32).contiguous().view(-1)
+    logits = model.engine_forward(text_emb_batch, img_emb_batch, save=True)
     loss, dlogits = torch.empty(1, device=dev), torch.empty_like(logits)
-    ops.smooth_l1(logits, target, loss, dlogits, n=logits.numel(), beta=0.3)
+    if model.n_out > 1:      # mode 'cls' (pointwise.py:228-232): NLL of log-softmax over labels_num classes
+        target = tgts_batch.to(device=dev, dtype=torch.int64).contiguous().view(-1)
+        ops.nll_loss(logits, target, loss, dlogits, rows=logits.shape[0], C=model.n_out)
+    else:
+        target = tgts_batch.to(device=dev, dtype=torch.float32).contiguous().view(-1)
+        ops.smooth_l1(logits.view(-1), target, loss, dlogits.view(-1), n=logits.numel(), beta=0.3)
     fuse = getattr(args, "fuse_fc1_update", True) and hasattr(optimizer, "external_update")
     fa = optimizer.external_update(model.out_layer.fc1.weight) if fuse else None
     model.engine_backward(dlogits, dp, fc1_update=fa)
@@ -168,7 +172,11 @@ def evaluate(args, model, dataloader, step, split="test", num_tasks=None):
     model.eval()
     scores, golds = [], []
     for text_emb, img_emb, tgts in dataloader:
-        scores.append(model.engine_forward(text_emb.to(args.device), img_emb.to(args.device), save=False).view(-1))
+        logits = model.engine_forward(text_emb.to(args.device), img_emb.to(args.device), save=False)
+        if model.n_out > 1:     # 'cls': 0 * z0 + 1 * z1 + 2 * z2 on the raw logits (pointwise.py:342-345)
+            logits = ops.cls_scores(logits, None, torch.empty(logits.shape[0], device=logits.device), rows=logits.shape[0],
+                                    C=logits.shape[1], softmax=False)
+        scores.append(logits.view(-1))
         golds.append(tgts.view(-1))
     mine = ndcg_rows(scores, golds, args.device, tuple(ndcg_obj.ndcg_at_k))   # one kernel + one copy for the whole split
     world = num_tasks or 1

@@ -159,8 +159,8 @@ class _Head(nn.Module):
         super().__init__()
         self.mode = args.mode
         self.labels_num = args.labels_num
-        if self.mode != "reg":
-            raise NotImplementedError("the HIP path implements mode='reg' (the mode of every LR2PPO launcher, ppo.sh:25)")
+        if self.mode not in ("reg", "cls"):
+            raise ValueError(f"mode must be 'reg' or 'cls' (finetune/ppo.py:209-212), got {self.mode!r}")
         if args.visual_feat_dim != FEAT:
             raise ValueError("visual_feat_dim must be 768 (hard-coded in the reference, finetune/ppo.py:202-208)")
         self.seq_length, self.max_imgs = args.seq_length, args.max_imgs
@@ -174,7 +174,11 @@ class _Head(nn.Module):
         if self.has_tail:
             self.xitt = XiT(feat_size=FEAT, attention_mask="causal")
         self.out_layer = Mlp((args.seq_length + args.max_imgs) * args.visual_feat_dim, FEAT * 4, FEAT, nn.GELU, 0)
-        self.head = nn.Linear(FEAT, 1)
+        # 'cls': the ACTOR scores through a labels_num-way classifier (finetune/ppo.py:209-210); Critic / Reward keep 768 -> 1
+        self.n_out = self.labels_num if (self.mode == "cls" and not self.has_tail) else 1
+        if self.n_out > 8:
+            raise ValueError("mode='cls' supports at most 8 labels (lr2_cls_head_fwd)")
+        self.head = nn.Linear(FEAT, self.n_out)
         self._P_cache: Optional[Dict[str, torch.Tensor]] = None
         self._ws: Optional[engine.Workspace] = None
         self._wp: Optional[engine.WeightPlanes] = None
@@ -267,8 +271,8 @@ class _Head(nn.Module):
 
 
 class Actor(_Head):
-    """finetune/ppo.py:196-244 (mode 'reg'): forward(text_emb, img_emb, tgts) -> (SmoothL1 loss, logits[bs*tags])
-    or logits when tgts is None."""
+    """finetune/ppo.py:196-244: forward(text_emb, img_emb, tgts) -> (loss, logits) or logits when tgts is None.
+    mode 'reg': logits [bs*tags], SmoothL1(beta = 0.3); mode 'cls': logits [bs*tags, labels_num], NLL of log-softmax."""
 
     def forward(self, text_emb, img_emb, tgts=None):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -277,6 +281,8 @@ class Actor(_Head):
             logits = self.engine_forward(text_emb, img_emb, save=False)
         if tgts is None:
             return logits
+        if self.mode == "cls":
+            return _NllFn.apply(logits, tgts.reshape(-1).to(torch.int64).contiguous()), logits
         return _SmoothL1Fn.apply(logits, tgts.reshape(-1).to(torch.float32).contiguous()), logits
 
     def engine_forward(self, text_emb, img_emb, *, save: bool) -> torch.Tensor:
@@ -285,8 +291,12 @@ class Actor(_Head):
         W = self._weights(P)
         drop = self._drop_cfg(0)
         g2 = engine.trunk_forward(ws, P, W, text2, img2, bs, tags, n_img, FEAT, save=save, drop=drop, img_shared=shared)
-        logits = torch.empty(bs * tags, device=text_emb.device)
-        ops.head_fwd(g2, P["head.weight"], P["head.bias"], logits, rows=bs * tags, D=FEAT)
+        if self.n_out == 1:
+            logits = torch.empty(bs * tags, device=text_emb.device)
+            ops.head_fwd(g2, P["head.weight"], P["head.bias"], logits, rows=bs * tags, D=FEAT)
+        else:
+            logits = torch.empty(bs * tags, self.n_out, device=text_emb.device)
+            ops.cls_head_fwd(g2, P["head.weight"], P["head.bias"], logits, rows=bs * tags, D=FEAT, C=self.n_out)
         if save:
             self._saved = (text2, img2, bs, tags, n_img, shared, drop)
         return logits
@@ -299,10 +309,24 @@ class Actor(_Head):
         N = bs * tags
         g2 = ws.mat("g2", N, FEAT)
         dg2 = ws.mat("dg2", N, FEAT)
-        ops.head_bwd(g2, P["head.weight"], dlogits.contiguous().view(-1), dg2, G["head.weight"], G["head.bias"], rows=N, D=FEAT)
+        if self.n_out == 1:
+            ops.head_bwd(g2, P["head.weight"], dlogits.contiguous().view(-1), dg2, G["head.weight"], G["head.bias"], rows=N, D=FEAT)
+        else:
+            ops.cls_head_bwd(g2, P["head.weight"], dlogits.contiguous().view(N, self.n_out), dg2, G["head.weight"], G["head.bias"],
+                             rows=N, D=FEAT, C=self.n_out)
         engine.trunk_backward(ws, P, W, G, text2, img2, dg2, bs, tags, n_img, FEAT, drop=drop, img_shared=shared, dp=dp,
                               fc1_update=fc1_update)
         self._saved = None
+
+    def action_scores(self, logits: torch.Tensor, bs: int, tags: int, want_probs: bool = False):
+        """The per-tag score the PPO loop ranks by: the logit itself ('reg'), or the expected label under softmax(logits)
+        ('cls', finetune/ppo.py:532-537,859-863) -> (scores [bs, tags], probs [bs*tags, C] or None)."""
+        if self.n_out == 1:
+            return logits.view(bs, tags), None
+        scores = torch.empty(bs * tags, device=logits.device)
+        probs = torch.empty(bs * tags, self.n_out, device=logits.device) if want_probs else None
+        ops.cls_scores(logits, probs, scores, rows=bs * tags, C=self.n_out, softmax=True)
+        return scores.view(bs, tags), probs
 
 
 class _TailHead(_Head):
@@ -436,6 +460,22 @@ class _SmoothL1Fn(torch.autograd.Function):
         return (ctx.dpred * dloss if ctx.dpred is not None else None), None
 
 
+class _NllFn(torch.autograd.Function):
+    """nn.NLLLoss()(nn.LogSoftmax(dim=-1)(logits), tgts) of finetune/ppo.py:239-241 (mean), differentiable w.r.t. the logits."""
+
+    @staticmethod
+    def forward(ctx, logits, targets):
+        loss = torch.empty(1, device=logits.device)
+        dl = torch.empty_like(logits) if logits.requires_grad else None
+        ops.nll_loss(logits.detach().contiguous(), targets, loss, dl, rows=logits.shape[0], C=logits.shape[1])
+        ctx.dl = dl
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        return (ctx.dl * dloss if ctx.dl is not None else None), None
+
+
 class _ActorFn(torch.autograd.Function):
     """Autograd entry of the drop-in nn.Module path: `loss.backward()` works as with the reference."""
 
@@ -528,7 +568,7 @@ def rollout_step(model, reward_model, text_emb, img_emb, tgts, state=None):
         state = torch.arange(tags, device=dev).unsqueeze(0).repeat(bs, 1)
     logits = model.actor.engine_forward(text_emb, img_emb, save=False)
     value = model.critic.engine_forward(text_emb, img_emb, state, save=False)
-    scores = logits.view(bs, tags)
+    scores, _ = model.actor.action_scores(logits, bs, tags)
     _, order = torch.sort(scores, dim=-1, descending=True)
     next_state = torch.cat([torch.arange(2, device=dev).unsqueeze(0).repeat(bs, 1), torch.gather(state, 1, order)], dim=1)
     rewards = reward_model.engine_forward(text_emb, img_emb, next_state, save=False)
@@ -611,8 +651,8 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
     value = critic.engine_forward(text, img, state, save=True)
     loss_kw = dict(B=bs, T=tags, kl_w=args.kl_div_loss_weight, ent_w=args.entropy_weight, value_clip=args.value_clip,
                    margin=0.01, adv_eps=-0.1)
-    loss_in = (logits.view(bs, tags), old_scores.contiguous(), rewards.contiguous(), old_value.contiguous(), value,
-               next_state.contiguous())
+    scores, probs = actor.action_scores(logits, bs, tags, want_probs=True)
+    loss_in = (scores, old_scores.contiguous(), rewards.contiguous(), old_value.contiguous(), value, next_state.contiguous())
     if dp.world > 1 and getattr(args, "global_rank_loss", True):
         # RankLoss is one scalar over the whole batch (finetune/ppo.py:43-55): with the batch sharded over ranks its hinge
         # sum / positive count (and mean |A|, which multiplies it) must be global before R is formed, or the rank-averaged
@@ -629,6 +669,9 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
         and hasattr(critic_optim, "external_update")
     fa = optimizer.external_update(actor.out_layer.fc1.weight) if fuse else None
     fc = critic_optim.external_update(critic.out_layer.fc1.weight) if fuse else None
+    if probs is not None:        # 'cls': chain d loss / d scores through the expected-label softmax to the class logits
+        dscores = ops.cls_scores_bwd(probs, scores.view(-1), dscores.view(-1), torch.empty_like(probs), rows=bs * tags,
+                                     C=actor.n_out)
     actor.engine_backward(dscores, dp, fc1_update=fa)
     wa = dp.reduce_start(actor)            # overlaps the critic's backward
     critic.engine_backward(dvalue, dp, fc1_update=fc)
@@ -675,7 +718,11 @@ def evaluate(args, val_loader, step, split="test", num_tasks=None):
     for text_emb, img_emb, tgts in val_loader:
         text_emb = text_emb.to(args.device)
         img_emb = img_emb.to(args.device)            # [1, n_img, 768]: shared by all tags of the item
-        scores.append(args.model.actor.engine_forward(text_emb, img_emb, save=False).view(-1))
+        logits = args.model.actor.engine_forward(text_emb, img_emb, save=False)
+        if args.model.actor.n_out > 1:               # 'cls': 0 * z0 + 1 * z1 + 2 * z2 on the RAW logits, as upstream (ppo.py:641-643)
+            logits = ops.cls_scores(logits, None, torch.empty(logits.shape[0], device=logits.device), rows=logits.shape[0],
+                                    C=logits.shape[1], softmax=False)
+        scores.append(logits.view(-1))
         golds.append(tgts.view(-1))
     # scores never leave the device: one batched NDCG kernel over the whole split (lr2_ndcg: sort by score, gain 2^rel - 1,
     # discount log2(i + 2), ideal DCG <= 1e-6 -> 1) and ONE device-to-host copy of the [items, 6] result -- the reference

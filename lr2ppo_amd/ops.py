@@ -527,6 +527,43 @@ def ppo_loss(scores, old_scores, rewards, old_value, value, next_state, scalars,
                                  _ptr(stats_out), _ptr(global_stats), world, _stream()), "lr2_ppo_loss")
 
 
+def cls_head_fwd(x, w, b, y, *, rows, D, C):
+    _chk_f32(x, w, b, y)
+    _nat.check(_nat.lib().lr2_cls_head_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), rows, D, C, _stream()),
+               "lr2_cls_head_fwd")
+    return y
+
+
+def cls_head_bwd(x, w, dy, dx, dw, db, *, rows, D, C):
+    _chk_f32(x, w, dy, dx, dw, db)
+    _nat.check(_nat.lib().lr2_cls_head_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _ptr(dx), _ptr(dw), _ptr(db), rows, D, C,
+                                           _stream()), "lr2_cls_head_bwd")
+
+
+def cls_scores(logits, probs, scores, *, rows, C, softmax=True):
+    """scores[r] = sum_k k * (softmax(logits[r]) if softmax else logits[r])_k; probs (optional) receives the distribution."""
+    _chk_f32(logits, probs, scores)
+    _nat.check(_nat.lib().lr2_cls_scores(logits.data_ptr(), _ptr(probs), scores.data_ptr(), rows, C, 1 if softmax else 0,
+                                         _stream()), "lr2_cls_scores")
+    return scores
+
+
+def cls_scores_bwd(probs, scores, dscores, dlogits, *, rows, C):
+    _chk_f32(probs, scores, dscores, dlogits)
+    _nat.check(_nat.lib().lr2_cls_scores_bwd(probs.data_ptr(), scores.data_ptr(), dscores.data_ptr(), dlogits.data_ptr(), rows,
+                                             C, _stream()), "lr2_cls_scores_bwd")
+    return dlogits
+
+
+def nll_loss(logits, tgts, loss, dlogits=None, *, rows, C):
+    _chk_f32(logits, loss, dlogits)
+    if tgts.dtype != torch.int64:
+        raise TypeError("tgts must be int64")
+    _nat.check(_nat.lib().lr2_nll_loss(logits.data_ptr(), tgts.data_ptr(), rows, C, loss.data_ptr(), _ptr(dlogits), _stream()),
+               "lr2_nll_loss")
+    return loss
+
+
 def smooth_l1(pred, target, loss, dpred=None, *, n, beta=0.3):
     _chk_f32(pred, target, loss, dpred)
     _nat.check(_nat.lib().lr2_smooth_l1(pred.data_ptr(), target.data_ptr(), n, beta, loss.data_ptr(), _ptr(dpred), _stream()),

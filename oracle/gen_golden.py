@@ -329,6 +329,57 @@ def gen_train_step():
     _save("train_step.npz", **arrays)
 
 
+def gen_cls():
+    """mode = 'cls' (finetune/ppo.py:209-210,229-242,532-537,641-643,859-863): the 3-way actor head, its NLL loss, the
+    expected-label scores of the rollout, and one train_model cycle (lr one scheduler step past 0) with the 10 returned
+    metrics, sampled actor gradients and post-step weights."""
+    import ppo
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    bs, tags = 2, 2
+    args = _ns(**{**HEAD_ARGS, "mode": "cls"}, is_master=False, kl_div_loss_weight=0.001, entropy_weight=0.001, value_clip=0.5,
+               optimizer="adamw", scheduler="linear", learning_rate=1e-3, critic_learning_rate=1e-3,
+               train_steps=41, warmup=0.1, device=torch.device("cpu"))
+    model = ppo.ActorCritic(args, None)
+    spec = [(n, tuple(p.shape)) for n, p in model.actor.named_parameters()]
+    assert spec == O.head_param_spec("actor", n_out=3)
+    _load(model.actor, O.seeded_params(O.head_param_spec("actor", n_out=3), seed=17))
+    _load(model.critic, O.seeded_params(O.head_param_spec("critic"), seed=18))
+    reward = _load(ppo.Reward(args, None).eval(), O.seeded_params(O.head_param_spec("reward"), seed=19))
+    opt, copt, sch, csch = ppo.build_optimizer(args, model)
+    sch.step(), csch.step()                 # leave the lr-0 first position
+    model.eval()
+    arrays = {"bs": np.array(bs), "tags": np.array(tags), "lr": np.array([opt.param_groups[0]["lr"], copt.param_groups[0]["lr"]])}
+    text, img, tgts = O.seeded_head_inputs(2000, bs, tags)
+    with torch.no_grad():
+        state = torch.arange(tags).unsqueeze(0).repeat(bs, 1)
+        loss, logits = model.actor(text, img, tgts)
+        value = model.critic(text, img, tgts, state)
+        p = logits.view(bs, tags, 3).softmax(dim=-1)
+        scores = p[:, :, 0] * 0 + p[:, :, 1] * 1 + p[:, :, 2] * 2
+        nxt = O.rollout_next_state(scores, state)
+        r = reward(text, img, tgts, nxt)
+        raw = logits.view(-1, 3)
+        arrays["eval_scores"] = raw[:, 0] * 0 + raw[:, 1] * 1 + raw[:, 2] * 2
+    arrays.update(logits=logits.clone(), nll=loss.clone(), scores=scores.clone(), value=value.clone(), reward=r.clone(),
+                  next_state=nxt.clone())
+    memories = [[state.clone(), nxt.clone(), scores.clone(), r.clone(), value.clone(), text.clone(), img.clone(), tgts.clone()]]
+    out = ppo.train_model(args, model, opt, copt, sch, csch, memories, 1)
+    arrays["metrics"] = torch.stack([torch.as_tensor(float(x)) for x in out])
+    named = dict(model.named_parameters())
+    names = ["actor.head.weight", "actor.head.bias", "actor.text_proj.fc1.weight", "actor.out_layer.fc2.weight",
+             "actor.xit.0.0.1.fn.1.3.weight", "actor.out_layer.fc1.weight"]
+    gi = torch.Generator().manual_seed(78)
+    for n in names:
+        idx = torch.randint(0, named[n].numel(), (min(64, named[n].numel()),), generator=gi)
+        arrays["idx." + n] = idx
+        arrays["g." + n] = named[n].grad.detach().flatten()[idx].clone()
+        arrays["w." + n] = named[n].detach().flatten()[idx].clone()
+    _save("cls_step.npz", **arrays)
+
+
 def _sampled(named, names, seed):
     gi = torch.Generator().manual_seed(seed)
     return {n: torch.randint(0, named[n].numel(), (64,), generator=gi) for n in names}
@@ -763,7 +814,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -54,7 +54,7 @@ def _xit_spec(prefix: str, d: int):
     return out
 
 
-def head_param_spec(kind: str, seq_length: int = SEQ_LEN, max_imgs: int = 16, feat: int = FEAT):
+def head_param_spec(kind: str, seq_length: int = SEQ_LEN, max_imgs: int = 16, feat: int = FEAT, n_out: int = 1):
     """(name, shape) list for ``kind`` in {"actor", "critic", "reward"}.
 
     Order follows module declaration order in finetune/ppo.py:196-212 (Actor) and
@@ -68,7 +68,7 @@ def head_param_spec(kind: str, seq_length: int = SEQ_LEN, max_imgs: int = 16, fe
     if kind in ("critic", "reward"):
         spec += _xit_spec("xitt", d)
     spec += _mlp_spec("out_layer", (seq_length + max_imgs) * d, 4 * d, d)
-    spec += [("head.weight", (1, d)), ("head.bias", (1,))]
+    spec += [("head.weight", (n_out, d)), ("head.bias", (n_out,))]     # n_out = labels_num for the 'cls' actor (ppo.py:209-210)
     return spec
 
 
@@ -218,6 +218,27 @@ def actor_forward(P: Params, text_emb, img_emb, tgts=None, drop=None):
         return logits
     loss = smooth_l1(logits, tgts.reshape(-1).to(logits.dtype))
     return loss, logits
+
+
+def actor_forward_cls(P: Params, text_emb, img_emb, tgts=None, drop=None):
+    """Actor.forward, mode 'cls' (finetune/ppo.py:214-244): logits [bs*tags, labels_num]; with targets the mean NLL of
+    log-softmax (:239-241)."""
+    x = trunk(P, text_emb, img_emb, drop)
+    logits = linear(P, "head", x).reshape(-1, P["head.weight"].shape[0])
+    if tgts is None:
+        return logits
+    lz = torch.log_softmax(logits, dim=-1)
+    loss = -lz[torch.arange(logits.shape[0]), tgts.reshape(-1)].mean()
+    return loss, logits
+
+
+def cls_action_scores(logits: torch.Tensor, bs: int, tags: int, softmax: bool = True) -> torch.Tensor:
+    """The score the PPO loop ranks by in mode 'cls': sum_k k * softmax(logits)_k (finetune/ppo.py:532-537,859-863);
+    evaluate() applies the same weights to the RAW logits (:641-643) -> softmax=False."""
+    z = logits.view(bs, tags, -1)
+    p = z.softmax(dim=-1) if softmax else z
+    k = torch.arange(p.shape[-1], dtype=p.dtype)
+    return (p * k).sum(-1)
 
 
 def critic_forward(P: Params, text_emb, img_emb, index, n_pos: Optional[int] = None, drop=None):

@@ -369,3 +369,35 @@ def test_dual_embedding_and_encoder_oracle_match_reference(tag):
     for k, v in Pn.items():
         ref = g[f"{tag}_ngrad.{k}"]
         assert (v.grad - ref).abs().max() < 5e-5 * max(1.0, float(ref.abs().max())), k
+
+
+@pytest.mark.slow
+def test_cls_mode_oracle_matches_reference():
+    """mode = 'cls': 3-way actor head, NLL loss, expected-label scores (rollout: softmax; evaluate: raw logits), rollout glue
+    and the update's loss / gradients against the reference's own run (tests/golden/cls_step.npz)."""
+    g = load_golden("cls_step.npz")
+    bs, tags = int(g["bs"]), int(g["tags"])
+    Pa = O.seeded_params(O.head_param_spec("actor", n_out=3), seed=17)
+    text, img, tgts = O.seeded_head_inputs(2000, bs, tags)
+    state = torch.arange(tags).unsqueeze(0).repeat(bs, 1)
+    with torch.no_grad():
+        loss, logits = O.actor_forward_cls(Pa, text, img, tgts)
+        scores = O.cls_action_scores(logits, bs, tags)
+        nxt = O.rollout_next_state(scores, state)
+    # (critic / reward are the 'reg'-mode functions, pinned by head_fwd.npz / train_step.npz; their fixture values are used)
+    assert (logits - g["logits"]).abs().max() < 2e-5 and abs(float(loss) - float(g["nll"])) < 1e-5
+    assert (scores - g["scores"]).abs().max() < 1e-5 and torch.equal(nxt, g["next_state"])
+    assert (O.cls_action_scores(logits, bs * tags, 1, softmax=False).view(-1) - g["eval_scores"]).abs().max() < 2e-5
+    Pg = {k: v.clone().requires_grad_(True) for k, v in Pa.items()}
+    new_logits = O.actor_forward_cls(Pg, text, img, None)
+    new_scores = O.cls_action_scores(new_logits, bs, tags)
+    new_value = g["value"]              # the critic is unchanged between the rollout and the update's forward (eval mode)
+    pl, vl, ex = O.ppo_update_math(new_scores, new_value, g["scores"], g["reward"], g["value"], g["next_state"], 0.001, 0.001, 0.5)
+    pl.backward()
+    m = g["metrics"]
+    assert abs(float(pl) - float(m[0])) < 1e-5 and abs(float(vl) - float(m[1])) < 1e-5 and abs(float(ex["rank_loss"]) - float(m[8])) < 1e-5
+    for key in [k for k in g if k.startswith("g.actor.")]:
+        n = key[len("g.actor."):]
+        ref = g[key]
+        got = Pg[n].grad.flatten()[g["idx.actor." + n]]
+        assert (got - ref).abs().max() < 1e-6 + 2e-4 * float(ref.abs().max()), n

@@ -424,3 +424,55 @@ def test_vit_l14_config_forward_matches_oracle(dev):
     with pytest.raises(Exception, match="256"):                 # the training path still needs one LDS-resident key block
         stack.train()
         stack(img.to(dev).requires_grad_(True), seg.to(dev)).sum().backward()
+
+
+# ---- mode = 'cls' (finetune/ppo.py:209-210,229-242,532-537,641-643,859-863) -----------------------------------------------------
+def test_cls_mode_rollout_and_update_match_reference(dev):
+    """The 3-way classification actor: logits, NLL loss, expected-label scores, the rollout record, the 10 metrics of one
+    train_model cycle, sampled actor gradients and post-step weights against the reference's own run (cls_step.npz)."""
+    import argparse
+    from lr2ppo_amd.finetune import ppo
+    g = load_golden("cls_step.npz")
+    bs, tags = int(g["bs"]), int(g["tags"])
+    args = argparse.Namespace(mode="cls", labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768, is_master=False,
+                              kl_div_loss_weight=0.001, entropy_weight=0.001, value_clip=0.5, optimizer="adamw", scheduler="linear",
+                              learning_rate=1e-3, critic_learning_rate=1e-3, train_steps=41, warmup=0.1, device=dev,
+                              fuse_fc1_update=False)
+    model = ppo.ActorCritic(args, None)
+    assert [(n, tuple(p.shape)) for n, p in model.actor.named_parameters()] == O.head_param_spec("actor", n_out=3)
+    model.actor.load_state_dict(O.seeded_params(O.head_param_spec("actor", n_out=3), seed=17), strict=True)
+    model.critic.load_state_dict(O.seeded_params(O.head_param_spec("critic"), seed=18), strict=True)
+    reward = ppo.Reward(args, None)
+    reward.load_state_dict(O.seeded_params(O.head_param_spec("reward"), seed=19), strict=True)
+    model, reward = model.to(dev).eval(), reward.to(dev).eval()
+    opt, copt, sch, csch = ppo.build_optimizer(args, model)
+    sch.step(), csch.step()
+    assert abs(opt.param_groups[0]["lr"] - float(g["lr"][0])) < 1e-12
+    text, img, tgts = O.seeded_head_inputs(2000, bs, tags)
+    with torch.no_grad():
+        loss, logits = model.actor(text.to(dev), img.to(dev), tgts.to(dev))
+    assert logits.shape == (bs * tags, 3)
+    assert _err(logits, g["logits"]) < 1e-4 and abs(float(loss) - float(g["nll"])) < 1e-4
+    rec = ppo.rollout_step(model, reward, text.to(dev), img.to(dev), tgts.to(dev))
+    assert _err(rec[2], g["scores"]) < 1e-4 and _err(rec[4], g["value"]) < 1e-4 and _err(rec[3], g["reward"]) < 1e-4
+    assert torch.equal(rec[1].cpu(), g["next_state"])
+    # evaluate()'s raw-logit scores
+    from lr2ppo_amd import ops
+    ev = ops.cls_scores(logits, None, torch.empty(bs * tags, device=dev), rows=bs * tags, C=3, softmax=False)
+    assert _err(ev, g["eval_scores"]) < 1e-4
+    out = ppo.train_model(args, model, opt, copt, sch, csch, [rec], 1)
+    for i, (a, b) in enumerate(zip(out, g["metrics"].tolist())):
+        assert abs(a - b) < 1e-4, f"metric {i}: {a} vs {b}"
+    named = dict(model.named_parameters())
+    for key in [k for k in g if k.startswith("g.")]:
+        n = key[2:]
+        idx = g["idx." + n].to(dev)
+        ref = g[key]
+        got = named[n].grad.detach().flatten()[idx]
+        assert _err(got, ref) < 1e-6 + 2e-3 * float(ref.abs().max()), f"grad {n}"
+        assert _err(named[n].detach().flatten()[idx], g["w." + n]) < 2e-6, f"weights {n}"
+    # NLL through autograd (the drop-in nn.Module path): gradient of the loss w.r.t. the head
+    model.zero_grad()
+    loss2, _ = model.actor(text.to(dev), img.to(dev), tgts.to(dev))
+    loss2.backward()
+    assert model.actor.head.weight.grad is not None and model.actor.head.weight.grad.abs().sum() > 0
