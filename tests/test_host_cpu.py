@@ -146,8 +146,9 @@ def test_no_cpu_fallback_and_bad_arguments_are_errors(native, small_models):
     actor = small_models["actor"]
     with pytest.raises(TypeError):
         actor(torch.zeros(1, 2, 196, 768), torch.zeros(1, 2, 1, 768), None)     # CPU tensors: refuse, don't emulate
-    with pytest.raises(NotImplementedError):
-        ppo.Actor(argparse.Namespace(**{**ARGS, "mode": "cls"}), None)
+    with pytest.raises(ValueError):
+        ppo.Actor(argparse.Namespace(**{**ARGS, "mode": "rank"}), None)          # 'reg' and 'cls' only (ppo.py:209-212)
+    assert ppo.Actor(argparse.Namespace(**{**ARGS, "mode": "cls"}), None).n_out == 3
     with pytest.raises(ValueError):
         ppo.Actor(argparse.Namespace(**{**ARGS, "seq_length": 128}), None)
     # the C entry points validate before launching anything (no GPU is touched by a rejected call)
