@@ -253,7 +253,8 @@ def main():
         enc_ms = ev0.elapsed_time(ev1) / iters
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
         import encoder_bench
-        fl = encoder_bench.flops(a.batch * 16, 197) + encoder_bench.flops(a.batch * a.tags, 196) + 2.0 * a.batch * 16 * 196 * 768 * 768
+        fl = (encoder_bench.flops(a.batch * 16, 197, first_token_only=True) + encoder_bench.flops(a.batch * a.tags, 196)
+              + 2.0 * a.batch * 16 * 196 * 768 * 768)
         out["config"]["with_online_feature_extraction"] = {
             "ms_per_step": round(dt2 / a.steps * 1e3, 3), "steps_per_sec": round(a.steps / dt2, 3), "measured": True,
             "steps": a.steps,
@@ -262,7 +263,9 @@ def main():
         out["config"]["dual_encoder_forward"] = {
             "ms": round(enc_ms, 3), "algorithmic_tflop": round(fl / 1e12, 2), "tflops": round(fl / enc_ms / 1e9, 1),
             "mfma_issue_frac": round(a.passes * fl / enc_ms / 1e9 / MFMA_BF16_PEAK_TF, 4), "passes": a.passes,
-            "includes": "uint8 normalise + patchify + patch projection, token embedding, 2 x 12 encoder layers, pooling"}
+            "includes": "uint8 normalise + patchify + patch projection, token embedding, 2 x 12 encoder layers, pooling; the image "
+                        "stack's last layer is evaluated for the pooled [CLS] row only (keys / values for all rows) and "
+                        "algorithmic_tflop counts it that way"}
         del fx, raw
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample (one untimed warm-up step
     # that allocates the Adam state, then the measured step(s) at the benchmark batch -- no extrapolation) ----

@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 11
+#define LR2_ABI_VERSION 12
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -166,6 +166,18 @@ int lr2_self_attn_fwd(const void* q_hi, const void* k_hi, const void* v_hi, uint
                       uint32_t drop_site, int batch, int heads, int L, int head_dim, float scale, void* stream);
 /* (above) lse: optional fp32 [batch, heads, L] log-sum-exp of the masked scores; drop_p > 0 applies the counter-based
  * dropout to the probabilities (element index ((b*heads + h)*L + q)*L + key, multi_headed_attn.py:72). */
+
+/* Self-attention for the FIRST query row of every sequence only: o[b, h*64 + d] = sum_j softmax_j(q[b] . K[b*L + j] * scale +
+ * (seg>0 ? 0 : -10000)) V[b*L + j] -- what pooling 'first' keeps of the last encoder layer (the [CLS] feature of the image
+ * encoder), so that layer's output projection and feed-forward run on `batch` rows instead of batch*L.
+ * q fp32 [batch, ld_q] (already projected, bias included); k_hi / v_hi bf16 hi planes of K and V over ALL rows, element
+ * (row, h*64 + d) at ptr[row*ld + h*64 + d], lo plane lo_off ELEMENTS behind; seg int64 [batch*L]; o fp32 [batch, ld_o];
+ * L <= 4096, head_dim == 64.
+ * replaces: tencentpretrain/layers/multi_headed_attn.py:61-74 restricted to query 0 (utils/misc.py:23-35 'first' pooling,
+ * as consumed at finetune/ppo.py:120-127). */
+int lr2_first_token_attn(const void* q, int ld_q, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld,
+                         const int64_t* seg, void* o, int ld_o, int batch, int heads, int L, int head_dim, float scale,
+                         void* stream);
 
 /* Backward of lr2_self_attn_fwd: from Q, K, V planes and dO planes (same layout rules) to dQ, dK, dV planes
  * (dq_hi / dk_hi / dv_hi: hi planes, element (row, h*64 + d) at ptr[row*ld_d + h*64 + d], lo plane d_lo_off elements behind --

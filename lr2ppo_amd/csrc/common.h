@@ -130,6 +130,7 @@ struct Epilogue {
   float* adam_m;
   float* adam_v;
   float adam_lr, adam_b1, adam_b2, adam_ob1, adam_ob2, adam_eps, adam_wd;
+  int stream_nt;         // optimizer state p / m / v: non-temporal loads and stores (each byte is touched once per launch)
 };
 
 // One AdamW element update, TencentPretrain semantics (correct_bias=False; eps outside the sqrt; decay after the

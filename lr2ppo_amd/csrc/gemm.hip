@@ -642,6 +642,7 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   splits = (total_k_tiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
   p.partial = (splits > 1 || (ablate & 32)) ? (float*)splitk_ws : nullptr;
   p.epi = to_device_epilogue(epi);
+  p.epi.stream_nt = (ablate & 64) ? 0 : 1;   // fused AdamW: +2-3 % on the 12-GB p / m / v stream (A/B with LR2_GEMM_ABLATE=64)
   p.ablate = ablate;
   // 128 x 128 planes tiles, NT / NN: 8-wave workgroups (two workgroups per CU = 4 waves per SIMD) overlap the MFMA issue,
   // the LDS-DMA issue and the fragment waits of different waves: +5..21 % over 4 waves (tools/gemm_bench.py); TN: equal.

@@ -66,6 +66,13 @@ __device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int bid, i
 // row segment of WN*4 bytes is contiguous across 16 (WN = 64) or 8 (WN = 32) lanes.
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+  const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+  __builtin_nontemporal_store(f32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_t*>(p));
+}
 
 // The epilogue is split into "request everything this element needs from HBM" and "combine + store", so that a caller can
 // issue the loads of all its elements before the first store: on CDNA loads and stores share one in-order counter
@@ -84,9 +91,15 @@ __device__ __forceinline__ void epilogue_load4(const Epilogue& e, EpiLoads<NS>& 
   if (e.resid) L.s[SR] = ld4(e.resid + (size_t)m * e.ld_resid + n);
   if (NS == 3 && e.adam_p) {
     const size_t off = (size_t)m * e.ld_out + n;
-    L.s[0] = ld4(e.adam_p + off);
-    L.s[SR] = ld4(e.adam_m + off);
-    L.s[SO] = ld4(e.adam_v + off);
+    if (e.stream_nt) {
+      L.s[0] = ld4_nt(e.adam_p + off);
+      L.s[SR] = ld4_nt(e.adam_m + off);
+      L.s[SO] = ld4_nt(e.adam_v + off);
+    } else {
+      L.s[0] = ld4(e.adam_p + off);
+      L.s[SR] = ld4(e.adam_m + off);
+      L.s[SO] = ld4(e.adam_v + off);
+    }
   } else if (e.out && e.accumulate) {
     L.s[SO] = ld4(e.out + (size_t)m * e.ld_out + n);
   }
@@ -119,7 +132,8 @@ __device__ __forceinline__ void epilogue_apply4(const Epilogue& e, float4 v, flo
     adam_update(p.y, v.y, mm.y, vv.y, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
     adam_update(p.z, v.z, mm.z, vv.z, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
     adam_update(p.w, v.w, mm.w, vv.w, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
-    st4(e.adam_p + off, p); st4(e.adam_m + off, mm); st4(e.adam_v + off, vv);
+    if (e.stream_nt) { st4_nt(e.adam_p + off, p); st4_nt(e.adam_m + off, mm); st4_nt(e.adam_v + off, vv); }
+    else { st4(e.adam_p + off, p); st4(e.adam_m + off, mm); st4(e.adam_v + off, vv); }
     return;
   }
   if (e.out) {

@@ -893,6 +893,77 @@ LR2_SA_INST(8)
 LR2_SA_INST(14)
 LR2_SA_INST(16)
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention for the FIRST query of every sequence only (the [CLS] row): what pooling 'first' (utils/misc.py:23-35 upstream)
+// keeps of the last encoder layer.  One workgroup per (sequence, head): scores of the one query against all L keys,
+// fp32 softmax with the same additive key mask and the same exp as the full kernels, then P V.  K / V rows are read as
+// whole 128-B hi and lo rows (bf16 planes, x = hi + lo).  ~0.2 % of the full layer's attention work: a vector kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int FT_THREADS = 256;
+constexpr int FT_MAXL = 4096;
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__global__ __launch_bounds__(FT_THREADS) void first_token_attn_kernel(const float* __restrict__ q, int ld_q,
+                                                                       const bf16_t* __restrict__ k_hi,
+                                                                       const bf16_t* __restrict__ v_hi, size_t lo_off, int ld,
+                                                                       const int64_t* __restrict__ seg, float* __restrict__ o,
+                                                                       int ld_o, int heads, int L, float scale) {
+  __shared__ float sq[HD];
+  __shared__ float sp[FT_MAXL];
+  __shared__ float red[FT_THREADS / 64];
+  __shared__ float so[FT_THREADS / 64][HD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const size_t row0 = (size_t)b * L;
+  if (tid < HD) sq[tid] = q[(size_t)b * ld_q + h * HD + tid];
+  __syncthreads();
+  // scores: one key per thread and sweep
+  float mx = -INFINITY;
+  for (int j = tid; j < L; j += FT_THREADS) {
+    const bf16_t* kr = k_hi + (row0 + j) * (size_t)ld + h * HD;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+      const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(kr + c * 8);
+      const u32x4_t lv = *reinterpret_cast<const u32x4_t*>(kr + lo_off + c * 8);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        acc = __builtin_fmaf(sq[c * 8 + 2 * w], bf_lo(hv[w]) + bf_lo(lv[w]), acc);
+        acc = __builtin_fmaf(sq[c * 8 + 2 * w + 1], bf_hi(hv[w]) + bf_hi(lv[w]), acc);
+      }
+    }
+    const float sc = acc * scale + ((seg[row0 + j] > 0) ? 0.f : -10000.0f);
+    sp[j] = sc;
+    mx = fmaxf(mx, sc);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int j = tid; j < L; j += FT_THREADS) {
+    const float e = exp_fast(sp[j] - mx);
+    sp[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = (red[0] + red[1]) + (red[2] + red[3]);
+  // O = P V: lane = head column, each wave a quarter of the keys (coalesced 128-B rows)
+  float acc = 0.f;
+  for (int j = wave; j < L; j += FT_THREADS / 64) {
+    const bf16_t* vr = v_hi + (row0 + j) * (size_t)ld + h * HD + lane;
+    acc = __builtin_fmaf(sp[j], bf2f(vr[0]) + bf2f(vr[lo_off]), acc);
+  }
+  so[wave][lane] = acc;
+  __syncthreads();
+  if (tid < HD) o[(size_t)b * ld_o + h * HD + tid] = ((so[0][tid] + so[1][tid]) + (so[2][tid] + so[3][tid])) / sum;
+}
+
 }  // namespace
 
 #define LR2_SA_DISPATCH(L, CALL)  \
@@ -933,4 +1004,14 @@ extern "C" int lr2_self_attn_bwd(const void* q_hi, const void* k_hi, const void*
                  (size_t)d_lo_off, ld_d, (float*)lse_ws, (float*)dsum_ws)
   LR2_SA_DISPATCH(L, CALL)
 #undef CALL
+}
+
+extern "C" int lr2_first_token_attn(const void* q, int ld_q, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld,
+                                    const int64_t* seg, void* o, int ld_o, int batch, int heads, int L, int head_dim,
+                                    float scale, void* stream) {
+  if (!q || !k_hi || !v_hi || !seg || !o || batch <= 0 || heads <= 0) return LR2_ERR_ARG;
+  if (head_dim != HD || L < 1 || L > FT_MAXL || ld % 8 || lo_off % 8) return LR2_ERR_SHAPE;
+  LR2_LAUNCH(first_token_attn_kernel, dim3(batch * heads), dim3(FT_THREADS), 0, (hipStream_t)stream, (const float*)q, ld_q,
+             (const bf16_t*)k_hi, (const bf16_t*)v_hi, (size_t)lo_off, ld, seg, (float*)o, ld_o, heads, L, scale);
+  return lr2_launch_status(__func__);
 }

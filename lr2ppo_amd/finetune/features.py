@@ -63,6 +63,10 @@ class EncoderStack(nn.Module):
     def forward(self, src, seg):
         return self.encoder(self.embedding(src, seg), seg)
 
+    def forward_first_token(self, src, seg):
+        """encoder output at token 0 only, [batch, hidden] (TransformerEncoder.forward_first_token)."""
+        return self.encoder.forward_first_token(self.embedding(src, seg), seg)
+
 
 class FeatureExtractor(nn.Module):
     """ViT-B/16 over the frames of an item and RoBERTa-base over its tags' token sequences (module docstring).
@@ -102,9 +106,10 @@ class FeatureExtractor(nn.Module):
         flat = frames.reshape(B * n_img, *frames.shape[2:])
         L = self.vit_args.max_seq_length
         seg = torch.ones(B * n_img, L, dtype=torch.int64, device=frames.device)
-        h = self.image(flat, seg)
-        # pooling(h, seg, "first") of utils/misc.py:23-35 = (h * seg)[:, 0, :]; only token 0 is multiplied here (same bits)
-        return (h[:, 0, :] * seg[:, :1].type_as(h)).reshape(B, n_img, -1)
+        # pooling(h, seg, "first") of utils/misc.py:23-35 = (h * seg)[:, 0, :]: only token 0 of the encoder output is consumed,
+        # so the last layer is evaluated for that token only (inference; bit-for-bit the full schedule's kernels on B rows)
+        h0 = self.image.forward_first_token(flat, seg)
+        return (h0 * seg[:, :1].type_as(h0)).reshape(B, n_img, -1)
 
     def text_features(self, ids: torch.Tensor, seg: Optional[torch.Tensor] = None) -> torch.Tensor:
         """ids [B, T, L] int64 (+ seg [B, T, L]; default all ones) -> text_emb [B, T, L, hidden]."""

@@ -435,6 +435,23 @@ def self_attn_fwd(qkv: "Planes", seg, o, *, batch, heads, L, head_dim, scale, ls
     return o
 
 
+def first_token_attn(q: torch.Tensor, kv: "Planes", seg, o: torch.Tensor, *, batch, heads, L, head_dim, scale):
+    """Attention of query row 0 of every sequence against all keys (lr2_first_token_attn).  q: fp32 [batch, E] (projected);
+    kv: Planes [batch*L, 2E] = [K | V]; seg: int64 [batch*L]; o: fp32 [batch, E]."""
+    E = heads * head_dim
+    if not isinstance(kv, Planes) or kv.cols != 2 * E or kv.rows != batch * L:
+        raise TypeError("first_token_attn: kv must be a Planes matrix [batch*L, 2*heads*head_dim]")
+    if seg.dtype != torch.int64:
+        raise TypeError("seg must be int64")
+    _chk_f32(q, o)
+    if q.shape != (batch, E) or o.shape != (batch, E) or not q.is_contiguous() or not o.is_contiguous():
+        raise ValueError("first_token_attn: q / o must be contiguous [batch, heads*head_dim]")
+    _nat.check(_nat.lib().lr2_first_token_attn(q.data_ptr(), E, kv.data_ptr(), kv.data_ptr() + 2 * E, kv.lo_off, 2 * E,
+                                               seg.data_ptr(), o.data_ptr(), E, batch, heads, L, head_dim, scale, _stream()),
+               "lr2_first_token_attn")
+    return o
+
+
 def self_attn_bwd(qkv: "Planes", do: "Planes", seg, dqkv: "Planes", lse_ws, dsum_ws, *, batch, heads, L, head_dim, scale,
                   drop: Optional[Drop] = None):
     """dQKV (Planes [batch*L, 3E]) from QKV and dO (Planes [batch*L, E]); lse_ws / dsum_ws: fp32 [batch*heads*L] scratch."""

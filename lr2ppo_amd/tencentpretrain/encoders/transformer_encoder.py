@@ -76,8 +76,20 @@ class TransformerEncoder(nn.Module):
             return out
         return self._forward_infer(emb, seg)
 
+    def forward_first_token(self, emb, seg):
+        """hidden[:, 0, :] of forward(emb, seg), [batch, hidden] -- for callers that pool with 'first' (utils/misc.py:23-35
+        upstream; the image encoder in front of the heads, finetune/ppo.py:120-127).  In inference the LAST layer then needs
+        its keys and values for every row but its query, output projection and feed-forward for row 0 only: 5/6 of that
+        layer's matrix work is never consumed and is not computed.  With gradients enabled: the full forward, sliced."""
+        needs_grad = torch.is_grad_enabled() and (emb.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if needs_grad or (self.training and any(l.dropout_1.p > 0 for l in self.transformer)):
+            return self.forward(emb, seg)[:, 0, :]
+        if emb.dtype != torch.float32 or not emb.is_cuda:
+            raise TypeError("lr2ppo_amd: emb must be a float32 tensor on the HIP device (no CPU path)")
+        return self._forward_infer(emb, seg, first_only=True)
+
     @torch.no_grad()
-    def _forward_infer(self, emb, seg):
+    def _forward_infer(self, emb, seg, first_only=False):
         B, L, E = emb.shape
         H, hd = self.heads_num, E // self.heads_num
         M = B * L
@@ -97,11 +109,13 @@ class TransformerEncoder(nn.Module):
         big_qkv, big_ff = ops.use_gemm256(M, 3 * E, E), ops.use_gemm256(M, F, E)
         if not pre:
             ops.split_planes(h, x_p)
-        for layer, w in zip(self.transformer, W):
+        for li, (layer, w) in enumerate(zip(self.transformer, W)):
             att, ffn = layer.self_attn, layer.feed_forward
             ln1, ln2 = layer.layer_norm_1, layer.layer_norm_2
             if pre:                                                   # layers/transformer.py:63-73
                 ops.layernorm_fwd(h, ln1.gamma.data, ln1.beta.data, None, rows=M, D=E, eps=ln1.eps, mode=1, out_planes=x_p)
+            if first_only and li == self.layers_num - 1:
+                return self._last_layer_first_token(ws, layer, w, h, x_p, seg, B, L, E, F)
             engine.linear_fwd(ws, x_p, w["wqkv" if big_qkv else "wqkv_t"], w["bqkv"], None, M, 3 * E, E, out_planes=qkv_p)
             ops.self_attn_fwd(qkv_p, seg, o_p, batch=B, heads=H, L=L, head_dim=hd, scale=scale)
             engine.linear_fwd(ws, o_p, w["wo"], att.final_linear.bias.data, h2, M, E, E, resid=h)
@@ -120,6 +134,47 @@ class TransformerEncoder(nn.Module):
                               eps=self.layer_norm.eps, mode=1)
         else:
             out.view(M, E).copy_(h)
+        return out
+
+    def _last_layer_first_token(self, ws, layer, w, h, x_p, seg, B, L, E, F):
+        """Last layer of the inference schedule for row 0 of every sequence.  h: the layer's input [B*L, E] (fp32); x_p: the
+        planes its QKV projection reads (LayerNorm_1(h) for 'pre', h itself for 'post').  K, V: all rows; everything after the
+        scores: B rows.  Same kernels and epilogues as the full schedule (the row-0 GEMMs run at M = B)."""
+        att, ffn, ln1, ln2 = layer.self_attn, layer.feed_forward, layer.layer_norm_1, layer.layer_norm_2
+        H, hd, M = self.heads_num, E // self.heads_num, B * L
+        pre = self.layernorm_positioning == "pre"
+        wqkv, dev = w["wqkv"], h.device
+        w_q = ops.Planes(wqkv.buf, E, E, lo_off=wqkv.lo_off)                       # rows [0, E) of [Wq; Wk; Wv]
+        w_kv = ops.Planes(wqkv.buf[E * E:], 2 * E, E, lo_off=wqkv.lo_off)          # rows [E, 3E)
+        kv_p = ws.planes("kv_p", M, 2 * E)
+        engine.linear_fwd(ws, x_p, w_kv, w["bqkv"][E:], None, M, 2 * E, E, out_planes=kv_p)
+        h0 = h.view(B, L, E)[:, 0, :].contiguous()                                  # the layer's input at row 0
+        x0_p, q0, o0, o0_p = ws.planes("x0_p", B, E), ws.mat("q0", B, E), ws.mat("o0", B, E), ws.planes("o0_p", B, E)
+        if pre:
+            ops.layernorm_fwd(h0, ln1.gamma.data, ln1.beta.data, None, rows=B, D=E, eps=ln1.eps, mode=1, out_planes=x0_p)
+        else:
+            ops.split_planes(h0, x0_p)
+        engine.linear_fwd(ws, x0_p, w_q, w["bqkv"][:E], q0, B, E, E)
+        ops.first_token_attn(q0, kv_p, seg, o0, batch=B, heads=H, L=L, head_dim=hd, scale=1.0 / math.sqrt(float(hd)))
+        ops.split_planes(o0, o0_p)
+        a0, t0_p, ff0_p, y0 = ws.mat("a0", B, E), ws.planes("t0_p", B, E), ws.planes("ff0_p", B, F), ws.mat("y0", B, E)
+        out = torch.empty(B, E, device=dev)
+        engine.linear_fwd(ws, o0_p, w["wo"], att.final_linear.bias.data, a0, B, E, E, resid=h0)
+        if pre:                                                       # layers/transformer.py:63-73
+            ops.layernorm_fwd(a0, ln2.gamma.data, ln2.beta.data, None, rows=B, D=E, eps=ln2.eps, mode=1, out_planes=t0_p)
+            engine.linear_fwd(ws, t0_p, w["w1"], ffn.linear_1.bias.data, None, B, F, E, act=1, out_planes=ff0_p)
+            engine.linear_fwd(ws, ff0_p, w["w2"], ffn.linear_2.bias.data, y0, B, E, F, resid=a0)
+            if self.final_layernorm:
+                ops.layernorm_fwd(y0, self.layer_norm.gamma.data, self.layer_norm.beta.data, out, rows=B, D=E,
+                                  eps=self.layer_norm.eps, mode=1)
+            else:
+                out.copy_(y0)
+        else:                                                         # layers/transformer.py:54-61
+            i0 = ws.mat("i0", B, E)
+            ops.layernorm_fwd(a0, ln1.gamma.data, ln1.beta.data, i0, rows=B, D=E, eps=ln1.eps, mode=1, out_planes=t0_p)
+            engine.linear_fwd(ws, t0_p, w["w1"], ffn.linear_1.bias.data, None, B, F, E, act=1, out_planes=ff0_p)
+            engine.linear_fwd(ws, ff0_p, w["w2"], ffn.linear_2.bias.data, y0, B, E, F, resid=i0)
+            ops.layernorm_fwd(y0, ln2.gamma.data, ln2.beta.data, out, rows=B, D=E, eps=ln2.eps, mode=1)
         return out
 
     # ---- training schedule: same kernels, activations kept for the backward -------------------------------------

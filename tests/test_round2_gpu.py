@@ -476,3 +476,64 @@ def test_cls_mode_rollout_and_update_match_reference(dev):
     loss2, _ = model.actor(text.to(dev), img.to(dev), tgts.to(dev))
     loss2.backward()
     assert model.actor.head.weight.grad is not None and model.actor.head.weight.grad.abs().sum() > 0
+
+
+# ---- last encoder layer for token 0 only ('first' pooling; TransformerEncoder.forward_first_token) --------------------------
+@pytest.mark.parametrize("batch,heads,L", [(3, 2, 50), (2, 12, 197), (1, 1, 700)])
+def test_first_token_attention_kernel(dev, batch, heads, L):
+    """lr2_first_token_attn against the fp64 formula of multi_headed_attn.py:61-74 restricted to query 0 (key mask on the last
+    sequence)."""
+    import math
+    from lr2ppo_amd import ops
+    from test_kernels_gpu import _close
+    g = torch.Generator().manual_seed(L + heads)
+    E = heads * 64
+    q = torch.randn(batch, E, generator=g)
+    kv = torch.cat([torch.randn(batch * L, E, generator=g) * 0.5, torch.randn(batch * L, E, generator=g)], dim=1)
+    seg = torch.ones(batch, L, dtype=torch.long)
+    seg[-1, (2 * L) // 3:] = 0
+    kv_p = _planes(ops, kv, dev)
+    kvf = kv_p.to_float().double().cpu()                                           # what the kernel reads (hi + lo)
+    k = kvf[:, :E].view(batch, L, heads, 64).permute(0, 2, 1, 3)
+    v = kvf[:, E:].view(batch, L, heads, 64).permute(0, 2, 1, 3)
+    s = torch.einsum("bhd,bhld->bhl", q.double().view(batch, heads, 64), k) / math.sqrt(64.0)
+    s = s + (1.0 - (seg > 0).double()).view(batch, 1, L) * -10000.0
+    ref = torch.einsum("bhl,bhld->bhd", torch.softmax(s, dim=-1), v).reshape(batch, E)
+    o = torch.full((batch, E), float("nan"), device=dev)
+    ops.first_token_attn(q.to(dev), kv_p, seg.view(-1).to(dev), o, batch=batch, heads=heads, L=L, head_dim=64,
+                         scale=1.0 / math.sqrt(64.0))
+    _close(o, ref, 2e-5, 2e-5, "first-token attention")
+
+
+@pytest.mark.parametrize("tag,hidden,heads,L,layers", [("pre", 768, 12, 197, 2), ("post", 768, 12, 196, 2), ("pre", 128, 2, 50, 3),
+                                                       ("post", 128, 2, 40, 1)])
+def test_forward_first_token_is_row_zero_of_the_full_forward(dev, tag, hidden, heads, L, layers):
+    """The pruned last layer (keys / values for every row; query, projection, feed-forward, LayerNorms for row 0) gives the
+    full inference forward's row 0 -- both LayerNorm placements, key padding, ViT-B/16 and RoBERTa-base widths; with
+    gradients enabled the call falls back to the full (differentiable) forward."""
+    from lr2ppo_amd.tencentpretrain.encoders import str2encoder
+    from test_encoder_gpu import _args, ROBERTA
+    a = _args(**{**ROBERTA, "hidden_size": hidden, "emb_size": hidden, "feedforward_size": 4 * hidden, "heads_num": heads,
+                 "layers_num": layers, "layernorm_positioning": tag, "dropout": 0.0})
+    enc = str2encoder["transformer"](a)
+    spec = [(n, tuple(p.shape)) for n, p in enc.named_parameters()]
+    enc.load_state_dict(O.seeded_params(spec, seed=31, std=0.05, skip_gamma_beta=False), strict=True)
+    enc = enc.to(dev).eval()
+    gen = torch.Generator().manual_seed(32)
+    B = 5
+    x = torch.randn(B, L, hidden, generator=gen).to(dev)
+    seg = torch.ones(B, L, dtype=torch.long)
+    seg[1, L // 2:] = 0
+    seg[4, L - 3:] = 0
+    seg = seg.to(dev)
+    with torch.no_grad():
+        full = enc(x, seg)
+        first = enc.forward_first_token(x, seg)
+    assert first.shape == (B, hidden)
+    err = (first - full[:, 0, :]).abs().max().item()
+    assert err < 2e-5 * max(1.0, full[:, 0, :].abs().max().item()), err
+    xg = x.clone().requires_grad_(True)
+    out = enc.forward_first_token(xg, seg)                      # grad mode: full forward, sliced, differentiable
+    out.sum().backward()
+    assert xg.grad is not None and xg.grad.abs().sum() > 0
+    assert (out.detach() - full[:, 0, :]).abs().max().item() < 2e-5 * max(1.0, full.abs().max().item())

@@ -27,11 +27,16 @@ def _args(**over):
     return argparse.Namespace(**d)
 
 
-def flops(B, L, E=768, F=3072, layers=12, heads=12):
+def flops(B, L, E=768, F=3072, layers=12, heads=12, first_token_only=False):
+    """Matrix flops of one encoder forward.  first_token_only: the last layer as TransformerEncoder.forward_first_token runs
+    it (keys / values for every row; query, scores, projection and feed-forward for row 0 of each sequence)."""
     M = B * L
     gemm = 2.0 * M * E * (3 * E + E + 2 * F)
     attn = 4.0 * B * heads * L * L * (E // heads)
-    return layers * (gemm + attn)
+    if not first_token_only:
+        return layers * (gemm + attn)
+    last = 2.0 * M * E * (2 * E) + 2.0 * B * E * (E + E + 2 * F) + 4.0 * B * heads * L * (E // heads)
+    return (layers - 1) * (gemm + attn) + last
 
 
 def measure_forward(batch_items=32, tags=2, n_img=16, iters=3, passes=3, dev=None):
