@@ -159,7 +159,8 @@ int lr2_xattn_bwd(const void* Q, const void* K, const void* V, const void* dO, v
  * P = softmax(S), O = P V -- both products on the matrix cores (split-bf16 x3), softmax in fp32.
  * q_hi / k_hi / v_hi: bf16 hi planes of Q, K, V, element (row, h*64 + d) at ptr[row*ld + h*64 + d], the lo plane lo_off
  * ELEMENTS behind each (one fused QKV matrix [batch*L, 3*heads*64] with ld = 3*heads*64 is the intended producer);
- * seg int64 [batch*L]; o fp32 [batch*L, ld_o] and/or o_hi planes (lo plane o_lo_off elements behind); L <= 256, hd == 64.
+ * seg int64 [batch*L]; o fp32 [batch*L, ld_o] and/or o_hi planes (lo plane o_lo_off elements behind); hd == 64; any L (one
+ * LDS-resident key block up to 256 keys, a key-block loop with running max / sum beyond).
  * replaces: tencentpretrain/layers/multi_headed_attn.py:61-74 and the mask of encoders/transformer_encoder.py:62-68. */
 int lr2_self_attn_fwd(const void* q_hi, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld, const int64_t* seg,
                       void* o, void* o_hi, uint64_t o_lo_off, int ld_o, void* lse, float drop_p, uint64_t drop_seed,
@@ -183,7 +184,8 @@ int lr2_first_token_attn(const void* q, int ld_q, const void* k_hi, const void* 
  * (dq_hi / dk_hi / dv_hi: hi planes, element (row, h*64 + d) at ptr[row*ld_d + h*64 + d], lo plane d_lo_off elements behind --
  * three column blocks of one dQKV matrix are the intended target).  Two kernels: dQ per 64 queries (also writes the
  * per-query log-sum-exp and sum_k dP*P into lse_ws / dsum_ws, fp32 [batch*heads*L] each), then dK, dV per 64 keys.
- * Probabilities are recomputed; pass the forward's drop_p / seed / site to replay its mask.
+ * Probabilities are recomputed; pass the forward's drop_p / seed / site to replay its mask.  L > 256: both kernels walk the
+ * other dimension in blocks of 128 rows; the dQ kernel sweeps the keys twice (running max / sum / sum of exp * dP first).
  * replaces: autograd of tencentpretrain/layers/multi_headed_attn.py:61-74. */
 int lr2_self_attn_bwd(const void* q_hi, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld, const void* do_hi,
                       uint64_t do_lo_off, int ld_do, const int64_t* seg, void* dq_hi, void* dk_hi, void* dv_hi,

@@ -775,6 +775,260 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dkv_kernel(const bf16_t* __
   }  // sub-tile loop
 }
 
+// ---- backward for sequences beyond one LDS-resident block (L > 256): the same two kernels with a block loop ---------------
+// dQ: the keys are walked in blocks of LPB = 16*NT, TWICE.  Sweep 1 keeps, per query, the running maximum m, the sum
+// l = sum_k exp(s_k - m) and a = sum_k exp(s_k - m) dP_k (rescaled like the forward's accumulator when m grows), which give
+// lse = m + log l and D = sum_k P_k dP_k = a / l without a second statistic pass; sweep 2 recomputes S and dP per block, forms
+// dS = P (dP - D) * scale and accumulates dQ = dS K.  Five matrix products per (query, key) pair instead of three.
+template <int NT>
+__global__ __launch_bounds__(256) void self_attn_bwd_dq_blocked_kernel(
+    const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh, const bf16_t* __restrict__ Vh, size_t lo_off, int ld,
+    const bf16_t* __restrict__ dOh, size_t do_lo_off, int ld_do, const int64_t* __restrict__ seg, bf16_t* __restrict__ dQh,
+    size_t dq_lo_off, int ld_dq, float* __restrict__ lse, float* __restrict__ dsum, int heads, int L, float scale, DropP dr) {
+  constexpr int LPB = 16 * NT;
+  constexpr int PLANE = LPB * ROW_B;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + 2 * PLANE;        // K layout (V is an A operand here)
+  float* sMask = reinterpret_cast<float*>(smem + 4 * PLANE);
+  float* sOut = sMask + LPB;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row0 = (size_t)b * L;
+  const int col0 = h * HD;
+  const int qn = lane & 15, g = lane >> 4;
+  const int sub = blockIdx.x * 4 + wave;             // one 16-query sub-tile per wave (waves past the end idle through the barriers)
+  const int q_row = sub * 16 + qn;
+  const bool q_ok = q_row < L;
+  bf16x8_t qh[2], ql[2], gh[2], gl[2];
+  load_frags(Qh, lo_off, (row0 + (q_ok ? q_row : 0)) * (size_t)ld + col0 + 8 * g, q_ok, qh, ql);
+  load_frags(dOh, do_lo_off, (row0 + (q_ok ? q_row : 0)) * (size_t)ld_do + col0 + 8 * g, q_ok, gh, gl);
+  const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_ok ? q_row : 0)) * (uint64_t)L;
+
+  float m = -INFINITY, l = 0.f, a = 0.f, lse_q = 0.f, dd = 0.f;
+  f32x4_t o[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+
+#pragma unroll 1
+  for (int sweep = 0; sweep < 2; ++sweep) {
+#pragma unroll 1
+    for (int k0 = 0; k0 < L; k0 += LPB) {
+      __syncthreads();                               // the previous block's readers are done
+      for (int i = tid; i < LPB * 8; i += 256) {
+        const int r = i >> 3, u = i & 7;
+        u32x4_t kh = {0, 0, 0, 0}, kl = kh, vh = kh, vl = kh;
+        if (k0 + r < L) {
+          const size_t off = (row0 + k0 + r) * (size_t)ld + col0 + u * 8;
+          kh = *reinterpret_cast<const u32x4_t*>(Kh + off);
+          kl = *reinterpret_cast<const u32x4_t*>(Kh + off + lo_off);
+          vh = *reinterpret_cast<const u32x4_t*>(Vh + off);
+          vl = *reinterpret_cast<const u32x4_t*>(Vh + off + lo_off);
+        }
+        *reinterpret_cast<u32x4_t*>(sK + k_off(r, u)) = kh;
+        *reinterpret_cast<u32x4_t*>(sK + PLANE + k_off(r, u)) = kl;
+        *reinterpret_cast<u32x4_t*>(sV + k_off(r, u)) = vh;
+        *reinterpret_cast<u32x4_t*>(sV + PLANE + k_off(r, u)) = vl;
+      }
+      for (int j = tid; j < LPB; j += 256) sMask[j] = (k0 + j < L) ? ((seg[row0 + k0 + j] > 0) ? 0.f : -10000.0f) : -INFINITY;
+      __syncthreads();
+
+      f32x4_t s[NT], dp[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, d = sa;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int r = 16 * t + qn;
+          const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(sK + k_off(r, g + 4 * ks));
+          const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(sK + PLANE + k_off(r, g + 4 * ks));
+          const bf16x8_t vh = *reinterpret_cast<const bf16x8_t*>(sV + k_off(r, g + 4 * ks));
+          const bf16x8_t vl = *reinterpret_cast<const bf16x8_t*>(sV + PLANE + k_off(r, g + 4 * ks));
+          sa = mfma3(kh, kl, qh[ks], ql[ks], sa);
+          d = mfma3(vh, vl, gh[ks], gl[ks], d);
+        }
+        const float4 mk = *reinterpret_cast<const float4*>(sMask + 16 * t + 4 * g);
+        sa[0] = sa[0] * scale + mk.x;
+        sa[1] = sa[1] * scale + mk.y;
+        sa[2] = sa[2] * scale + mk.z;
+        sa[3] = sa[3] * scale + mk.w;
+        if (dr.thr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = k0 + 16 * t + 4 * g + r;
+            d[r] *= drop_mul(dr, drow + (uint64_t)(key < L ? key : 0));         // dP = dPd o M
+          }
+        }
+        s[t] = sa;
+        dp[t] = d;
+      }
+      if (sweep == 0) {
+        float bm = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bm = fmaxf(fmaxf(bm, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float m_new = fmaxf(m, bm);              // finite: every block holds at least one real key
+        const float corr = exp_fast(m - m_new);        // 0 on the first block (m = -inf)
+        l *= corr;
+        a *= corr;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = exp_fast(s[t][r] - m_new);
+            l += e;
+            a = __builtin_fmaf(e, dp[t][r], a);
+          }
+        m = m_new;
+      } else {
+#pragma unroll
+        for (int u = 0; u < NT / 2; ++u) {
+          float e[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            e[r] = exp_fast(s[2 * u][r] - lse_q) * (dp[2 * u][r] - dd) * scale;
+            e[4 + r] = exp_fast(s[2 * u + 1][r] - lse_q) * (dp[2 * u + 1][r] - dd) * scale;
+          }
+          bf16x8_t eh, el;
+          split8(e, eh, el);
+          const int ra = 32 * u + 4 * g + tq, rb = ra + 16;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const int unit = 2 * n + (tp >> 1), half8 = 8 * (tp & 1);
+            o[n] = mfma3(eh, el, tr_pair_k(sK, ra, rb, unit, half8), tr_pair_k(sK + PLANE, ra, rb, unit, half8), o[n]);
+          }
+        }
+      }
+    }
+    if (sweep == 0) {                                  // per-query statistics (lanes of one query hold disjoint key subsets)
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      lse_q = m + logf(l);
+      dd = a / l;
+      if (g == 0 && q_ok) {
+        const size_t si = ((size_t)b * heads + h) * L + q_row;
+        lse[si] = lse_q;
+        dsum[si] = dd;
+      }
+    }
+  }
+  if (sub * 16 < L)
+    store_tile_planes(o, sOut + wave * 16 * (HD + 4), lane, sub * 16, L, dQh, dq_lo_off, (size_t)ld_dq, row0 * (size_t)ld_dq + col0);
+}
+
+// dK, dV: each wave keeps its 16 keys' K / V fragments and accumulators while the queries (Q, dO, lse, D) pass through LDS in
+// blocks of LPB.
+template <int NT>
+__global__ __launch_bounds__(256) void self_attn_bwd_dkv_blocked_kernel(
+    const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh, const bf16_t* __restrict__ Vh, size_t lo_off, int ld,
+    const bf16_t* __restrict__ dOh, size_t do_lo_off, int ld_do, const int64_t* __restrict__ seg, bf16_t* __restrict__ dKh,
+    bf16_t* __restrict__ dVh, size_t dkv_lo_off, int ld_dkv, const float* __restrict__ lse, const float* __restrict__ dsum,
+    int heads, int L, float scale, DropP dr) {
+  constexpr int LPB = 16 * NT;
+  constexpr int PLANE = LPB * ROW_B;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQ = smem;
+  char* sG = smem + 2 * PLANE;
+  float* sLse = reinterpret_cast<float*>(smem + 4 * PLANE);
+  float* sD = sLse + LPB;
+  float* sOut = sD + LPB;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t row0 = (size_t)b * L;
+  const int col0 = h * HD;
+  const int kn = lane & 15, g = lane >> 4;
+  const int sub = blockIdx.x * 4 + wave;
+  const int key = sub * 16 + kn;
+  const bool k_ok = key < L;
+  bf16x8_t kh[2], kl[2], vh[2], vl[2];
+  load_frags(Kh, lo_off, (row0 + (k_ok ? key : 0)) * (size_t)ld + col0 + 8 * g, k_ok, kh, kl);
+  load_frags(Vh, lo_off, (row0 + (k_ok ? key : 0)) * (size_t)ld + col0 + 8 * g, k_ok, vh, vl);
+  const float kmask = k_ok ? ((seg[row0 + key] > 0) ? 0.f : -10000.0f) : -INFINITY;
+  f32x4_t dv[4], dk[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) dv[n] = dk[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+  const uint64_t dbase = ((uint64_t)b * heads + h) * (uint64_t)L;
+#pragma unroll 1
+  for (int q0 = 0; q0 < L; q0 += LPB) {
+    __syncthreads();
+    for (int i = tid; i < LPB * 8; i += 256) {
+      const int r = i >> 3, u = i & 7;
+      u32x4_t qa = {0, 0, 0, 0}, qc = qa, ga = qa, gc = qa;
+      if (q0 + r < L) {
+        const size_t off = (row0 + q0 + r) * (size_t)ld + col0 + u * 8;
+        const size_t og = (row0 + q0 + r) * (size_t)ld_do + col0 + u * 8;
+        qa = *reinterpret_cast<const u32x4_t*>(Qh + off);
+        qc = *reinterpret_cast<const u32x4_t*>(Qh + off + lo_off);
+        ga = *reinterpret_cast<const u32x4_t*>(dOh + og);
+        gc = *reinterpret_cast<const u32x4_t*>(dOh + og + do_lo_off);
+      }
+      *reinterpret_cast<u32x4_t*>(sQ + k_off(r, u)) = qa;
+      *reinterpret_cast<u32x4_t*>(sQ + PLANE + k_off(r, u)) = qc;
+      *reinterpret_cast<u32x4_t*>(sG + k_off(r, u)) = ga;
+      *reinterpret_cast<u32x4_t*>(sG + PLANE + k_off(r, u)) = gc;
+    }
+    for (int j = tid; j < LPB; j += 256) {
+      const size_t si = ((size_t)b * heads + h) * L + q0 + j;
+      sLse[j] = (q0 + j < L) ? lse[si] : INFINITY;     // padded queries: P = exp(-inf) = 0
+      sD[j] = (q0 + j < L) ? dsum[si] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int u = 0; u < NT / 2; ++u) {
+      float pd[8], ds[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * u + half;
+        f32x4_t sa = {0.f, 0.f, 0.f, 0.f}, d = sa;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int r = 16 * t + kn;
+          const bf16x8_t qh = *reinterpret_cast<const bf16x8_t*>(sQ + k_off(r, g + 4 * ks));
+          const bf16x8_t ql = *reinterpret_cast<const bf16x8_t*>(sQ + PLANE + k_off(r, g + 4 * ks));
+          const bf16x8_t gh = *reinterpret_cast<const bf16x8_t*>(sG + k_off(r, g + 4 * ks));
+          const bf16x8_t gl = *reinterpret_cast<const bf16x8_t*>(sG + PLANE + k_off(r, g + 4 * ks));
+          sa = mfma3(qh, ql, kh[ks], kl[ks], sa);
+          d = mfma3(gh, gl, vh[ks], vl[ks], d);
+        }
+        const float4 ls = *reinterpret_cast<const float4*>(sLse + 16 * t + 4 * g);
+        const float4 dd = *reinterpret_cast<const float4*>(sD + 16 * t + 4 * g);
+        const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, ddv[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp_fast(sa[r] * scale + kmask - lsv[r]);
+          float mm = 1.0f;
+          if (dr.thr) {
+            const int q = q0 + 16 * t + 4 * g + r;
+            mm = drop_mul(dr, (dbase + (uint64_t)(q < L ? q : 0)) * (uint64_t)L + (uint64_t)(k_ok ? key : 0));
+          }
+          pd[4 * half + r] = p * mm;
+          ds[4 * half + r] = p * (d[r] * mm - ddv[r]) * scale;
+        }
+      }
+      bf16x8_t ph, pl, eh, el;
+      split8(pd, ph, pl);
+      split8(ds, eh, el);
+      const int ra = 32 * u + 4 * g + tq, rb = ra + 16;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int unit = 2 * n + (tp >> 1), half8 = 8 * (tp & 1);
+        dv[n] = mfma3(ph, pl, tr_pair_k(sG, ra, rb, unit, half8), tr_pair_k(sG + PLANE, ra, rb, unit, half8), dv[n]);
+        dk[n] = mfma3(eh, el, tr_pair_k(sQ, ra, rb, unit, half8), tr_pair_k(sQ + PLANE, ra, rb, unit, half8), dk[n]);
+      }
+    }
+  }
+  if (sub * 16 < L) {
+    float* slab = sOut + wave * 16 * (HD + 4);
+    store_tile_planes(dk, slab, lane, sub * 16, L, dKh, dkv_lo_off, (size_t)ld_dkv, row0 * (size_t)ld_dkv + col0);
+    store_tile_planes(dv, slab, lane, sub * 16, L, dVh, dkv_lo_off, (size_t)ld_dkv, row0 * (size_t)ld_dkv + col0);
+  }
+}
+
 static DropP make_drop(float p, uint64_t seed, uint32_t site) {
   DropP d{0, 0, 1.0f};
   if (p > 0.f) {
@@ -876,6 +1130,25 @@ int launch_bwd(const AttnArgs& a, const bf16_t* go, size_t do_lo_off, int ld_do,
   LR2_LAUNCH(self_attn_bwd_dkv_kernel<NT>, grid, dim3(256), lds2, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, go, do_lo_off, ld_do,
              a.seg, dk, dv, d_lo_off, ld_d, (const float*)lse, (const float*)dsum, a.heads, a.L, a.scale, a.dr);
   return lr2_launch_status("lr2_self_attn_bwd(dkv)");
+}
+
+// L > 256: query / key blocks of 128 rows through 64 KiB of LDS (two workgroups per CU)
+int launch_bwd_blocked(const AttnArgs& a, const bf16_t* go, size_t do_lo_off, int ld_do, bf16_t* dq, bf16_t* dk, bf16_t* dv,
+                       size_t d_lo_off, int ld_d, float* lse, float* dsum) {
+  constexpr int NT = 8, LPB = 16 * NT;
+  const size_t lds1 = (size_t)4 * LPB * ROW_B + (size_t)LPB * 4 + (size_t)4 * 16 * (HD + 4) * 4;
+  const size_t lds2 = (size_t)4 * LPB * ROW_B + (size_t)LPB * 8 + (size_t)4 * 16 * (HD + 4) * 4;
+  static bool done1 = false, done2 = false;
+  if (allow_lds_once(self_attn_bwd_dq_blocked_kernel<NT>, lds1, done1, "self_attn_bwd_dq_blocked")) return LR2_ERR_LAUNCH;
+  if (allow_lds_once(self_attn_bwd_dkv_blocked_kernel<NT>, lds2, done2, "self_attn_bwd_dkv_blocked")) return LR2_ERR_LAUNCH;
+  const int n_sub = (a.L + 15) / 16;
+  const dim3 grid((n_sub + 3) / 4, a.heads, a.batch);
+  LR2_LAUNCH(self_attn_bwd_dq_blocked_kernel<NT>, grid, dim3(256), lds1, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, go, do_lo_off,
+             ld_do, a.seg, dq, d_lo_off, ld_d, lse, dsum, a.heads, a.L, a.scale, a.dr);
+  if (lr2_launch_status("lr2_self_attn_bwd(dq, blocked)")) return LR2_ERR_LAUNCH;
+  LR2_LAUNCH(self_attn_bwd_dkv_blocked_kernel<NT>, grid, dim3(256), lds2, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, go, do_lo_off,
+             ld_do, a.seg, dk, dv, d_lo_off, ld_d, (const float*)lse, (const float*)dsum, a.heads, a.L, a.scale, a.dr);
+  return lr2_launch_status("lr2_self_attn_bwd(dkv, blocked)");
 }
 
 #define LR2_SA_INST(NT)                                                                                                        \
@@ -994,11 +1267,14 @@ extern "C" int lr2_self_attn_bwd(const void* q_hi, const void* k_hi, const void*
                                  void* stream) {
   if (!q_hi || !k_hi || !v_hi || !do_hi || !seg || !dq_hi || !dk_hi || !dv_hi || !lse_ws || !dsum_ws || batch <= 0 || heads <= 0)
     return LR2_ERR_ARG;
-  if (head_dim != HD || L < 1 || L > 256 || ld % 8 || ld_do % 8 || ld_d % 8 || lo_off % 8 || do_lo_off % 8 || d_lo_off % 8)
+  if (head_dim != HD || L < 1 || ld % 8 || ld_do % 8 || ld_d % 8 || lo_off % 8 || do_lo_off % 8 || d_lo_off % 8)
     return LR2_ERR_SHAPE;
   if (drop_p < 0.f || drop_p >= 1.f) return LR2_ERR_ARG;
   const AttnArgs a{(const bf16_t*)q_hi, (const bf16_t*)k_hi, (const bf16_t*)v_hi, (size_t)lo_off, ld, seg, batch, heads, L,
                    scale, make_drop(drop_p, drop_seed, drop_site), (hipStream_t)stream};
+  if (L > 256)
+    return launch_bwd_blocked(a, (const bf16_t*)do_hi, (size_t)do_lo_off, ld_do, (bf16_t*)dq_hi, (bf16_t*)dk_hi, (bf16_t*)dv_hi,
+                              (size_t)d_lo_off, ld_d, (float*)lse_ws, (float*)dsum_ws);
 #define CALL(NT)                                                                                                           \
   launch_bwd<NT>(a, (const bf16_t*)do_hi, (size_t)do_lo_off, ld_do, (bf16_t*)dq_hi, (bf16_t*)dk_hi, (bf16_t*)dv_hi,        \
                  (size_t)d_lo_off, ld_d, (float*)lse_ws, (float*)dsum_ws)

@@ -462,9 +462,6 @@ def self_attn_bwd(qkv: "Planes", do: "Planes", seg, dqkv: "Planes", lse_ws, dsum
     if seg.dtype != torch.int64:
         raise TypeError("seg must be int64")
     _chk_f32(lse_ws, dsum_ws)
-    if L > 256:
-        raise NotImplementedError(f"self_attn_bwd: sequences of {L} tokens need the key-block loop, which only the forward has; the "
-                                  "backward kernels keep a whole head (L <= 256) in LDS")
     if lse_ws.numel() < batch * heads * L or dsum_ws.numel() < batch * heads * L:
         raise ValueError("self_attn_bwd: statistics workspaces too small")
     q, k, v = _qkv_ptrs(qkv, E)

@@ -248,10 +248,12 @@ def test_self_attn_fwd_with_key_mask(ops, dev, batch, heads, L, planes_out):
 
 
 @pytest.mark.parametrize("batch,heads,L,drop_p", [(2, 3, 197, 0.0), (1, 2, 64, 0.0), (2, 1, 130, 0.1), (1, 2, 256, 0.0),
-                                                    (2, 2, 196, 0.1)])
+                                                    (2, 2, 196, 0.1), (2, 2, 257, 0.0), (1, 2, 514, 0.1), (1, 3, 300, 0.1),
+                                                    (1, 1, 449, 0.0)])
 def test_self_attn_bwd_matches_autograd(ops, dev, batch, heads, L, drop_p):
     """dQ / dK / dV of the MFMA self-attention (two kernels, probabilities recomputed, dropout mask replayed) against
-    fp64 autograd of the reference formula; the forward with dropout and its log-sum-exp output are checked on the way."""
+    fp64 autograd of the reference formula; the forward with dropout and its log-sum-exp output are checked on the way.
+    L > 256 (ViT-L/14's 257 tokens, RoBERTa's max_seq_length 514): the key / query block loops of both kernels."""
     import numpy as np
     from oracle import lr2ppo_oracle as O
     g = torch.Generator().manual_seed(L + heads)
@@ -287,7 +289,10 @@ def test_self_attn_bwd_matches_autograd(ops, dev, batch, heads, L, drop_p):
     for name, lo in (("dQ", 0), ("dK", E), ("dV", 2 * E)):
         ref = x.grad[:, lo:lo + E]
         _close(got[:, lo:lo + E], ref, 3e-5 * max(1.0, float(ref.abs().max())), 5e-5, name)
-    assert torch.equal(ws1, lse)
+    if L <= 256:
+        assert torch.equal(ws1, lse)
+    else:                               # blocked kernels: the running max / sum is updated in a different order
+        _close(ws1, lse.double().cpu(), 1e-5, 1e-5, "lse (backward sweep 1)")
 
 
 # ------------------------------------------------------------------------------------- small ops

@@ -421,9 +421,21 @@ def test_vit_l14_config_forward_matches_oracle(dev):
         want = O.transformer_encoder(pn, O.vit_embedding(pe, img, 14), seg, 2, 16, True)
     assert got.shape == (2, 257, 1024)
     _cmp(got, want, "ViT-L/14, 2 layers")
-    with pytest.raises(Exception, match="256"):                 # the training path still needs one LDS-resident key block
-        stack.train()
-        stack(img.to(dev).requires_grad_(True), seg.to(dev)).sum().backward()
+    # training path at 257 tokens: the key / query block loops of the attention backward -- parameter gradients of both layers
+    # against the oracle's autograd (eval mode: no dropout to pin)
+    for prm in stack.parameters():
+        prm.grad = None
+    w = torch.randn(2, 257, 1024, generator=gen)
+    (stack(img.to(dev), seg.to(dev)) * w.to(dev)).sum().backward()
+    pg = {k: v.clone().requires_grad_(True) for k, v in pn.items()}
+    (O.transformer_encoder(pg, O.vit_embedding(pe, img, 14), seg, 2, 16, True) * w).sum().backward()
+    for name in ("transformer.0.self_attn.linear_layers.0.weight", "transformer.0.self_attn.linear_layers.1.weight",
+                 "transformer.0.self_attn.linear_layers.2.bias", "transformer.1.self_attn.linear_layers.0.weight",
+                 "transformer.1.feed_forward.linear_1.weight", "transformer.0.layer_norm_1.gamma"):
+        got_g = dict(stack.encoder.named_parameters())[name].grad
+        ref_g = pg[name].grad
+        err = (got_g.cpu().double() - ref_g.double()).abs().max().item()
+        assert err < 1e-3 * max(1.0, ref_g.abs().max().item()), (name, err, ref_g.abs().max().item())
 
 
 # ---- mode = 'cls' (finetune/ppo.py:209-210,229-242,532-537,641-643,859-863) -----------------------------------------------------
