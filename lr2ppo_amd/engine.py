@@ -62,6 +62,33 @@ class Workspace:
         self._bufs.clear()
 
 
+class Arena:
+    """ONE device allocation carved into fp32 / bf16-planes views: the activations a training forward keeps for its backward
+    (freed as a whole when the last view dies).  256-byte aligned pieces; a request beyond the reserved size falls back to
+    its own allocation, so a wrong size estimate costs speed, never correctness."""
+
+    def __init__(self, device, nbytes: int):
+        self.device = device
+        self.buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        self.off = 0
+
+    def _take(self, nbytes: int) -> torch.Tensor:
+        start = (self.off + 255) & ~255
+        if start + nbytes > self.buf.numel():
+            return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.off = start + nbytes
+        return self.buf[start:start + nbytes]
+
+    def vec(self, numel: int) -> torch.Tensor:
+        return self._take(4 * numel).view(torch.float32)
+
+    def mat(self, rows: int, cols: int) -> torch.Tensor:
+        return self.vec(rows * cols).view(rows, cols)
+
+    def planes(self, rows: int, cols: int) -> Planes:
+        return Planes(self._take(4 * rows * cols).view(torch.int16), rows, cols)
+
+
 class DropCfg:
     """Train-time dropout of one XiT block: three sites (attention out, FFN hidden, FFN out)."""
 

@@ -194,10 +194,12 @@ class TransformerEncoder(nn.Module):
         p = float(self.transformer[0].dropout_1.p) if self.training else 0.0
         seed = runtime.next_drop(p, 0).seed if p > 0 else 0
         drop = (lambda site: ops.Drop(p, seed, site)) if p > 0 else (lambda site: None)
-        mat = lambda r, c: torch.empty(r, c, device=dev)                # noqa: E731
-        vec = lambda n: torch.empty(n, device=dev)                      # noqa: E731
-        pl = lambda r, c: ops.Planes.empty(r, c, dev)                   # noqa: E731
         pre = self.layernorm_positioning == "pre"
+        # everything the backward needs lives in one allocation per forward: per layer 32 (pre-LN) / 40 (post-LN) x M x E bytes
+        # of hidden-width tensors, 8 x M x F of feed-forward ones, 4 row statistics; + the final LayerNorm's statistics
+        per_layer = (32 if pre else 40) * M * E + 8 * M * F + 16 * M + 16 * 256
+        arena = engine.Arena(dev, self.layers_num * per_layer + 4 * M * E + 8 * M + 8 * 256)
+        mat, vec, pl = arena.mat, arena.vec, arena.planes
         scale = 1.0 / math.sqrt(float(hd))
         big_qkv, big_ff = ops.use_gemm256(M, 3 * E, E), ops.use_gemm256(M, F, E)
         h = emb.detach().contiguous().view(M, E)
@@ -261,8 +263,10 @@ class TransformerEncoder(nn.Module):
         ws = self._ws
         p, seed = saved["drop"]
         drop = (lambda site: ops.Drop(p, seed, site)) if p > 0 else (lambda site: None)
-        mat = lambda r, c: torch.empty(r, c, device=dev)                # noqa: E731
-        pl = lambda r, c: ops.Planes.empty(r, c, dev)                   # noqa: E731
+        # transient gradients: named workspace buffers, reused by every layer and every call (one stream, sequential); the
+        # running hidden-state gradient alternates between two of them
+        mat = lambda name, r, c: ws.mat("bwd:" + name, r, c)            # noqa: E731
+        pl = lambda name, r, c: ws.planes("bwd:" + name, r, c)          # noqa: E731
         params = list(self.parameters())
         flat = torch.empty(sum(q.numel() for q in params), device=dev)
         G, off = {}, 0
@@ -277,40 +281,41 @@ class TransformerEncoder(nn.Module):
         dh = dout.contiguous().view(M, E)
         if self.final_layernorm:
             ln = self.layer_norm
-            dnew = mat(M, E)
+            dnew = mat("dh0", M, E)
             ops.layernorm_bwd(dh, saved["h_final"], ln.gamma.data, saved["mf"], saved["rf"], dnew, partials, G[ln.gamma],
                               G[ln.beta], rows=M, D=E, mode=1, eps=ln.eps)
             dh = dnew
+        flip = 1
         for i in reversed(range(self.layers_num)):
             layer, w, S = self.transformer[i], W[i], saved["layers"][i]
             att, ffn = layer.self_attn, layer.feed_forward
             ln1, ln2 = layer.layer_norm_1, layer.layer_norm_2
             s0 = 4 * i
-            dff_p, dz_p = pl(M, E), pl(M, F)
+            dff_p, dz_p = pl("dff_p", M, E), pl("dz_p", M, F)
             if pre:
                 ops.dropout_planes(dh, dff_p, drop(s0 + 2))
                 ffn_in_p = S["x2_p"]
             else:
-                d_t2 = mat(M, E)
+                d_t2 = mat("d_t2", M, E)
                 ops.layernorm_bwd(dh, S["t2"], ln2.gamma.data, S["m2"], S["r2"], d_t2, partials, G[ln2.gamma], G[ln2.beta],
                                   rows=M, D=E, dx_planes=dff_p, drop=drop(s0 + 2), mode=1, eps=ln2.eps)
                 ffn_in_p = S["inter_p"]
             engine.linear_wgrad(ws, dff_p, S["ff_p"], G[ffn.linear_2.weight], G[ffn.linear_2.bias], M, F, E)
             engine.linear_dgrad(ws, dff_p, w["w2"], None, M, F, E, act=2, aux_z=S["z"], out_planes=dz_p)
             engine.linear_wgrad(ws, dz_p, ffn_in_p, G[ffn.linear_1.weight], G[ffn.linear_1.bias], M, E, F)
-            d_t1, dao_p = mat(M, E), pl(M, E)
+            d_t1, dao_p = mat("d_t1", M, E), pl("dao_p", M, E)
             if pre:
-                d_x2 = mat(M, E)
+                d_x2 = mat("d_x2", M, E)
                 engine.linear_dgrad(ws, dz_p, w["w1"], d_x2, M, E, F)
                 ops.layernorm_bwd(d_x2, S["t1"], ln2.gamma.data, S["m2"], S["r2"], d_t1, partials, G[ln2.gamma], G[ln2.beta],
                                   rows=M, D=E, resid_grad=dh, dx_planes=dao_p, drop=drop(s0 + 1), mode=1, eps=ln2.eps)
             else:
-                d_inter = mat(M, E)
+                d_inter = mat("d_x2", M, E)
                 engine.linear_dgrad(ws, dz_p, w["w1"], d_inter, M, E, F, resid=d_t2)
                 ops.layernorm_bwd(d_inter, S["t1"], ln1.gamma.data, S["m1"], S["r1"], d_t1, partials, G[ln1.gamma], G[ln1.beta],
                                   rows=M, D=E, dx_planes=dao_p, drop=drop(s0 + 1), mode=1, eps=ln1.eps)
             engine.linear_wgrad(ws, dao_p, S["o_p"], G[att.final_linear.weight], G[att.final_linear.bias], M, E, E)
-            do_p, dqkv_p = pl(M, E), pl(M, 3 * E)
+            do_p, dqkv_p = pl("do_p", M, E), pl("dqkv_p", M, 3 * E)
             engine.linear_dgrad(ws, dao_p, w["wo"], None, M, E, E, out_planes=do_p)
             ops.self_attn_bwd(S["qkv_p"], do_p, seg, dqkv_p, lse_ws, dsum_ws, batch=B, heads=H, L=L, head_dim=hd, scale=scale,
                               drop=drop(s0))
@@ -318,9 +323,11 @@ class TransformerEncoder(nn.Module):
             for j in range(3):
                 G[att.linear_layers[j].weight].copy_(dwqkv[j * E:(j + 1) * E])
                 G[att.linear_layers[j].bias].copy_(dbqkv[j * E:(j + 1) * E])
-            dprev = mat(M, E)
+            # the gradient handed back to autograd (layer 0) gets its own storage: it outlives this call
+            dprev = torch.empty(M, E, device=dev) if i == 0 else mat("dh%d" % flip, M, E)
+            flip ^= 1
             if pre:
-                d_x1 = mat(M, E)
+                d_x1 = mat("d_x1", M, E)
                 engine.linear_dgrad(ws, dqkv_p, w["wqkv"], d_x1, M, E, 3 * E)
                 ops.layernorm_bwd(d_x1, S["h_in"], ln1.gamma.data, S["m1"], S["r1"], dprev, partials, G[ln1.gamma], G[ln1.beta],
                                   rows=M, D=E, resid_grad=d_t1, mode=1, eps=ln1.eps)
