@@ -20,6 +20,7 @@ duplicate tags in the reward model's index) -- results are bit-identical.
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import random
@@ -346,7 +347,28 @@ class _TailHead(_Head):
             raise IndexError("pos_emb has 4 rows (finetune/ppo.py:256): at most 4 positions")
         return t_out
 
-    def engine_forward(self, text_emb, img_emb, index, *, save: bool) -> torch.Tensor:
+    @torch.no_grad()
+    def trunk_no_grad(self, text_emb, img_emb):
+        """The index-free part of the no-grad forward: every (item, tag) pair through the trunk once -> ([bs*tags, 768] in a
+        workspace buffer, the dropout configuration drawn for this forward).  The trunk is per pair, so gathering ITS OUTPUT
+        by `index` is bit-identical to gathering the inputs (finetune/ppo.py:267-271) -- and the rollout can run it before
+        the actor has produced the ordering."""
+        dev = text_emb.device
+        bs, tags_in = text_emb.shape[:2]
+        ws, P = self._workspace(dev), self._P()
+        W = self._weights(P)
+        n_img = img_emb.shape[-2]
+        text2, img2, _, _, _, shared = self._prep_inputs(text_emb, img_emb)
+        drop = self._drop_cfg(0)
+        return engine.trunk_forward(ws, P, W, text2, img2, bs, tags_in, n_img, FEAT, save=False, drop=drop, img_shared=shared), drop
+
+    def _gather_trunk(self, g2_all, index, bs, tags_in, t_out):
+        g2 = self._workspace(g2_all.device).mat("g2_g", bs * t_out, FEAT)
+        ops.gather_rows(g2_all, index, g2, B=bs, t_in=tags_in, t_out=t_out, row_elems=FEAT)
+        return g2
+
+    def engine_forward(self, text_emb, img_emb, index, *, save: bool, trunk_out=None) -> torch.Tensor:
+        """trunk_out: the result of trunk_no_grad(text_emb, img_emb) when the caller already ran it (no-grad only)."""
         dev = text_emb.device
         bs, tags_in = text_emb.shape[:2]
         index = index.to(device=dev, dtype=torch.int64).contiguous()
@@ -372,13 +394,8 @@ class _TailHead(_Head):
             g2 = engine.trunk_forward(ws, P, W, text_p, img_p, bs, t_out, n_img, FEAT, save=True, drop=drop, img_shared=False)
             drop_t = engine.DropCfg(drop.p, drop.seed, 3) if drop else None
         else:
-            # no-grad: every (item, tag) pair goes through the trunk once; duplicates in `index` are gathered
-            # from the [bs, tags, 768] trunk output (the trunk is per-pair, so this is bit-identical)
-            text2, img2, _, _, _, shared = self._prep_inputs(text_emb, img_emb)
-            drop = self._drop_cfg(0)
-            g2_all = engine.trunk_forward(ws, P, W, text2, img2, bs, tags_in, n_img, FEAT, save=False, drop=drop, img_shared=shared)
-            g2 = ws.mat("g2_g", bs * t_out, FEAT)
-            ops.gather_rows(g2_all, index, g2, B=bs, t_in=tags_in, t_out=t_out, row_elems=FEAT)
+            g2_all, drop = trunk_out if trunk_out is not None else self.trunk_no_grad(text_emb, img_emb)
+            g2 = self._gather_trunk(g2_all, index, bs, tags_in, t_out)
             drop_t = engine.DropCfg(drop.p, drop.seed, 3) if drop else None
         M = bs * t_out
         xin = ws.mat("xin", M, FEAT)
@@ -559,6 +576,39 @@ def build_optimizer(args, model):
 # ---------------------------------------------------------------------------------------------
 # rollout + update  (finetune/ppo.py:501-617, 844-883)
 # ---------------------------------------------------------------------------------------------
+class _Side:
+    """The critic's HIP stream beside the actor's.  Actor and critic share nothing between the inputs and the PPO loss, and
+    nothing again between the loss and the end of the step, so their launches may interleave: the critic's HBM-bound
+    out_layer.fc1 passes (forward 2 GB, fused gradient + AdamW 12 GB) run beside the actor's MFMA-bound token GEMMs and the
+    other way round, and partial last rounds of one model's launches are filled by the other's.  Same kernels, same order
+    per model, same bits.  LR2_PPO_STREAMS=0 puts everything back on one stream."""
+    _streams: Dict[int, "torch.cuda.Stream"] = {}
+
+    def __init__(self, device):
+        self.on = os.environ.get("LR2_PPO_STREAMS", "1") != "0" and device.type == "cuda"
+        if self.on:
+            key = device.index if device.index is not None else torch.cuda.current_device()
+            if key not in _Side._streams:
+                _Side._streams[key] = torch.cuda.Stream(device=device)
+            self.side = _Side._streams[key]
+            self.main = torch.cuda.current_stream(device)
+
+    def fork_point(self):
+        """Work issued on the side stream from now on starts after everything issued on the main stream SO FAR (and not after
+        what the main stream is given later)."""
+        if self.on:
+            self.side.wait_stream(self.main)
+
+    def run(self):
+        """-> context manager: work issued inside goes to the side stream."""
+        return torch.cuda.stream(self.side) if self.on else contextlib.nullcontext()
+
+    def join(self):
+        """What follows on the main stream sees everything issued on the side stream so far."""
+        if self.on:
+            self.main.wait_stream(self.side)
+
+
 @torch.no_grad()
 def rollout_step(model, reward_model, text_emb, img_emb, tgts, state=None):
     """One timestep of the rollout loop (finetune/ppo.py:844-883) -> the 8-entry memory record."""
@@ -566,12 +616,19 @@ def rollout_step(model, reward_model, text_emb, img_emb, tgts, state=None):
     dev = text_emb.device
     if state is None:
         state = torch.arange(tags, device=dev).unsqueeze(0).repeat(bs, 1)
+    # the critic beside the actor and the reward model (host order stays actor, critic, reward: a train-mode caller draws its
+    # dropout seeds in call order).  A third stream for the reward model's trunk, which needs the actor's ordering only at its
+    # end, was measured: no further gain (18.35 vs 18.20 ms per step).
+    side = _Side(dev)
+    side.fork_point()
     logits = model.actor.engine_forward(text_emb, img_emb, save=False)
-    value = model.critic.engine_forward(text_emb, img_emb, state, save=False)
+    with side.run():
+        value = model.critic.engine_forward(text_emb, img_emb, state, save=False)
     scores, _ = model.actor.action_scores(logits, bs, tags)
     _, order = torch.sort(scores, dim=-1, descending=True)
     next_state = torch.cat([torch.arange(2, device=dev).unsqueeze(0).repeat(bs, 1), torch.gather(state, 1, order)], dim=1)
     rewards = reward_model.engine_forward(text_emb, img_emb, next_state, save=False)
+    side.join()
     return [state, next_state, scores.clone(), rewards, value, text_emb, img_emb, tgts]
 
 
@@ -647,8 +704,12 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
     bs, tags = old_scores.shape[:2]
     scal, per = torch.empty(4, device=dev), torch.empty(4, bs, device=dev)
     dscores, dvalue = torch.empty(bs, tags, device=dev), torch.empty(bs, device=dev)
-    logits = actor.engine_forward(text, img, save=True)
-    value = critic.engine_forward(text, img, state, save=True)
+    side = _Side(dev)
+    side.fork_point()
+    logits = actor.engine_forward(text, img, save=True)         # host order actor, critic: the order the dropout seeds are drawn in
+    with side.run():
+        value = critic.engine_forward(text, img, state, save=True)
+    side.join()
     loss_kw = dict(B=bs, T=tags, kl_w=args.kl_div_loss_weight, ent_w=args.entropy_weight, value_clip=args.value_clip,
                    margin=0.01, adv_eps=-0.1)
     scores, probs = actor.action_scores(logits, bs, tags, want_probs=True)
@@ -672,14 +733,21 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
     if probs is not None:        # 'cls': chain d loss / d scores through the expected-label softmax to the class logits
         dscores = ops.cls_scores_bwd(probs, scores.view(-1), dscores.view(-1), torch.empty_like(probs), rows=bs * tags,
                                      C=actor.n_out)
+    side.fork_point()
     actor.engine_backward(dscores, dp, fc1_update=fa)
     wa = dp.reduce_start(actor)            # overlaps the critic's backward
-    critic.engine_backward(dvalue, dp, fc1_update=fc)
-    wc = dp.reduce_start(critic)
+    with side.run():                       # the critic's backward, gradient exchange and optimizer step beside the actor's
+        critic.engine_backward(dvalue, dp, fc1_update=fc)
+        wc = dp.reduce_start(critic)
+        if side.on:
+            dp.finish(wc)
+            critic_optim.step()
     dp.finish(wa)
     optimizer.step()
-    dp.finish(wc)
-    critic_optim.step()
+    if not side.on:
+        dp.finish(wc)
+        critic_optim.step()
+    side.join()
     pm = per.mean(dim=1)
     metrics = torch.stack([scal[0], scal[1], pm[0], old_value.mean(), value.mean(), rewards.mean(), pm[2], pm[3], scal[2],
                            pm[1]])

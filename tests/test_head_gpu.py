@@ -362,11 +362,13 @@ def test_ndcg_gate_256_items_after_two_update_cycles(dev):
     assert abs(float(vals) - float(ref[5])) <= 0.002
 
 
-def test_full_batch_properties(dev):
+def test_full_batch_properties(dev, monkeypatch):
     """BASELINE-size batch (32 items x 2 tags), where the CPU oracle is too slow to be the checker: size-independent
     properties of the HIP path.  (1) determinism: the same rollout twice gives the same bits; (2) items are independent:
     permuting the batch permutes scores / values / rewards bit for bit; (3) an update at lr = 0 leaves every weight
-    untouched while still producing finite metrics; (4) the fused and the separate out_layer.fc1 update agree bit for bit."""
+    untouched while still producing finite metrics; (4) the fused and the separate out_layer.fc1 update agree bit for bit;
+    (5) the multi-stream schedule (critic / reward trunk beside the actor) and the single-stream one (LR2_PPO_STREAMS=0)
+    agree bit for bit, rollout and update."""
     import copy
     from lr2ppo_amd import runtime
     from lr2ppo_amd.finetune import ppo
@@ -386,6 +388,11 @@ def test_full_batch_properties(dev):
     rec2 = ppo.rollout_step(model, reward, text, img, tgts)
     for a, b in zip(rec[1:5], rec2[1:5]):
         assert torch.equal(a, b)                                           # (1)
+    monkeypatch.setenv("LR2_PPO_STREAMS", "0")
+    rec1s = ppo.rollout_step(model, reward, text, img, tgts)
+    monkeypatch.delenv("LR2_PPO_STREAMS")
+    for a, b in zip(rec[1:5], rec1s[1:5]):
+        assert torch.equal(a, b)                                           # (5) rollout
     perm = torch.randperm(bs, generator=g).to(dev)
     recp = ppo.rollout_step(model, reward, text[perm].contiguous(), img[perm].contiguous(), tgts[perm].contiguous())
     for a, b in zip(rec[1:5], recp[1:5]):
@@ -403,16 +410,19 @@ def test_full_batch_properties(dev):
     # (4): one more cycle (lr > 0 now) from identical state, fused vs separate
     state = copy.deepcopy({"m": model.state_dict(), "o": opt.state_dict(), "c": copt.state_dict()})
     results = []
-    for fuse in (True, False):
+    for fuse, streams in ((True, "1"), (False, "1"), (True, "0")):
         model.load_state_dict(state["m"])
         opt.load_state_dict(copy.deepcopy(state["o"])), copt.load_state_dict(copy.deepcopy(state["c"]))
         args.fuse_fc1_update = fuse
+        monkeypatch.setenv("LR2_PPO_STREAMS", streams)
         runtime.set_dropout_seed(77)
-        ppo.update_minibatch(args, model, opt, copt, rec)
+        metrics = ppo.update_minibatch(args, model, opt, copt, rec)
         results.append((model.actor.out_layer.fc1.weight[:64, :512].clone(), model.critic.out_layer.fc1.weight[-64:, -512:].clone(),
-                        model.actor.head.weight.clone()))
-    for a, b in zip(*results):
-        assert torch.equal(a, b)
+                        model.actor.head.weight.clone(), model.critic.head.weight.clone(), metrics.clone()))
+    monkeypatch.delenv("LR2_PPO_STREAMS")
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert torch.equal(a, b)                                       # (4), (5) update
     assert not torch.equal(results[0][0][:8, :256], probe)                  # and the step did move the weights
 
 
