@@ -393,11 +393,15 @@ def trunk_forward(ws: Workspace, P, W, text, img, bs: int, tags: int, n_img: int
 
 
 def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *, drop: Optional[DropCfg] = None,
-                   img_shared: bool = False, dp=None, fc1_update=None):
+                   img_shared: bool = False, dp=None, fc1_update=None, fc1_early: bool = False):
     """Backward of trunk_forward(save=True); fills G[...] for every trunk parameter (inputs get no gradient:
     text/img embeddings are data, finetune/ppo.py:827-835).  dg2: fp32 [bs*tags, E].
     fc1_update (ops.AdamArgs): apply the optimizer step of out_layer.fc1.weight inside its weight-gradient GEMM, issued
-    after the last reader of the old weight (the input-gradient GEMM); G[out_layer.fc1.weight] is then left untouched."""
+    after the last reader of the old weight (the input-gradient GEMM); G[out_layer.fc1.weight] is then left untouched.
+    fc1_early: issue that fused update right behind the input-gradient GEMM instead of at the very end -- same operands, same
+    bits; a model whose backward runs on a second stream uses it so that its 12-GB HBM-bound pass falls beside the other
+    model's MFMA-bound token GEMMs instead of beside the other model's own 12-GB pass (single-rank only: with data
+    parallelism the update waits for the factor all-gather and stays last)."""
     N = bs * tags
     Mt, F = N * SEQ_LEN, 4 * E
     Mi_src = (bs if img_shared else N) * n_img
@@ -429,6 +433,15 @@ def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *
             ops.colsum(dzo, G["out_layer.fc1.bias"], ws.vec("colsum_partials", nb * F), rows=N, cols=F, nblocks=nb)
     dflat = ws.mat("dflat", N, Wflat)
     linear_dgrad(ws, dzo, P[FC1], dflat, N, Wflat, F)
+
+    def fused_fc1_update(dzo_all, flat_all, Kall, alpha):
+        skw, sp, bm = _splitk_ws(ws, F, Wflat, Kall, trans_a=True, trans_b=True)
+        ops.gemm(dzo_all, flat_all, None if fc1_update is not None else G[FC1], F, Wflat, Kall, trans_a=True, trans_b=True,
+                 lda=F, ldb=Wflat, splitk_ws=skw, splits=sp, block_m=bm, alpha=alpha, adam=fc1_update)
+
+    early = fc1_early and fc1_update is not None and fc1_pending is None
+    if early:
+        fused_fc1_update(dzo, flat, N, 1.0)
     # image part of the concat -> dense [Mi, E] gradient
     dimf_cat = ws.mat("dimf_cat", Mi, E)
     ops.gather_rows(dflat[:, SEQ_LEN * E:], None, dimf_cat.view(N, 1, n_img * E), B=N, t_in=1, t_out=1,
@@ -455,12 +468,9 @@ def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *
     dzi = ws.planes("dzi", Mi_src, F)
     linear_dgrad(ws, dimf_p, W["img_proj.fc2.weight"], None, Mi_src, F, E, act=2, aux_z=zi, out_planes=dzi)
     linear_wgrad(ws, dzi, img, G["img_proj.fc1.weight"], G["img_proj.fc1.bias"], Mi_src, E, F)
-    if fc1_pending is not None or fc1_update is not None:
+    if (fc1_pending is not None or fc1_update is not None) and not early:
         if fc1_pending is not None:
             dzo_all, flat_all = dp.gather_planes_finish(fc1_pending[0]), dp.gather_planes_finish(fc1_pending[1])
-            Kall, alpha = N * dp.world, 1.0 / dp.world            # already the rank average
+            fused_fc1_update(dzo_all, flat_all, N * dp.world, 1.0 / dp.world)            # already the rank average
         else:
-            dzo_all, flat_all, Kall, alpha = dzo, flat, N, 1.0
-        skw, sp, bm = _splitk_ws(ws, F, Wflat, Kall, trans_a=True, trans_b=True)
-        ops.gemm(dzo_all, flat_all, None if fc1_update is not None else G[FC1], F, Wflat, Kall, trans_a=True, trans_b=True,
-                 lda=F, ldb=Wflat, splitk_ws=skw, splits=sp, block_m=bm, alpha=alpha, adam=fc1_update)
+            fused_fc1_update(dzo, flat, N, 1.0)

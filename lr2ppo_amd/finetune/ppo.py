@@ -408,7 +408,7 @@ class _TailHead(_Head):
             self._saved = (text_p, img_p, bs, t_out, n_img, drop, drop_t)
         return value
 
-    def engine_backward(self, dvalue: torch.Tensor, dp=None, fc1_update=None):
+    def engine_backward(self, dvalue: torch.Tensor, dp=None, fc1_update=None, fc1_early: bool = False):
         text_g, img_g, bs, t_out, n_img, drop, drop_t = self._saved
         P, G = self._P(), self.grad_buffers()
         ws, W = self._workspace(dvalue.device), self._weights(P, refresh=False)
@@ -423,7 +423,7 @@ class _TailHead(_Head):
         G["pos_emb.weight"].zero_()
         ops.period_rows_grad(dxin, G["pos_emb.weight"], rows=M, D=FEAT, period=t_out)
         engine.trunk_backward(ws, P, W, G, text_g, img_g, dxin, bs, t_out, n_img, FEAT, drop=drop, img_shared=False, dp=dp,
-                              fc1_update=fc1_update)
+                              fc1_update=fc1_update, fc1_early=fc1_early)
         self._saved = None
 
 
@@ -737,7 +737,8 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
     actor.engine_backward(dscores, dp, fc1_update=fa)
     wa = dp.reduce_start(actor)            # overlaps the critic's backward
     with side.run():                       # the critic's backward, gradient exchange and optimizer step beside the actor's
-        critic.engine_backward(dvalue, dp, fc1_update=fc)
+        # (its out_layer.fc1 update first, the actor's last: the two HBM-bound passes fall beside the other model's GEMMs)
+        critic.engine_backward(dvalue, dp, fc1_update=fc, fc1_early=side.on and os.environ.get("LR2_FC1_EARLY", "1") != "0")
         wc = dp.reduce_start(critic)
         if side.on:
             dp.finish(wc)

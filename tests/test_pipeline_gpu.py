@@ -170,3 +170,4 @@ def test_stage1_pointwise_step_from_raw_inputs_at_reference_shape(dev):
     model.train()
     loss1 = pointwise.train_model(args, model, opt, sch, text_emb, img_emb, tgts)
     assert float(loss1) == float(loss1) and not torch.equal(w0, model.head.weight.detach())
+
