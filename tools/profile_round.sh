@@ -10,9 +10,15 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 S="python3 $R/tools/rocprof_summary.py"
-echo "== kernel trace of the bench (10 PPO steps)"
+# bench.py runs W warm-up + 3 host-enqueue + K timed steps, and (default schedule only) 1 + 4 single-stream steps for the
+# exclusive timing of the dominant launch: 2 + 3 + 8 + 5 = 18 steps in the default trace, 13 in the --serial-streams one.
+echo "== kernel trace of the bench, ONE stream (exclusive per-kernel durations: what roofline.avg_launch_ms must agree with)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online --serial-streams > $O/bench_under_kernel_trace_serial.json 2> $O/kts.err || exit 1
+$S kernel-trace $O/kts --steps 13 --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online --serial-streams ($TAG; 13 PPO steps, one HIP stream)" --md $O/${TAG}_bench_kernel_trace_serial.md --json $O/${TAG}_bench_kernel_trace_serial.json || exit 1
+rm -rf $O/kts
+echo "== kernel trace of the bench, default two-stream schedule (overlapped durations: roofline.in_timed_region)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online > $O/bench_under_kernel_trace.json 2> $O/kt.err || exit 1
-$S kernel-trace $O/kt --steps 10 --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online ($TAG)" --md $O/${TAG}_bench_kernel_trace.md --json $O/${TAG}_bench_kernel_trace.json || exit 1
+$S kernel-trace $O/kt --steps 18 --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online ($TAG; 18 PPO steps: 13 on two streams, 5 on one)" --md $O/${TAG}_bench_kernel_trace.md --json $O/${TAG}_bench_kernel_trace.json || exit 1
 rm -rf $O/kt
 echo "== FETCH_SIZE pass"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile > /dev/null 2> $O/fetch.err || exit 1
