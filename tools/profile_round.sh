@@ -12,10 +12,14 @@ cd /tmp && export TMPDIR=/tmp
 S="python3 $R/tools/rocprof_summary.py"
 # bench.py runs W warm-up + 3 host-enqueue + K timed steps, and (default schedule only) 1 + 4 single-stream steps for the
 # exclusive timing of the dominant launch: 2 + 3 + 8 + 5 = 18 steps in the default trace, 13 in the --serial-streams one.
+echo "== warm-up (discarded: the first process on a fresh box pages the image in and finds the chip cold)"
+python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-online > /dev/null 2>&1
 echo "== kernel trace of the bench, ONE stream (exclusive per-kernel durations: what roofline.avg_launch_ms must agree with)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online --serial-streams > $O/bench_under_kernel_trace_serial.json 2> $O/kts.err || exit 1
 $S kernel-trace $O/kts --steps 13 --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online --serial-streams ($TAG; 13 PPO steps, one HIP stream)" --md $O/${TAG}_bench_kernel_trace_serial.md --json $O/${TAG}_bench_kernel_trace_serial.json || exit 1
 rm -rf $O/kts
+echo "== plain bench on the same box, right after the exclusive trace"
+python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_same_box.json 2> $O/bench.err
 echo "== kernel trace of the bench, default two-stream schedule (overlapped durations: roofline.in_timed_region)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online > $O/bench_under_kernel_trace.json 2> $O/kt.err || exit 1
 $S kernel-trace $O/kt --steps 18 --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online ($TAG; 18 PPO steps: 13 on two streams, 5 on one)" --md $O/${TAG}_bench_kernel_trace.md --json $O/${TAG}_bench_kernel_trace.json || exit 1
@@ -36,6 +40,4 @@ echo "== encoder forward: MFMA counters"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/enc_pmc -- python3 $R/tools/encoder_bench.py --ppo-shapes --iters 1 > /dev/null 2> $O/enc_pmc.err || exit 1
 $S pmc $O/enc_pmc --title "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python3 tools/encoder_bench.py --ppo-shapes --iters 1 ($TAG)" --md $O/${TAG}_encoder_pmc_mfma.md --json $O/${TAG}_encoder_pmc_mfma.json || exit 1
 rm -rf $O/enc_pmc
-echo "== plain bench on the same box"
-python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_same_box.json 2> $O/bench.err
 ls -la $O
