@@ -20,6 +20,7 @@ namespace {
 
 constexpr int HD = 64;          // head dim
 constexpr int ROW_B = HD * 2;   // bytes of one K / V row in one LDS plane
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 // Dropout on the attention probabilities (multi_headed_attn.py:72): element (b, h, q, key) of the [B, H, L, L] tensor
 // is kept iff dropout_keep(key, flat index, thr); thr == 0 switches it off.
@@ -44,6 +45,128 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* plane, int row_a, int ro
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
   const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// One 16-query sub-tile against the K / V planes resident in LDS: S^T = K Q^T (MFMA), fp32 softmax in the log2 domain,
+// O = P V (MFMA), rows stored through the wave's LDS slab.  qh / ql: the sub-tile's query fragments.
+template <int NT>
+__device__ __forceinline__ void attn_subtile_fwd(const char* sK, const char* sV, const float* sMask, float* slab,
+                                                 const bf16x8_t (&qh)[2], const bf16x8_t (&ql)[2], int sub, int lane, int L, int b,
+                                                 int h, int heads, size_t row0, int col0, float scale, float* __restrict__ lse,
+                                                 const DropP& dr, float* __restrict__ O, bf16_t* __restrict__ Oh, size_t o_lo_off,
+                                                 int ld_o) {
+  constexpr int PLANE = 16 * NT * ROW_B;
+  const int qn = lane & 15, g = lane >> 4;
+  const int q_row = sub * 16 + qn;
+  // ---- S^T tiles: acc[t][r] = S[query qn][key 16t + 4g + r] ----
+  f32x4_t s[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r = 16 * t + qn;          // A fragment: key row 16t + (l & 15), hd 8g + 32ks ..
+      const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(sK + k_off(r, g + 4 * ks));
+      const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(sK + PLANE + k_off(r, g + 4 * ks));
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], acc, 0, 0, 0);
+    }
+    s[t] = acc;
+  }
+
+  // ---- softmax over the keys of query qn: in-lane over (t, r), across the 4 lanes l, l^16, l^32, l^48 ----
+  float mx = -INFINITY;
+  const float scale2 = scale * LOG2E;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float4 mk = *reinterpret_cast<const float4*>(sMask + 16 * t + 4 * g);
+    s[t][0] = __builtin_fmaf(s[t][0], scale2, mk.x);
+    s[t][1] = __builtin_fmaf(s[t][1], scale2, mk.y);
+    s[t][2] = __builtin_fmaf(s[t][2], scale2, mk.z);
+    s[t][3] = __builtin_fmaf(s[t][3], scale2, mk.w);
+    mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - mx);     // padded keys: 2^(-inf) = 0
+      sum += s[t][r];
+    }
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  if (lse && g == 0 && q_row < L) lse[((size_t)b * heads + h) * L + q_row] = mx * LN2 + logf(sum);
+  const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_row < L ? q_row : 0)) * (uint64_t)L;
+
+  // ---- O = (P~ V) / sum over 32-key blocks, P~ = the un-normalised exponentials in (0, 1]: fragments straight from the
+  // accumulators (permuted contraction index); the 1 / sum goes onto the 16 output values instead of the NT * 4 probabilities
+  f32x4_t o[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+#pragma unroll
+  for (int u = 0; u < NT / 2; ++u) {
+    float p[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = s[2 * u][r];
+      p[4 + r] = s[2 * u + 1][r];
+    }
+    if (dr.thr) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p[r] *= drop_mul(dr, drow + 32 * u + 4 * g + r);
+        p[4 + r] *= drop_mul(dr, drow + 32 * u + 16 + 4 * g + r);
+      }
+    }
+    const uint32_t h01 = cvt_pk_bf16(p[0], p[1]), h23 = cvt_pk_bf16(p[2], p[3]);
+    const uint32_t h45 = cvt_pk_bf16(p[4], p[5]), h67 = cvt_pk_bf16(p[6], p[7]);
+    const uint32_t l01 = cvt_pk_bf16(p[0] - __uint_as_float(h01 << 16), p[1] - __uint_as_float(h01 & 0xffff0000u));
+    const uint32_t l23 = cvt_pk_bf16(p[2] - __uint_as_float(h23 << 16), p[3] - __uint_as_float(h23 & 0xffff0000u));
+    const uint32_t l45 = cvt_pk_bf16(p[4] - __uint_as_float(h45 << 16), p[5] - __uint_as_float(h45 & 0xffff0000u));
+    const uint32_t l67 = cvt_pk_bf16(p[6] - __uint_as_float(h67 << 16), p[7] - __uint_as_float(h67 & 0xffff0000u));
+    const bf16x8_t ph = __builtin_bit_cast(bf16x8_t, (u32x4_t{h01, h23, h45, h67}));
+    const bf16x8_t pl = __builtin_bit_cast(bf16x8_t, (u32x4_t{l01, l23, l45, l67}));
+    // transposed V reads: lane (tq, tp) of a 16-lane group supplies row base + tq, hd 16n + 4tp .. +3
+    const int ra = 32 * u + 4 * g + tq, rb = ra + 16;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int unit = 2 * n + (tp >> 1), half8 = 8 * (tp & 1);
+      const bf16x8_t vh = tr_pair(sV, ra, rb, unit, half8);
+      const bf16x8_t vl = tr_pair(sV + PLANE, ra, rb, unit, half8);
+      o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh, o[n], 0, 0, 0);
+      o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl, o[n], 0, 0, 0);
+      o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh, o[n], 0, 0, 0);
+    }
+  }
+
+  // ---- o[n][r] = O[query 4g + r][hd 16n + (l & 15)] -> LDS slab -> 16-B row-contiguous stores ----
+  float inv_q[4];                         // 1 / sum of query 4g + r (lane 4g + r holds it: its own query is l & 15)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) inv_q[r] = __shfl(inv, 4 * g + r, 64);
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slab[(4 * g + r) * (HD + 4) + 16 * n + qn] = o[n][r] * inv_q[r];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = pass * 4 + (lane >> 4), c = (lane & 15) * 4;
+    const int qr = sub * 16 + r;
+    if (qr < L) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + r * (HD + 4) + c);
+      const size_t off = (row0 + qr) * (size_t)ld_o + col0 + c;
+      if (O) *reinterpret_cast<float4*>(O + off) = v;
+      if (Oh) store_planes4(Oh + off, o_lo_off, v);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 
 template <int NT, int NW>   // NT = key tiles of 16 (even), LP = 16 * NT padded keys; NW = waves per workgroup
@@ -119,121 +242,19 @@ __global__ __launch_bounds__(64 * NW) void self_attn_mfma_kernel(const bf16_t* _
       }
     }
   }
-  for (int j = tid; j < LP; j += 64 * NW) sMask[j] = j < L ? ((seg[row0 + j] > 0) ? 0.f : -10000.0f) : -INFINITY;
+  // additive key mask, pre-multiplied by log2(e): the softmax below works on t = s * scale * log2(e) + mask * log2(e)
+  // (2^(t - max t) = e^(s' - max s')), one fma + one v_exp_f32 per score instead of fma, multiply and v_exp_f32
+  for (int j = tid; j < LP; j += 64 * NW) sMask[j] = j < L ? ((seg[row0 + j] > 0) ? 0.f : -10000.0f * LOG2E) : -INFINITY;
 
   __syncthreads();
   // K / V stay resident; each wave walks over 16-query sub-tiles (blockIdx.x strides them when the grid splits the queries)
   for (int sub = sub_first; sub < n_sub; sub += sub_step) {
-  const int q_row = sub * 16 + qn;
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) { qh[ks] = qh_next[ks]; ql[ks] = ql_next[ks]; }
   load_q(sub + sub_step, qh_next, ql_next);     // next sub-tile's queries travel while this one is computed
 
-  // ---- S^T tiles: acc[t][r] = S[query qn][key 16t + 4g + r] ----
-  f32x4_t s[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int r = 16 * t + qn;          // A fragment: key row 16t + (l & 15), hd 8g + 32ks ..
-      const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(sK + k_off(r, g + 4 * ks));
-      const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(sK + PLANE + k_off(r, g + 4 * ks));
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], acc, 0, 0, 0);
-    }
-    s[t] = acc;
-  }
-
-  // ---- softmax over the keys of query qn: in-lane over (t, r), across the 4 lanes l, l^16, l^32, l^48 ----
-  float mx = -INFINITY;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const float4 mk = *reinterpret_cast<const float4*>(sMask + 16 * t + 4 * g);
-    s[t][0] = s[t][0] * scale + mk.x;
-    s[t][1] = s[t][1] * scale + mk.y;
-    s[t][2] = s[t][2] * scale + mk.z;
-    s[t][3] = s[t][3] * scale + mk.w;
-    mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
-  }
-  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-  float sum = 0.f;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      s[t][r] = exp_fast(s[t][r] - mx);     // padded keys: exp(-inf) = 0
-      sum += s[t][r];
-    }
-  }
-  sum += __shfl_xor(sum, 16, 64);
-  sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.0f / sum;
-  if (lse && g == 0 && q_row < L) lse[((size_t)b * heads + h) * L + q_row] = mx + logf(sum);
-  const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_row < L ? q_row : 0)) * (uint64_t)L;
-
-  // ---- O = P V over 32-key blocks; P fragments straight from the accumulators (permuted contraction index) ----
-  f32x4_t o[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
-#pragma unroll
-  for (int u = 0; u < NT / 2; ++u) {
-    float p[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      p[r] = s[2 * u][r] * inv;
-      p[4 + r] = s[2 * u + 1][r] * inv;
-    }
-    if (dr.thr) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        p[r] *= drop_mul(dr, drow + 32 * u + 4 * g + r);
-        p[4 + r] *= drop_mul(dr, drow + 32 * u + 16 + 4 * g + r);
-      }
-    }
-    const uint32_t h01 = cvt_pk_bf16(p[0], p[1]), h23 = cvt_pk_bf16(p[2], p[3]);
-    const uint32_t h45 = cvt_pk_bf16(p[4], p[5]), h67 = cvt_pk_bf16(p[6], p[7]);
-    const uint32_t l01 = cvt_pk_bf16(p[0] - __uint_as_float(h01 << 16), p[1] - __uint_as_float(h01 & 0xffff0000u));
-    const uint32_t l23 = cvt_pk_bf16(p[2] - __uint_as_float(h23 << 16), p[3] - __uint_as_float(h23 & 0xffff0000u));
-    const uint32_t l45 = cvt_pk_bf16(p[4] - __uint_as_float(h45 << 16), p[5] - __uint_as_float(h45 & 0xffff0000u));
-    const uint32_t l67 = cvt_pk_bf16(p[6] - __uint_as_float(h67 << 16), p[7] - __uint_as_float(h67 & 0xffff0000u));
-    const bf16x8_t ph = __builtin_bit_cast(bf16x8_t, (u32x4_t{h01, h23, h45, h67}));
-    const bf16x8_t pl = __builtin_bit_cast(bf16x8_t, (u32x4_t{l01, l23, l45, l67}));
-    // transposed V reads: lane (tq, tp) of a 16-lane group supplies row base + tq, hd 16n + 4tp .. +3
-    const int ra = 32 * u + 4 * g + tq, rb = ra + 16;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int unit = 2 * n + (tp >> 1), half8 = 8 * (tp & 1);
-      const bf16x8_t vh = tr_pair(sV, ra, rb, unit, half8);
-      const bf16x8_t vl = tr_pair(sV + PLANE, ra, rb, unit, half8);
-      o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh, o[n], 0, 0, 0);
-      o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl, o[n], 0, 0, 0);
-      o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh, o[n], 0, 0, 0);
-    }
-  }
-
-  // ---- o[n][r] = O[query 4g + r][hd 16n + (l & 15)] -> LDS slab -> 16-B row-contiguous stores ----
-  float* slab = sOut + wave * 16 * (HD + 4);
-#pragma unroll
-  for (int n = 0; n < 4; ++n)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) slab[(4 * g + r) * (HD + 4) + 16 * n + qn] = o[n][r];
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int r = pass * 4 + (lane >> 4), c = (lane & 15) * 4;
-    const int qr = sub * 16 + r;
-    if (qr < L) {
-      const float4 v = *reinterpret_cast<const float4*>(slab + r * (HD + 4) + c);
-      const size_t off = (row0 + qr) * (size_t)ld_o + col0 + c;
-      if (O) *reinterpret_cast<float4*>(O + off) = v;
-      if (Oh) store_planes4(Oh + off, o_lo_off, v);
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
+  attn_subtile_fwd<NT>(sK, sV, sMask, sOut + wave * 16 * (HD + 4), qh, ql, sub, lane, L, b, h, heads, row0, col0, scale, lse, dr,
+                       O, Oh, o_lo_off, ld_o);
   }  // sub-tile loop
 }
 

@@ -289,10 +289,9 @@ def test_self_attn_bwd_matches_autograd(ops, dev, batch, heads, L, drop_p):
     for name, lo in (("dQ", 0), ("dK", E), ("dV", 2 * E)):
         ref = x.grad[:, lo:lo + E]
         _close(got[:, lo:lo + E], ref, 3e-5 * max(1.0, float(ref.abs().max())), 5e-5, name)
-    if L <= 256:
-        assert torch.equal(ws1, lse)
-    else:                               # blocked kernels: the running max / sum is updated in a different order
-        _close(ws1, lse.double().cpu(), 1e-5, 1e-5, "lse (backward sweep 1)")
+    # the backward recomputes the statistics itself (natural-log domain, or block by block for L > 256; the forward works in
+    # the log2 domain): equal to rounding
+    _close(ws1, lse.double().cpu(), 1e-5, 1e-5, "lse (backward)")
 
 
 # ------------------------------------------------------------------------------------- small ops
