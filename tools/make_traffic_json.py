@@ -11,7 +11,9 @@ import sys
 d, tag = sys.argv[1], sys.argv[2]
 f = json.load(open(os.path.join(d, f"{tag}_bench_pmc_fetch.json")))
 w = json.load(open(os.path.join(d, f"{tag}_bench_pmc_write.json")))
-kt = json.load(open(os.path.join(d, f"{tag}_bench_kernel_trace.json")))
+# exclusive per-kernel durations: the --serial-streams trace when the round has one (the default schedule overlaps two streams)
+_kt = os.path.join(d, f"{tag}_bench_kernel_trace_serial.json")
+kt = json.load(open(_kt if os.path.exists(_kt) else os.path.join(d, f"{tag}_bench_kernel_trace.json")))
 key = lambda r: (r["kernel"], r["workgroups"], r["workgroup_size"])  # noqa: E731
 W, K = {key(r): r for r in w}, {key(r): r for r in kt}
 by_label, by_sig = {}, {}
@@ -33,5 +35,6 @@ print(json.dumps({
     "_method": "tools/profile_round.sh " + tag + ": rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) on "
                "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile`, summarised per dispatch signature by "
                "tools/rocprof_summary.py; counters are KiB; read bytes = 2 x FETCH_SIZE (gfx950, 16-B/lane streaming reads), WRITE_SIZE as "
-               "is.  kernel_trace_* come from the kernel-trace pass of the SAME gpurun call (same box), 10 PPO steps.",
+               "is.  kernel_trace_* come from the `--serial-streams` kernel-trace pass of the SAME gpurun call (same box, 13 PPO steps on one "
+               "HIP stream: exclusive per-launch durations).",
     "by_bench_label": by_label, "by_dispatch_signature": by_sig}, indent=1))
