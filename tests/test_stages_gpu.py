@@ -177,3 +177,44 @@ def test_trad_classifier_dropout_and_autograd_match_oracle(dev):
         ref = Pg[n].grad
         err = (p.grad.cpu() - ref).abs().max().item()
         assert err < 1e-6 + 2e-3 * ref.abs().max().item(), f"grad {n}: {err} vs {ref.abs().max().item()}"
+
+
+def test_stage1_cls_mode_train_step_and_evaluate_match_oracle(dev):
+    """finetune/pointwise.py with --mode cls (:228-232, :342-345): one train_model step at lr 0 (first scheduler step) --
+    NLL loss and gradients against the oracle's autograd with the dropout masks pinned --, then evaluate's class-weighted raw
+    logits.  (The oracle's cls head is pinned to the reference by tests/golden/cls_step.npz.)"""
+    from lr2ppo_amd import ops, runtime
+    from lr2ppo_amd.finetune import pointwise as pw
+    bs, tags = 2, 3
+    P = O.seeded_params(O.head_param_spec("actor", n_out=3), seed=51)
+    with torch.no_grad():
+        P["head.weight"] *= 30.0
+    text, img, _ = O.seeded_head_inputs(5100, bs, tags)
+    tgts = torch.tensor([[0, 2, 1], [1, 1, 0]])
+    args = _args(dev, fuse_fc1_update=False)
+    args.mode = "cls"
+    model = pw.Classifier(args, None)
+    model.load_state_dict(P, strict=True)
+    model = model.to(dev).train()
+    assert model.n_out == 3
+    opt, sch = pw.build_optimizer(args, model)
+    runtime.set_dropout_seed(777, calls=2)
+    seed = runtime.peek_drop_seed()
+    loss = pw.train_model(args, model, opt, sch, text.to(dev), img.to(dev), tgts.to(dev))
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref_loss, ref_logits = O.actor_forward_cls(Pg, text, img, tgts, drop={"p": 0.1, "seed": seed, "site_base": 0})
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss.detach())) < 1e-4 * max(1.0, abs(float(ref_loss.detach())))
+    G = model.grad_buffers()
+    for n in ["text_proj.fc1.weight", "img_proj.fc2.bias", "xit.0.0.0.fn.1.queries.weight", "out_layer.fc1.weight",
+              "out_layer.fc2.weight", "head.weight", "head.bias"]:
+        ref_g = Pg[n].grad
+        err = (G[n].cpu().view_as(ref_g) - ref_g).abs().max().item()
+        assert err < 1e-6 + 2e-3 * ref_g.abs().max().item(), f"grad {n}: {err} vs scale {ref_g.abs().max().item()}"
+    # evaluate's score (pointwise.py:342-345): 0 * z0 + 1 * z1 + 2 * z2 on the raw logits, no softmax
+    model.eval()
+    with torch.no_grad():
+        logits = model.engine_forward(text.to(dev), img.to(dev), save=False)
+        score = ops.cls_scores(logits, None, torch.empty(bs * tags, device=dev), rows=bs * tags, C=3, softmax=False).cpu()
+        want = O.cls_action_scores(O.actor_forward_cls(P, text, img), bs, tags, softmax=False).view(-1)
+    assert (score - want).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))
