@@ -557,8 +557,8 @@ __device__ __forceinline__ void store_tile_planes(const f32x4_t (&o)[4], float* 
 // in the transposed layout (lane = one query, 4 keys per 16-key tile):
 //   S^T = K Q^T, P = softmax;  dPd^T = V dO^T;  dP = dPd o M;  D = sum_k dP P;  dS = P (dP - D) * scale;  dQ = dS K
 // (M = dropout keep / (1 - p)).  dQ goes to columns [h*64, h*64+64) of the dQKV planes matrix.
-template <int NT>
-__global__ __launch_bounds__(256) void self_attn_bwd_dq_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void self_attn_bwd_dq_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
                                                                const bf16_t* __restrict__ Vh, size_t lo_off, int ld,
                                                                const bf16_t* __restrict__ dOh, size_t do_lo_off, int ld_do,
                                                                const int64_t* __restrict__ seg, bf16_t* __restrict__ dQh,
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dq_kernel(const bf16_t* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t row0 = (size_t)b * L;
   const int col0 = h * HD;
-  for (int i = tid; i < LP * 8; i += 256) {
+  for (int i = tid; i < LP * 8; i += 64 * NW) {
     const int r = i >> 3, u = i & 7;
     u32x4_t kh = {0, 0, 0, 0}, kl = kh, vh = kh, vl = kh;
     if (r < L) {
@@ -591,11 +591,11 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dq_kernel(const bf16_t* __r
     *reinterpret_cast<u32x4_t*>(sV + k_off(r, u)) = vh;
     *reinterpret_cast<u32x4_t*>(sV + PLANE + k_off(r, u)) = vl;
   }
-  for (int j = tid; j < LP; j += 256) sMask[j] = j < L ? ((seg[row0 + j] > 0) ? 0.f : -10000.0f) : -INFINITY;
+  for (int j = tid; j < LP; j += 64 * NW) sMask[j] = j < L ? ((seg[row0 + j] > 0) ? 0.f : -10000.0f) : -INFINITY;
   const int qn = lane & 15, g = lane >> 4;
   __syncthreads();
   const int n_sub = (L + 15) >> 4;
-  for (int sub = blockIdx.x * 4 + wave; sub < n_sub; sub += gridDim.x * 4) {
+  for (int sub = blockIdx.x * NW + wave; sub < n_sub; sub += gridDim.x * NW) {
   const int q_row = sub * 16 + qn;
   const bool q_ok = q_row < L;
   bf16x8_t qh[2], ql[2], gh[2], gl[2];
@@ -690,8 +690,8 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dq_kernel(const bf16_t* __r
 // registers) and walks over the queries in the NON-transposed layout (lane = one key, 4 queries per 16-query tile):
 //   S = Q K^T, P = exp(S - lse[q]);  dPd = dO V^T;  Pd = P o M, dP = dPd o M, dS = P (dP - D[q]) * scale
 //   dV = Pd^T dO,  dK = dS^T Q       (contraction over queries: P / dS tiles reused as A fragments, Q / dO transposed reads)
-template <int NT>
-__global__ __launch_bounds__(256) void self_attn_bwd_dkv_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void self_attn_bwd_dkv_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
                                                                 const bf16_t* __restrict__ Vh, size_t lo_off, int ld,
                                                                 const bf16_t* __restrict__ dOh, size_t do_lo_off, int ld_do,
                                                                 const int64_t* __restrict__ seg, bf16_t* __restrict__ dKh,
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dkv_kernel(const bf16_t* __
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t row0 = (size_t)b * L;
   const int col0 = h * HD;
-  for (int i = tid; i < LP * 8; i += 256) {
+  for (int i = tid; i < LP * 8; i += 64 * NW) {
     const int r = i >> 3, u = i & 7;
     u32x4_t a = {0, 0, 0, 0}, c = a, d = a, e = a;
     if (r < L) {
@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dkv_kernel(const bf16_t* __
     *reinterpret_cast<u32x4_t*>(sG + k_off(r, u)) = d;
     *reinterpret_cast<u32x4_t*>(sG + PLANE + k_off(r, u)) = e;
   }
-  for (int j = tid; j < LP; j += 256) {
+  for (int j = tid; j < LP; j += 64 * NW) {
     const size_t si = ((size_t)b * heads + h) * L + j;
     sLse[j] = j < L ? lse[si] : INFINITY;     // padded queries: P = exp(-inf) = 0
     sD[j] = j < L ? dsum[si] : 0.f;
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dkv_kernel(const bf16_t* __
   const int kn = lane & 15, g = lane >> 4;
   __syncthreads();
   const int n_sub = (L + 15) >> 4;
-  for (int sub = blockIdx.x * 4 + wave; sub < n_sub; sub += gridDim.x * 4) {
+  for (int sub = blockIdx.x * NW + wave; sub < n_sub; sub += gridDim.x * NW) {
   const int key = sub * 16 + kn;
   const bool k_ok = key < L;
   bf16x8_t kh[2], kl[2], vh[2], vl[2];
@@ -1139,17 +1139,21 @@ template <int NT>
 int launch_bwd(const AttnArgs& a, const bf16_t* go, size_t do_lo_off, int ld_do, bf16_t* dq, bf16_t* dk, bf16_t* dv,
                size_t d_lo_off, int ld_d, float* lse, float* dsum) {
   constexpr int LP = 16 * NT;
-  const size_t lds1 = (size_t)4 * LP * ROW_B + (size_t)LP * 4 + (size_t)4 * 16 * (HD + 4) * 4;
-  const size_t lds2 = (size_t)4 * LP * ROW_B + (size_t)LP * 8 + (size_t)4 * 16 * (HD + 4) * 4;
+  constexpr int NW = NT <= 14 ? 8 : 4;          // two waves per SIMD where the K / V (Q / dO) planes + 8 output slabs fit the LDS
+  const size_t lds1 = (size_t)4 * LP * ROW_B + (size_t)LP * 4 + (size_t)NW * 16 * (HD + 4) * 4;
+  const size_t lds2 = (size_t)4 * LP * ROW_B + (size_t)LP * 8 + (size_t)NW * 16 * (HD + 4) * 4;
   static bool done1 = false, done2 = false;
-  if (allow_lds_once(self_attn_bwd_dq_kernel<NT>, lds1, done1, "self_attn_bwd_dq")) return LR2_ERR_LAUNCH;
-  if (allow_lds_once(self_attn_bwd_dkv_kernel<NT>, lds2, done2, "self_attn_bwd_dkv")) return LR2_ERR_LAUNCH;
-  const dim3 grid(attn_chunks(a.batch, a.heads, a.L), a.heads, a.batch);
-  LR2_LAUNCH(self_attn_bwd_dq_kernel<NT>, grid, dim3(256), lds1, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, go, do_lo_off, ld_do,
-             a.seg, dq, d_lo_off, ld_d, lse, dsum, a.heads, a.L, a.scale, a.dr);
+  if (allow_lds_once(self_attn_bwd_dq_kernel<NT, NW>, lds1, done1, "self_attn_bwd_dq")) return LR2_ERR_LAUNCH;
+  if (allow_lds_once(self_attn_bwd_dkv_kernel<NT, NW>, lds2, done2, "self_attn_bwd_dkv")) return LR2_ERR_LAUNCH;
+  const int n_sub = (a.L + 15) / 16, max_chunks = (n_sub + NW - 1) / NW;
+  int chunks = attn_chunks(a.batch, a.heads, a.L);
+  if (chunks > max_chunks) chunks = max_chunks;
+  const dim3 grid(chunks, a.heads, a.batch);
+  LR2_LAUNCH((self_attn_bwd_dq_kernel<NT, NW>), grid, dim3(64 * NW), lds1, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, go, do_lo_off,
+             ld_do, a.seg, dq, d_lo_off, ld_d, lse, dsum, a.heads, a.L, a.scale, a.dr);
   if (lr2_launch_status("lr2_self_attn_bwd(dq)")) return LR2_ERR_LAUNCH;
-  LR2_LAUNCH(self_attn_bwd_dkv_kernel<NT>, grid, dim3(256), lds2, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, go, do_lo_off, ld_do,
-             a.seg, dk, dv, d_lo_off, ld_d, (const float*)lse, (const float*)dsum, a.heads, a.L, a.scale, a.dr);
+  LR2_LAUNCH((self_attn_bwd_dkv_kernel<NT, NW>), grid, dim3(64 * NW), lds2, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, go, do_lo_off,
+             ld_do, a.seg, dk, dv, d_lo_off, ld_d, (const float*)lse, (const float*)dsum, a.heads, a.L, a.scale, a.dr);
   return lr2_launch_status("lr2_self_attn_bwd(dkv)");
 }
 
@@ -1176,10 +1180,10 @@ int launch_bwd_blocked(const AttnArgs& a, const bf16_t* go, size_t do_lo_off, in
   template __global__ void self_attn_mfma_kernel<NT, (NT <= 14 ? 8 : 4)>(const bf16_t*, const bf16_t*, const bf16_t*, size_t,  \
                                                                          int, const int64_t*, float*, bf16_t*, size_t, int,   \
                                                                          int, int, float, float*, DropP);                      \
-  template __global__ void self_attn_bwd_dq_kernel<NT>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int, const bf16_t*, \
+  template __global__ void self_attn_bwd_dq_kernel<NT, (NT <= 14 ? 8 : 4)>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int, const bf16_t*, \
                                                        size_t, int, const int64_t*, bf16_t*, size_t, int, float*, float*, int,  \
                                                        int, float, DropP);                                                     \
-  template __global__ void self_attn_bwd_dkv_kernel<NT>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int,               \
+  template __global__ void self_attn_bwd_dkv_kernel<NT, (NT <= 14 ? 8 : 4)>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int,               \
                                                         const bf16_t*, size_t, int, const int64_t*, bf16_t*, bf16_t*, size_t,   \
                                                         int, const float*, const float*, int, int, float, DropP);
 LR2_SA_INST(4)
