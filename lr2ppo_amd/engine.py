@@ -474,3 +474,42 @@ def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *
             fused_fc1_update(dzo_all, flat_all, N * dp.world, 1.0 / dp.world)            # already the rank average
         else:
             fused_fc1_update(dzo, flat, N, 1.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# The `_trad` trunk: the head at sequence length 1 (finetune/pointwise_trad.py:146-157, ppo_trad.py:160-171)
+# ---------------------------------------------------------------------------------------------
+TRAD_FC1, TRAD_FC2 = "out_layer.fc1.weight", "out_layer.fc2.weight"
+
+
+def trad_trunk_forward(ws: Workspace, P, W, x0: torch.Tensor, N: int, E: int, *, save: bool, drop: Optional[DropCfg] = None):
+    """x0 [N, E]: one pre-projected feature per document, used as both streams of the XiT block, concatenated behind the
+    block's output, through out_layer = Mlp(2E, 4E, E) -> g2 [N, E] (workspace buffer "g2")."""
+    F = 4 * E
+    cat = ws.planes("cat", N, 2 * E)                         # [XiT(x0, x0) | x0]
+    ops.copy_rows(x0, cat, rows=N, D=E, group=1, dst_gstride=2 * E, dst_off=E)
+    xit_forward(ws, "xit.", P, W, XIT, x0, x0, N, 1, 1, E, cat, save=save, drop=drop, out_group=1, out_gstride=2 * E)
+    g1 = ws.planes("g1", N, F)
+    zo = ws.mat("zo", N, F) if save else None
+    linear_fwd(ws, cat, fwd_weight(W, TRAD_FC1), P["out_layer.fc1.bias"], None, N, F, 2 * E, act=1, out_z=zo, out_planes=g1)
+    g2 = ws.mat("g2", N, E)
+    linear_fwd(ws, g1, W[TRAD_FC2], P["out_layer.fc2.bias"], g2, N, E, F)
+    return g2
+
+
+def trad_trunk_backward(ws: Workspace, P, W, G, x0: torch.Tensor, dg2: torch.Tensor, N: int, E: int, *,
+                        drop: Optional[DropCfg] = None):
+    """Backward of trad_trunk_forward(save=True): fills G[...] for xit.* and out_layer.* (the feature is data: no input
+    gradient is returned)."""
+    F = 4 * E
+    cat, g1, zo = ws.planes("cat", N, 2 * E), ws.planes("g1", N, F), ws.mat("zo", N, F)
+    dg2p = ops.split_planes(dg2, ws.planes("dg2p", N, E))
+    linear_wgrad(ws, dg2p, g1, G[TRAD_FC2], G["out_layer.fc2.bias"], N, F, E)
+    dzo = ws.planes("dzo", N, F)
+    linear_dgrad(ws, dg2p, W[TRAD_FC2], None, N, F, E, act=2, aux_z=zo, out_planes=dzo)
+    linear_wgrad(ws, dzo, cat, G[TRAD_FC1], G["out_layer.fc1.bias"], N, 2 * E, F)
+    dcat = ws.mat("dcat", N, 2 * E)
+    linear_dgrad(ws, dzo, W[TRAD_FC1], dcat, N, 2 * E, F)
+    # only the block's parameters need gradients; d(out) / d(block output) = dcat[:, :E]
+    xit_backward(ws, "xit.", P, W, G, XIT, x0, x0, dcat, N, 1, 1, E, ws.mat("dx0", N, E), None, drop=drop, out_group=1,
+                 out_gstride=2 * E, same_xy=True)

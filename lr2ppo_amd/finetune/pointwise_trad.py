@@ -74,19 +74,10 @@ class Classifier(nn.Module):
             self._ws = engine.Workspace(dev)
         ws, P = self._ws, self._P()
         W = self._weights(P)
-        N, E, F = text_emb.shape[0] * text_emb.shape[1], FEAT, 4 * FEAT
+        N, E = text_emb.shape[0] * text_emb.shape[1], FEAT
         x0 = text_emb.contiguous().view(N, E)
         drop = runtime.next_drop(engine.DROP_P, 0) if self.training else None
-        cat = ws.planes("cat", N, 2 * E)                         # [XiT(x0, x0) | x0]  (pointwise_trad.py:154-155)
-        ops.copy_rows(x0, cat, rows=N, D=E, group=1, dst_gstride=2 * E, dst_off=E)
-        engine.xit_forward(ws, "xit.", P, W, engine.XIT, x0, x0, N, 1, 1, E, cat, save=save, drop=drop, out_group=1,
-                           out_gstride=2 * E)
-        g1 = ws.planes("g1", N, F)
-        zo = ws.mat("zo", N, F) if save else None
-        engine.linear_fwd(ws, cat, engine.fwd_weight(W, OUT_FC1), P["out_layer.fc1.bias"], None, N, F, 2 * E, act=1, out_z=zo,
-                          out_planes=g1)
-        g2 = ws.mat("g2", N, E)
-        engine.linear_fwd(ws, g1, W[OUT_FC2], P["out_layer.fc2.bias"], g2, N, E, F)
+        g2 = engine.trad_trunk_forward(ws, P, W, x0, N, E, save=save, drop=drop)
         logits = torch.empty(N, device=dev)
         ops.head_fwd(g2, P["head.weight"], P["head.bias"], logits, rows=N, D=E)
         if save:
@@ -98,20 +89,11 @@ class Classifier(nn.Module):
         x0, N, drop = self._saved
         ws, P, G = self._ws, self._P(), self.grad_buffers()
         W = self._wp.planes
-        E, F = FEAT, 4 * FEAT
-        cat, g1, zo, g2 = ws.planes("cat", N, 2 * E), ws.planes("g1", N, F), ws.mat("zo", N, F), ws.mat("g2", N, E)
+        E = FEAT
+        g2 = ws.mat("g2", N, E)
         dg2 = ws.mat("dg2", N, E)
         ops.head_bwd(g2, P["head.weight"], dlogits.contiguous().view(-1), dg2, G["head.weight"], G["head.bias"], rows=N, D=E)
-        dg2p = ops.split_planes(dg2, ws.planes("dg2p", N, E))
-        engine.linear_wgrad(ws, dg2p, g1, G[OUT_FC2], G["out_layer.fc2.bias"], N, F, E)
-        dzo = ws.planes("dzo", N, F)
-        engine.linear_dgrad(ws, dg2p, W[OUT_FC2], None, N, F, E, act=2, aux_z=zo, out_planes=dzo)
-        engine.linear_wgrad(ws, dzo, cat, G[OUT_FC1], G["out_layer.fc1.bias"], N, 2 * E, F)
-        dcat = ws.mat("dcat", N, 2 * E)
-        engine.linear_dgrad(ws, dzo, W[OUT_FC1], dcat, N, 2 * E, F)
-        # the feature is data: only the block's parameters need gradients; d(out)/d(block output) = dcat[:, :E]
-        engine.xit_backward(ws, "xit.", P, W, G, engine.XIT, x0, x0, dcat, N, 1, 1, E, ws.mat("dx0", N, E), None, drop=drop,
-                            out_group=1, out_gstride=2 * E, same_xy=True)
+        engine.trad_trunk_backward(ws, P, W, G, x0, dg2, N, E, drop=drop)
         self._saved = None
 
     def forward(self, text_emb, img_emb=None, tgts=None):

@@ -152,9 +152,13 @@ class Mlp(nn.Module):
 
 
 class _Head(nn.Module):
-    """Shared machinery of Actor / Critic / Reward: parameters, flat gradient buffer, workspace, engine calls."""
+    """Shared machinery of Actor / Critic / Reward: parameters, flat gradient buffer, workspace, engine calls.
+    TRAD = True (finetune/ppo_trad.py here and upstream, :142-281): the same heads at sequence length 1 -- no text_proj /
+    img_proj, the [bs, tags, 768] document feature is both streams of the XiT block and is concatenated behind its output,
+    out_layer = Mlp(2 * 768, 3072, 768); img_emb is ignored."""
     has_tail = False
     fixed_positions: Optional[int] = None
+    TRAD = False
 
     def __init__(self, args, vit_args=None):
         super().__init__()
@@ -162,19 +166,23 @@ class _Head(nn.Module):
         self.labels_num = args.labels_num
         if self.mode not in ("reg", "cls"):
             raise ValueError(f"mode must be 'reg' or 'cls' (finetune/ppo.py:209-212), got {self.mode!r}")
-        if args.visual_feat_dim != FEAT:
-            raise ValueError("visual_feat_dim must be 768 (hard-coded in the reference, finetune/ppo.py:202-208)")
-        self.seq_length, self.max_imgs = args.seq_length, args.max_imgs
-        if self.seq_length != SEQ_LEN:
-            raise ValueError("seq_length must be 196 (hard-coded in the reference, finetune/ppo.py:219-220)")
-        self.text_proj = Mlp(FEAT, FEAT * 4, FEAT, nn.GELU, 0)
-        self.img_proj = Mlp(FEAT, FEAT * 4, FEAT, nn.GELU, 0)
+        if not self.TRAD:
+            if args.visual_feat_dim != FEAT:
+                raise ValueError("visual_feat_dim must be 768 (hard-coded in the reference, finetune/ppo.py:202-208)")
+            self.seq_length, self.max_imgs = args.seq_length, args.max_imgs
+            if self.seq_length != SEQ_LEN:
+                raise ValueError("seq_length must be 196 (hard-coded in the reference, finetune/ppo.py:219-220)")
+            self.text_proj = Mlp(FEAT, FEAT * 4, FEAT, nn.GELU, 0)
+            self.img_proj = Mlp(FEAT, FEAT * 4, FEAT, nn.GELU, 0)
         if self.has_tail:
             self.pos_emb = nn.Embedding(4, FEAT)
         self.xit = XiT(feat_size=FEAT)
         if self.has_tail:
             self.xitt = XiT(feat_size=FEAT, attention_mask="causal")
-        self.out_layer = Mlp((args.seq_length + args.max_imgs) * args.visual_feat_dim, FEAT * 4, FEAT, nn.GELU, 0)
+        if self.TRAD:
+            self.out_layer = Mlp(2 * FEAT, FEAT * 4, FEAT, nn.GELU, 0)               # ppo_trad.py:150
+        else:
+            self.out_layer = Mlp((args.seq_length + args.max_imgs) * args.visual_feat_dim, FEAT * 4, FEAT, nn.GELU, 0)
         # 'cls': the ACTOR scores through a labels_num-way classifier (finetune/ppo.py:209-210); Critic / Reward keep 768 -> 1
         self.n_out = self.labels_num if (self.mode == "cls" and not self.has_tail) else 1
         if self.n_out > 8:
@@ -212,8 +220,13 @@ class _Head(nn.Module):
         """bf16 hi/lo planes of the token-GEMM weights (everything but the 2 GB out_layer.fc1), re-split from the
         fp32 parameters at the start of every forward."""
         if self._wp is None or not self._wp.matches(P):
-            names = engine.TRUNK_GEMM_WEIGHTS + (engine.XITT.gemm_weights() if self.has_tail else [])
-            tnames = engine.TRUNK_T_WEIGHTS + ([engine.XITT.f1_w] if self.has_tail else [])
+            if self.TRAD:
+                names = engine.XIT.gemm_weights() + [engine.TRAD_FC1, engine.TRAD_FC2]
+                tnames = [engine.XIT.f1_w, engine.TRAD_FC1]
+            else:
+                names, tnames = list(engine.TRUNK_GEMM_WEIGHTS), list(engine.TRUNK_T_WEIGHTS)
+            if self.has_tail:
+                names, tnames = names + engine.XITT.gemm_weights(), tnames + [engine.XITT.f1_w]
             self._wp = engine.WeightPlanes(P, names, transposed=tnames)
             refresh = True
         if refresh:
@@ -230,7 +243,8 @@ class _Head(nn.Module):
         if self._G is not None and self._flat_grad.device == dev:
             return self._G
         named = dict(self.named_parameters())
-        order = [n for n in self.GRAD_ORDER_FIRST if n in named] + [n for n in named if n not in self.GRAD_ORDER_FIRST]
+        first = () if self.TRAD else self.GRAD_ORDER_FIRST     # `_trad`: no 2-GB matrix, every gradient goes through the all-reduce
+        order = [n for n in first if n in named] + [n for n in named if n not in first]
         total = sum((named[n].numel() + 3) // 4 * 4 for n in order)
         self._flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self._G, off = {}, 0
@@ -239,7 +253,7 @@ class _Head(nn.Module):
             k = named[n].numel()
             self._G[n] = self._flat_grad[off:off + k].view_as(named[n])
             off += (k + 3) // 4 * 4
-            if n == self.GRAD_ORDER_FIRST[-1]:
+            if first and n == first[-1]:
                 self._bucket_split = off
         return self._G
 
@@ -267,6 +281,15 @@ class _Head(nn.Module):
         text2 = text_emb.contiguous().view(bs * tags * SEQ_LEN, FEAT)
         return engine.input_planes(text_emb, text2), engine.input_planes(img_emb, img2), bs, tags, n_img, shared
 
+    def _prep_trad(self, text_emb):
+        """[bs, tags, 768] document features -> ([bs*tags, 768] fp32 view, bs, tags) (ppo_trad.py:160-166)."""
+        if text_emb.dtype != torch.float32 or not text_emb.is_cuda:
+            raise TypeError("lr2ppo_amd: text_emb must be a float32 tensor on the HIP device (no CPU path)")
+        if text_emb.dim() != 3 or text_emb.shape[-1] != FEAT:
+            raise ValueError(f"text_emb must be [bs, tags, {FEAT}] (ppo_trad.py:160-166)")
+        bs, tags = text_emb.shape[:2]
+        return text_emb.contiguous().view(bs * tags, FEAT), bs, tags
+
     def _drop_cfg(self, site_base=0):
         return runtime.next_drop(engine.DROP_P, site_base) if self.training else None
 
@@ -287,11 +310,18 @@ class Actor(_Head):
         return _SmoothL1Fn.apply(logits, tgts.reshape(-1).to(torch.float32).contiguous()), logits
 
     def engine_forward(self, text_emb, img_emb, *, save: bool) -> torch.Tensor:
-        text2, img2, bs, tags, n_img, shared = self._prep_inputs(text_emb, img_emb)
         ws, P = self._workspace(text_emb.device), self._P()
-        W = self._weights(P)
-        drop = self._drop_cfg(0)
-        g2 = engine.trunk_forward(ws, P, W, text2, img2, bs, tags, n_img, FEAT, save=save, drop=drop, img_shared=shared)
+        if self.TRAD:
+            x0, bs, tags = self._prep_trad(text_emb)
+            W = self._weights(P)
+            drop = self._drop_cfg(0)
+            g2 = engine.trad_trunk_forward(ws, P, W, x0, bs * tags, FEAT, save=save, drop=drop)
+            text2, img2, n_img, shared = x0, None, 0, False
+        else:
+            text2, img2, bs, tags, n_img, shared = self._prep_inputs(text_emb, img_emb)
+            W = self._weights(P)
+            drop = self._drop_cfg(0)
+            g2 = engine.trunk_forward(ws, P, W, text2, img2, bs, tags, n_img, FEAT, save=save, drop=drop, img_shared=shared)
         if self.n_out == 1:
             logits = torch.empty(bs * tags, device=text_emb.device)
             ops.head_fwd(g2, P["head.weight"], P["head.bias"], logits, rows=bs * tags, D=FEAT)
@@ -315,8 +345,13 @@ class Actor(_Head):
         else:
             ops.cls_head_bwd(g2, P["head.weight"], dlogits.contiguous().view(N, self.n_out), dg2, G["head.weight"], G["head.bias"],
                              rows=N, D=FEAT, C=self.n_out)
-        engine.trunk_backward(ws, P, W, G, text2, img2, dg2, bs, tags, n_img, FEAT, drop=drop, img_shared=shared, dp=dp,
-                              fc1_update=fc1_update)
+        if self.TRAD:
+            if fc1_update is not None:
+                raise ValueError("the fused out_layer.fc1 update belongs to the 2-GB matrix of the full heads; pass fuse_fc1_update=False")
+            engine.trad_trunk_backward(ws, P, W, G, text2, dg2, N, FEAT, drop=drop)
+        else:
+            engine.trunk_backward(ws, P, W, G, text2, img2, dg2, bs, tags, n_img, FEAT, drop=drop, img_shared=shared, dp=dp,
+                                  fc1_update=fc1_update)
         self._saved = None
 
     def action_scores(self, logits: torch.Tensor, bs: int, tags: int, want_probs: bool = False):
@@ -376,8 +411,18 @@ class _TailHead(_Head):
         self._n_pos(t_out)
         ws, P = self._workspace(dev), self._P()
         W = self._weights(P)
-        n_img = img_emb.shape[-2]
-        if save:
+        n_img = 0 if self.TRAD else img_emb.shape[-2]
+        if self.TRAD:
+            # sequence length 1 (ppo_trad.py:214-232): gather the document features by index, then the trunk
+            x_all, _, _ = self._prep_trad(text_emb)
+            text_p = ws.mat("x_g", bs * t_out, FEAT)
+            ops.gather_rows(x_all.view(bs, tags_in, FEAT), index, text_p.view(bs, t_out, FEAT), B=bs, t_in=tags_in, t_out=t_out,
+                            row_elems=FEAT)
+            img_p = None
+            drop = self._drop_cfg(0)
+            g2 = engine.trad_trunk_forward(ws, P, W, text_p, bs * t_out, FEAT, save=save, drop=drop)
+            drop_t = engine.DropCfg(drop.p, drop.seed, 3) if drop else None
+        elif save:
             # train mode: gather the inputs by index exactly like the reference (ppo.py:267-271), then run the trunk
             shared_in = engine._img_shared(img_emb)
             text_g = ws.mat("text_g", bs * t_out * SEQ_LEN, FEAT)
@@ -422,8 +467,13 @@ class _TailHead(_Head):
                             drop=drop_t, same_xy=True)
         G["pos_emb.weight"].zero_()
         ops.period_rows_grad(dxin, G["pos_emb.weight"], rows=M, D=FEAT, period=t_out)
-        engine.trunk_backward(ws, P, W, G, text_g, img_g, dxin, bs, t_out, n_img, FEAT, drop=drop, img_shared=False, dp=dp,
-                              fc1_update=fc1_update, fc1_early=fc1_early)
+        if self.TRAD:
+            if fc1_update is not None:
+                raise ValueError("the fused out_layer.fc1 update belongs to the 2-GB matrix of the full heads; pass fuse_fc1_update=False")
+            engine.trad_trunk_backward(ws, P, W, G, text_g, dxin, M, FEAT, drop=drop)
+        else:
+            engine.trunk_backward(ws, P, W, G, text_g, img_g, dxin, bs, t_out, n_img, FEAT, drop=drop, img_shared=False, dp=dp,
+                                  fc1_update=fc1_update, fc1_early=fc1_early)
         self._saved = None
 
 
@@ -727,7 +777,7 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
     # out_layer.fc1.weight (96 % of each model): gradient GEMM and AdamW step in one kernel, the 2 GB gradient is never
     # materialised (args.fuse_fc1_update=False restores the separate wgrad + optimizer passes; same bits either way)
     fuse = getattr(args, "fuse_fc1_update", True) and hasattr(optimizer, "external_update") \
-        and hasattr(critic_optim, "external_update")
+        and hasattr(critic_optim, "external_update") and not actor.TRAD          # (`_trad` heads have no 2-GB matrix to fuse)
     fa = optimizer.external_update(actor.out_layer.fc1.weight) if fuse else None
     fc = critic_optim.external_update(critic.out_layer.fc1.weight) if fuse else None
     if probs is not None:        # 'cls': chain d loss / d scores through the expected-label softmax to the class logits
@@ -786,7 +836,7 @@ def evaluate(args, val_loader, step, split="test", num_tasks=None):
     scores, golds = [], []
     for text_emb, img_emb, tgts in val_loader:
         text_emb = text_emb.to(args.device)
-        img_emb = img_emb.to(args.device)            # [1, n_img, 768]: shared by all tags of the item
+        img_emb = img_emb.to(args.device) if img_emb is not None else None   # [1, n_img, 768]: shared by all tags (None: `_trad`)
         logits = args.model.actor.engine_forward(text_emb, img_emb, save=False)
         if args.model.actor.n_out > 1:               # 'cls': 0 * z0 + 1 * z1 + 2 * z2 on the RAW logits, as upstream (ppo.py:641-643)
             logits = ops.cls_scores(logits, None, torch.empty(logits.shape[0], device=logits.device), rows=logits.shape[0],

@@ -762,6 +762,61 @@ def gen_trad():
     _save("trad_step.npz", **arrays)
 
 
+def gen_ppo_trad():
+    """finetune/ppo_trad.py (the stage-3 twin at sequence length 1): Actor / Critic / Reward forwards, the rollout
+    record and two train_model cycles (cycle 1 at lr 0, cycle 2 one warm-up step in), dropout off -- 3 queries x 2 documents."""
+    import ppo_trad as pt
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    bs, tags = 3, 2
+    args = _ns(mode="reg", labels_num=3, is_master=False, kl_div_loss_weight=0.001, entropy_weight=0.001, value_clip=0.5,
+               optimizer="adamw", scheduler="linear", learning_rate=1e-3, critic_learning_rate=1e-3, train_steps=41, warmup=0.1,
+               device=torch.device("cpu"))
+    model = pt.ActorCritic(args, None)
+    reward = pt.Reward(args, None).eval()
+    for mod, kind in ((model.actor, "actor"), (model.critic, "critic"), (reward, "reward")):
+        assert _spec_of(mod) == [[n, list(sh)] for n, sh in O.trad_head_param_spec(kind)], kind
+    _load(model.actor, O.seeded_params(O.trad_head_param_spec("actor"), seed=37))
+    _load(model.critic, O.seeded_params(O.trad_head_param_spec("critic"), seed=38))
+    _load(reward, O.seeded_params(O.trad_head_param_spec("reward"), seed=39))
+    opt, copt, sch, csch = pt.build_optimizer(args, model)
+    model.eval()          # dropout off; train_model itself never toggles the mode
+    sample_names = ["actor.xit.0.0.0.fn.1.queries.weight", "actor.out_layer.fc1.weight", "actor.out_layer.fc2.bias",
+                    "actor.head.weight", "critic.pos_emb.weight", "critic.xit.0.0.1.fn.1.0.weight",
+                    "critic.xitt.0.0.0.fn.1.values.weight", "critic.out_layer.fc1.weight", "critic.head.bias"]
+    named = dict(model.named_parameters())
+    sample_idx = _sampled(named, sample_names, 377)
+    arrays = {"bs": np.array(bs), "tags": np.array(tags)}
+    for n in sample_names:
+        arrays["idx." + n] = sample_idx[n]
+    g = torch.Generator().manual_seed(40)
+    for cycle in range(2):
+        arrays[f"lr_{cycle}"] = np.array([opt.param_groups[0]["lr"], copt.param_groups[0]["lr"]])
+        memories = []
+        for mb in range(2):
+            text = torch.randn(bs, tags, 768, generator=g)
+            tgts = torch.randint(0, 3, (bs, tags), generator=g)
+            with torch.no_grad():
+                state = torch.arange(tags).unsqueeze(0).repeat(bs, 1)
+                _, logits = model.actor(text, None, tgts)
+                value = model.critic(text, None, tgts, state)
+                scores = logits.view(bs, tags)
+                nxt = O.rollout_next_state(scores, state)
+                r = reward(text, None, tgts, nxt)
+            k = f"c{cycle}_mb{mb}_"
+            arrays[k + "text"], arrays[k + "tgts"] = text.clone(), tgts.clone()
+            arrays[k + "scores"], arrays[k + "value"] = scores.clone(), value.clone()
+            arrays[k + "reward"], arrays[k + "next_state"] = r.clone(), nxt.clone()
+            memories.append([state.clone(), nxt.clone(), scores.clone(), r.clone(), value.clone(), text.clone(), tgts.clone()])
+        out = pt.train_model(args, model, opt, copt, sch, csch, memories, 1)
+        arrays[f"metrics_{cycle}"] = torch.stack([torch.as_tensor(float(x)) for x in out])
+        for n in sample_names:
+            arrays[f"w{cycle}." + n] = named[n].detach().flatten()[sample_idx[n]].clone()
+    _save("ppo_trad_step.npz", **arrays)
+
+
 def gen_encoder_full():
     """ViT-B/16 and RoBERTa-base stacks from the shipped JSON configs, seeded weights, eval."""
     from tencentpretrain.embeddings import Embedding, str2embedding
@@ -814,7 +869,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls, ppo_trad=gen_ppo_trad)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -636,3 +636,48 @@ def trad_forward(P: Params, text_emb: torch.Tensor, tgts=None, drop=None):
     if tgts is None:
         return logits
     return smooth_l1(logits.view(-1), tgts.view(-1).to(torch.float32)), logits
+
+
+def trad_head_param_spec(kind: str, feat: int = FEAT, n_out: int = 1):
+    """(name, shape) list of finetune/ppo_trad.py's Actor (:143-156) / Critic (:193-205) / Reward (:240-252), in module
+    declaration order: [pos_emb,] xit, [xitt,] out_layer = Mlp(2 * 768, 3072, 768), head."""
+    spec = []
+    if kind in ("critic", "reward"):
+        spec += [("pos_emb.weight", (4, feat))]
+    spec += _xit_spec("xit", feat)
+    if kind in ("critic", "reward"):
+        spec += _xit_spec("xitt", feat)
+    spec += _mlp_spec("out_layer", 2 * feat, 4 * feat, feat)
+    spec += [("head.weight", (n_out, feat)), ("head.bias", (n_out,))]
+    return spec
+
+
+def trad_trunk(P: Params, text_emb: torch.Tensor, drop=None) -> torch.Tensor:
+    """ppo_trad.py:160-171: [bs, tags, 768] -> [bs, tags, 768]; the feature is both streams of the XiT block and is
+    concatenated behind its output."""
+    bs, tags = text_emb.shape[:2]
+    f = text_emb.to(torch.float32).reshape(bs * tags, 1, FEAT)
+    x = xit(P, "xit", f, f, drop=drop)
+    x = mlp(P, "out_layer", torch.cat([x, f], dim=1).reshape(bs * tags, -1))
+    return x.view(bs, tags, FEAT)
+
+
+def trad_actor_forward(P: Params, text_emb, tgts=None, drop=None):
+    """ppo_trad.Actor.forward, mode 'reg' (:158-183): logits [bs*tags] (+ SmoothL1 loss with targets)."""
+    logits = linear(P, "head", trad_trunk(P, text_emb, drop)).view(-1)
+    if tgts is None:
+        return logits
+    return smooth_l1(logits, tgts.view(-1).to(torch.float32)), logits
+
+
+def trad_critic_forward(P: Params, text_emb, index, n_pos: Optional[int] = None, drop=None):
+    """ppo_trad.Critic.forward (:207-236); Reward.forward (:254-281) is the same with pos_emb(arange(4)) (n_pos=4)."""
+    bs = text_emb.shape[0]
+    bi = torch.arange(bs).view(bs, 1)
+    x = trad_trunk(P, text_emb[bi, index], drop)
+    tags = x.shape[1]
+    n_pos = tags if n_pos is None else n_pos
+    x = x + P["pos_emb.weight"][:n_pos].unsqueeze(0)
+    drop2 = None if drop is None else dict(drop, site_base=int(drop.get("site_base", 0)) + 3)
+    x = xit(P, "xitt", x, x, drop2)
+    return linear(P, "head", x)[:, -1].reshape(bs)

@@ -185,6 +185,15 @@ def test_stage1_stage2_modules_mirror_the_reference_surface():
     from lr2ppo_amd.finetune import pointwise as pw, pointwise_trad as pt, reward_pair_dataloader as rp
     for n in ("Mlp", "Classifier", "load_or_initialize_parameters", "build_optimizer", "train_model"):
         assert hasattr(pt, n), n
+    from lr2ppo_amd.finetune import ppo_trad
+    from oracle import lr2ppo_oracle as O
+    for n in ("RankLoss", "ActorCritic", "Actor", "Critic", "Reward", "load_or_initialize_parameters",
+              "load_or_initialize_parameters_reward", "build_optimizer", "clipped_value_loss", "train_model", "evaluate"):
+        assert hasattr(ppo_trad, n), n                                       # finetune/ppo_trad.py's public names
+    a = argparse.Namespace(mode="reg", labels_num=3)
+    for cls_, kind in ((ppo_trad.Actor, "actor"), (ppo_trad.Critic, "critic"), (ppo_trad.Reward, "reward")):
+        m = cls_(a, None)
+        assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == O.trad_head_param_spec(kind)   # pinned by gen_ppo_trad
     for n in ("get_scores", "log_sig", "get_def_cls", "MovieNet", "Mlp", "Classifier", "load_or_initialize_parameters",
               "build_optimizer", "train_model", "evaluate", "get_dataloader", "main"):
         assert hasattr(pw, n), n

@@ -401,3 +401,23 @@ def test_cls_mode_oracle_matches_reference():
         ref = g[key]
         got = Pg[n].grad.flatten()[g["idx.actor." + n]]
         assert (got - ref).abs().max() < 1e-6 + 2e-4 * float(ref.abs().max()), n
+
+
+def test_ppo_trad_oracle_matches_reference():
+    """finetune/ppo_trad.py's Actor / Critic / Reward at sequence length 1 (trad_actor_forward, trad_critic_forward) against
+    the imported reference's rollout tensors at the initial weights (ppo_trad_step.npz, cycle 0)."""
+    g = load_golden("ppo_trad_step.npz")
+    bs, tags = int(g["bs"]), int(g["tags"])
+    Pa = O.seeded_params(O.trad_head_param_spec("actor"), seed=37)
+    Pc = O.seeded_params(O.trad_head_param_spec("critic"), seed=38)
+    Pr = O.seeded_params(O.trad_head_param_spec("reward"), seed=39)
+    state = torch.arange(tags).unsqueeze(0).repeat(bs, 1)
+    for mb in range(2):
+        k = f"c0_mb{mb}_"
+        with torch.no_grad():
+            scores = O.trad_actor_forward(Pa, g[k + "text"]).view(bs, tags)
+            value = O.trad_critic_forward(Pc, g[k + "text"], state)
+            nxt = O.rollout_next_state(scores, state)
+            r = O.trad_critic_forward(Pr, g[k + "text"], nxt, n_pos=4)
+        assert (scores - g[k + "scores"]).abs().max() < 2e-5 and (value - g[k + "value"]).abs().max() < 2e-5
+        assert torch.equal(nxt, g[k + "next_state"]) and (r - g[k + "reward"]).abs().max() < 2e-5

@@ -218,3 +218,82 @@ def test_stage1_cls_mode_train_step_and_evaluate_match_oracle(dev):
         score = ops.cls_scores(logits, None, torch.empty(bs * tags, device=dev), rows=bs * tags, C=3, softmax=False).cpu()
         want = O.cls_action_scores(O.actor_forward_cls(P, text, img), bs, tags, softmax=False).view(-1)
     assert (score - want).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))
+
+
+def test_ppo_trad_two_cycles_match_reference_golden(dev):
+    """finetune/ppo_trad.py (stage 3 at sequence length 1, 3 queries x 2 documents): rollout tensors of four
+    minibatches, the 10 metrics of two train_model cycles (lr 0, then one warm-up step in) and sampled post-step weights of
+    actor and critic against the imported reference; the modules' state_dict keys are the reference's."""
+    from lr2ppo_amd.finetune import ppo_trad as pt
+    g = load_golden("ppo_trad_step.npz")
+    bs, tags = int(g["bs"]), int(g["tags"])
+    args = argparse.Namespace(mode="reg", labels_num=3, is_master=False, kl_div_loss_weight=0.001, entropy_weight=0.001,
+                              value_clip=0.5, optimizer="adamw", scheduler="linear", learning_rate=1e-3, critic_learning_rate=1e-3,
+                              train_steps=41, warmup=0.1, device=dev)
+    model = pt.ActorCritic(args, None)
+    reward = pt.Reward(args, None)
+    for mod, kind, seed in ((model.actor, "actor", 37), (model.critic, "critic", 38), (reward, "reward", 39)):
+        spec = O.trad_head_param_spec(kind)
+        assert [n for n, _ in mod.named_parameters()] == [n for n, _ in spec]
+        mod.load_state_dict(O.seeded_params(spec, seed=seed), strict=True)
+    model, reward = model.to(dev).eval(), reward.to(dev).eval()
+    opt, copt, sch, csch = pt.build_optimizer(args, model)
+    named = dict(model.named_parameters())
+    for cycle in range(2):
+        lrs = g[f"lr_{cycle}"]
+        assert abs(opt.param_groups[0]["lr"] - float(lrs[0])) < 1e-12 and abs(copt.param_groups[0]["lr"] - float(lrs[1])) < 1e-12
+        memories = []
+        for mb in range(2):
+            k = f"c{cycle}_mb{mb}_"
+            rec = pt.rollout_step(model, reward, g[k + "text"].to(dev), None, g[k + "tgts"].to(dev))
+            for got, key in ((rec[2], "scores"), (rec[4], "value"), (rec[3], "reward")):
+                assert (got.cpu() - g[k + key]).abs().max() < 1e-4, (cycle, mb, key)
+            assert torch.equal(rec[1].cpu(), g[k + "next_state"])
+            memories.append(rec)
+        out = pt.train_model(args, model, opt, copt, sch, csch, memories, 1)
+        for i, (a, b) in enumerate(zip(out, g[f"metrics_{cycle}"].tolist())):
+            assert abs(a - b) < 1e-4, f"cycle {cycle} metric {i}: {a} vs {b}"
+        for key in [k for k in g if k.startswith(f"w{cycle}.")]:
+            n = key[len(f"w{cycle}."):]
+            w = named[n].detach().flatten()[g["idx." + n].to(dev)].cpu()
+            assert (w - g[key]).abs().max() < 2e-6, f"weights {n} after cycle {cycle}"
+    assert out[2] > 0.0          # KL becomes non-zero only after the first real update
+
+
+def test_ppo_trad_train_mode_gradients_match_oracle(dev):
+    """Dropout on: critic value and every sampled gradient of the seq-len-1 critic (trunk + pos_emb + second XiT + head)
+    against the oracle's autograd with the masks pinned; evaluate() over SyntheticLTR runs and returns an NDCG in [0, 1]."""
+    from lr2ppo_amd import runtime
+    from lr2ppo_amd.finetune import ppo_trad as pt
+    from torch.utils.data import DataLoader
+    bs, tags = 3, 3
+    args = argparse.Namespace(mode="reg", labels_num=3, is_master=True, device=dev)
+    spec = O.trad_head_param_spec("critic")
+    P = O.seeded_params(spec, seed=71)
+    with torch.no_grad():
+        P["head.weight"] *= 30.0
+    critic = pt.Critic(args, None)
+    critic.load_state_dict(P, strict=True)
+    critic = critic.to(dev).train()
+    g = torch.Generator().manual_seed(72)
+    text = torch.randn(bs, tags, 768, generator=g)
+    index = torch.tensor([[2, 0, 1], [1, 1, 0], [0, 2, 2]])
+    runtime.set_dropout_seed(4343, calls=1)
+    seed = runtime.peek_drop_seed()
+    value = critic.engine_forward(text.to(dev), None, index.to(dev), save=True)
+    w = torch.tensor([0.7, -1.1, 0.4])
+    critic.engine_backward(w.to(dev))
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = O.trad_critic_forward(Pg, text, index, drop={"p": 0.1, "seed": seed, "site_base": 0})
+    (ref * w).sum().backward()
+    assert (value.cpu() - ref.detach()).abs().max() < 1e-3 * max(1.0, float(ref.detach().abs().max()))
+    G = critic.grad_buffers()
+    for n in ["pos_emb.weight", "xit.0.0.0.fn.1.queries.weight", "xit.1.0.weight", "xitt.0.0.0.fn.1.keys.weight",
+              "xitt.0.0.1.fn.1.3.weight", "out_layer.fc1.weight", "out_layer.fc2.bias", "head.weight", "head.bias"]:
+        ref_g = Pg[n].grad
+        err = (G[n].cpu().view_as(ref_g) - ref_g).abs().max().item()
+        assert err < 1e-6 + 2e-3 * ref_g.abs().max().item(), f"grad {n}: {err} vs scale {ref_g.abs().max().item()}"
+    model = pt.ActorCritic(args, None).to(dev)
+    args.model = model
+    ndcg = pt.evaluate(args, DataLoader(pt.SyntheticLTR(6, docs=20), batch_size=1))
+    assert 0.0 <= float(ndcg) <= 1.0
