@@ -167,14 +167,15 @@ def build_optimizer(args, model):
 def _pair_batch(text_emb, img_emb, chosen_index, reject_index):
     if chosen_index.shape != reject_index.shape or chosen_index.shape[1] != 4:
         raise ValueError("chosen_index / reject_index must both be [bs, 4] (pos_emb has 4 rows, reward_pair_dataloader.py:269)")
-    return (torch.cat([text_emb, text_emb]), torch.cat([img_emb, img_emb]),
+    return (torch.cat([text_emb, text_emb]), torch.cat([img_emb, img_emb]) if img_emb is not None else None,
             torch.cat([chosen_index, reject_index]).to(torch.int64))
 
 
 def train_model(args, model, optimizer, scheduler, text_emb_batch, img_emb_batch, tgts_batch, chosen_index_batch,
-                reject_index_batch):
+                reject_index_batch, margin: float = 1.0):
     """One batch (reward_pair_dataloader.py:347-365) -> (loss, acc) as 0-dim device tensors.  Gradients are averaged
-    over ranks before the step (upstream trains independent replicas; same deviation as stage 3)."""
+    over ranks before the step (upstream trains independent replicas; same deviation as stage 3).
+    margin: 1 upstream here; finetune/reward_trad.py:270 uses 0.01 (lr2ppo_amd.finetune.reward_trad passes it)."""
     dev = text_emb_batch.device
     bs = text_emb_batch.shape[0]
     model.bind_grads()
@@ -182,8 +183,8 @@ def train_model(args, model, optimizer, scheduler, text_emb_batch, img_emb_batch
     text2, img2, index2 = _pair_batch(text_emb_batch, img_emb_batch, chosen_index_batch, reject_index_batch)
     scores = model.engine_forward(text2, img2, index2, save=True).view(-1)
     loss_acc, dscores = torch.empty(2, device=dev), torch.empty_like(scores)
-    ops.pair_hinge(scores, loss_acc, dscores, bs=bs, margin=1.0)
-    fuse = getattr(args, "fuse_fc1_update", True) and hasattr(optimizer, "external_update")
+    ops.pair_hinge(scores, loss_acc, dscores, bs=bs, margin=margin)
+    fuse = getattr(args, "fuse_fc1_update", True) and hasattr(optimizer, "external_update") and not model.TRAD
     fa = optimizer.external_update(model.out_layer.fc1.weight) if fuse else None
     model.engine_backward(dscores, dp, fc1_update=fa)
     dp.finish(dp.reduce_start(model))
@@ -200,7 +201,8 @@ def evaluate(args, model, dataloader, step, split="test", num_tasks=None):
     counts = torch.zeros(2, device=dev, dtype=torch.float64)       # correct, samples
     for text_emb, img_emb, tgts, chosen_index, reject_index in dataloader:
         bs = text_emb.shape[0]
-        text2, img2, index2 = _pair_batch(text_emb.to(dev), img_emb.to(dev), chosen_index.to(dev), reject_index.to(dev))
+        text2, img2, index2 = _pair_batch(text_emb.to(dev), img_emb.to(dev) if img_emb is not None else None, chosen_index.to(dev),
+                                          reject_index.to(dev))
         scores = model.engine_forward(text2, img2, index2, save=False).view(-1)
         counts[0] += (scores[:bs] > scores[bs:]).sum()
         counts[1] += bs

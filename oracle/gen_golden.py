@@ -817,6 +817,42 @@ def gen_ppo_trad():
     _save("ppo_trad_step.npz", **arrays)
 
 
+def gen_reward_trad():
+    """finetune/reward_trad.py (stage 2 at sequence length 1): three train_model calls (:263-281, hinge margin 0.01), dropout
+    off: loss, acc, lr and sampled weights per step -- 3 queries x 5 documents, 4-column chosen / reject index orders."""
+    import reward_trad as rt
+    bs, docs, steps = 3, 5, 3
+    args = _ns(mode="reg", labels_num=3, is_master=False, optimizer="adamw", scheduler="linear", learning_rate=1e-3,
+               train_steps=21, warmup=0.1, device=torch.device("cpu"))
+    model = rt.Classifier(args, None)
+    assert _spec_of(model) == [[n, list(sh)] for n, sh in O.trad_head_param_spec("reward")]
+    P = O.seeded_params(O.trad_head_param_spec("reward"), seed=43)
+    P["head.weight"] = P["head.weight"] * 25.0            # scores far enough apart that the 0.01-margin hinge is not all-active
+    _load(model, P)
+    opt, sch = rt.build_optimizer(args, model)
+    model.eval()
+    named = dict(model.named_parameters())
+    names = ["pos_emb.weight", "xit.0.0.1.fn.1.0.weight", "xitt.0.0.0.fn.1.values.weight", "xitt.1.0.bias",
+             "out_layer.fc1.weight", "out_layer.fc2.bias", "head.weight"]
+    idx = _sampled(named, names, 299)
+    arrays = {"bs": np.array(bs), "docs": np.array(docs), "steps": np.array(steps)}
+    for n in names:
+        arrays["idx." + n] = idx[n]
+    g = torch.Generator().manual_seed(44)
+    for step in range(steps):
+        feats = torch.randn(bs, docs, 768, generator=g)
+        tgts = torch.randint(0, 3, (bs, docs), generator=g)
+        chosen = torch.randint(0, docs, (bs, 4), generator=g)
+        reject = torch.randint(0, docs, (bs, 4), generator=g)
+        arrays[f"feats_{step}"], arrays[f"chosen_{step}"], arrays[f"reject_{step}"] = feats, chosen, reject
+        arrays[f"lr_{step}"] = np.array(opt.param_groups[0]["lr"])
+        loss, acc = rt.train_model(args, model, opt, sch, feats, None, tgts, chosen, reject)
+        arrays[f"loss_{step}"], arrays[f"acc_{step}"] = loss.detach().clone(), acc.detach().clone()
+        for n in names:
+            arrays[f"w{step}." + n] = named[n].detach().flatten()[idx[n]].clone()
+    _save("reward_trad_step.npz", **arrays)
+
+
 def gen_encoder_full():
     """ViT-B/16 and RoBERTa-base stacks from the shipped JSON configs, seeded weights, eval."""
     from tencentpretrain.embeddings import Embedding, str2embedding
@@ -869,7 +905,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls, ppo_trad=gen_ppo_trad)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls, ppo_trad=gen_ppo_trad, reward_trad=gen_reward_trad)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

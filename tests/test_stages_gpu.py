@@ -297,3 +297,31 @@ def test_ppo_trad_train_mode_gradients_match_oracle(dev):
     args.model = model
     ndcg = pt.evaluate(args, DataLoader(pt.SyntheticLTR(6, docs=20), batch_size=1))
     assert 0.0 <= float(ndcg) <= 1.0
+
+
+def test_reward_trad_three_steps_match_reference_golden(dev):
+    """finetune/reward_trad.py (stage 2 at sequence length 1, hinge margin 0.01): loss, accuracy, lr and sampled weights of
+    three train_model steps against the imported reference; evaluate() over SyntheticTradPairs returns an accuracy."""
+    from torch.utils.data import DataLoader
+    from lr2ppo_amd.finetune import reward_trad as rt
+    g = load_golden("reward_trad_step.npz")
+    steps = int(g["steps"])
+    args = argparse.Namespace(mode="reg", labels_num=3, is_master=True, optimizer="adamw", scheduler="linear", learning_rate=1e-3,
+                              train_steps=21, warmup=0.1, device=dev)
+    model = rt.Classifier(args, None)
+    P = O.seeded_params(O.trad_head_param_spec("reward"), seed=43)
+    P["head.weight"] = P["head.weight"] * 25.0
+    model.load_state_dict(P, strict=True)
+    model = model.to(dev).eval()
+    opt, sch = rt.build_optimizer(args, model)
+    named = dict(model.named_parameters())
+    for step in range(steps):
+        assert abs(opt.param_groups[0]["lr"] - float(g[f"lr_{step}"])) < 1e-12
+        loss, acc = rt.train_model(args, model, opt, sch, g[f"feats_{step}"].to(dev), None, None, g[f"chosen_{step}"].to(dev),
+                                   g[f"reject_{step}"].to(dev))
+        ref = float(g[f"loss_{step}"])
+        assert abs(float(loss) - ref) < 1e-4 * max(1.0, abs(ref)), (step, float(loss), ref)
+        assert abs(float(acc) - float(g[f"acc_{step}"])) < 1e-6, step
+        _check_weights(g, named, step, "reward_trad")
+    acc = rt.evaluate(args, model, DataLoader(rt.SyntheticTradPairs(8, docs=6), batch_size=4))
+    assert 0.0 <= acc <= 1.0
