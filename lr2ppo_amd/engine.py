@@ -498,9 +498,10 @@ def trad_trunk_forward(ws: Workspace, P, W, x0: torch.Tensor, N: int, E: int, *,
 
 
 def trad_trunk_backward(ws: Workspace, P, W, G, x0: torch.Tensor, dg2: torch.Tensor, N: int, E: int, *,
-                        drop: Optional[DropCfg] = None):
-    """Backward of trad_trunk_forward(save=True): fills G[...] for xit.* and out_layer.* (the feature is data: no input
-    gradient is returned)."""
+                        drop: Optional[DropCfg] = None, want_dx: bool = False):
+    """Backward of trad_trunk_forward(save=True): fills G[...] for xit.* and out_layer.*.  The feature is data in
+    pointwise_trad / ppo_trad (no input gradient); want_dx (pointwise_2data_trad: the feature comes out of a projection MLP)
+    returns dL/dx0 [N, E] = the block's two input gradients + the concat's share."""
     F = 4 * E
     cat, g1, zo = ws.planes("cat", N, 2 * E), ws.planes("g1", N, F), ws.mat("zo", N, F)
     dg2p = ops.split_planes(dg2, ws.planes("dg2p", N, E))
@@ -511,5 +512,45 @@ def trad_trunk_backward(ws: Workspace, P, W, G, x0: torch.Tensor, dg2: torch.Ten
     dcat = ws.mat("dcat", N, 2 * E)
     linear_dgrad(ws, dzo, W[TRAD_FC1], dcat, N, 2 * E, F)
     # only the block's parameters need gradients; d(out) / d(block output) = dcat[:, :E]
-    xit_backward(ws, "xit.", P, W, G, XIT, x0, x0, dcat, N, 1, 1, E, ws.mat("dx0", N, E), None, drop=drop, out_group=1,
+    dx0 = ws.mat("dx0", N, E)
+    xit_backward(ws, "xit.", P, W, G, XIT, x0, x0, dcat, N, 1, 1, E, dx0, None, drop=drop, out_group=1,
                  out_gstride=2 * E, same_xy=True)
+    if want_dx:
+        dx0.add_(dcat[:, E:])
+        return dx0
+    return None
+
+
+def feature_proj_forward(ws: Workspace, P, prefix: str, x: torch.Tensor, N: int, Kin: int, E: int, *, save: bool):
+    """Mlp(Kin, 4E, E) on raw LETOR features (finetune/pointwise_2data_trad.py:135-136,147-150: 46-d MQ2008 / 136-d MSLR rows)
+    -> [N, E] fp32 (workspace buffer).  Kin is not a multiple of the GEMM's K tile: x and fc1.weight are zero-padded to
+    Kp = ceil(Kin / 64) * 64 columns (padding contributes exact zeros to every product)."""
+    F, Kp = 4 * E, -(-Kin // 64) * 64
+    t = "fp:" + prefix
+    xpad, w1pad = ws.mat(t + "x", N, Kp), ws.mat(t + "w1", F, Kp)
+    xpad.zero_(), w1pad.zero_()
+    xpad[:, :Kin].copy_(x.reshape(N, Kin))
+    w1pad[:, :Kin].copy_(P[prefix + ".fc1.weight"])
+    x_p = ops.split_planes(xpad, ws.planes(t + "x", N, Kp))
+    w1_p = ops.split_planes(w1pad, ws.planes(t + "w1", F, Kp))
+    w2_p = ops.split_planes(P[prefix + ".fc2.weight"], ws.planes(t + "w2", E, F))
+    h_p = ws.planes(t + "h", N, F)
+    z = ws.mat(t + "z", N, F) if save else None
+    linear_fwd(ws, x_p, w1_p, P[prefix + ".fc1.bias"], None, N, F, Kp, act=1, out_z=z, out_planes=h_p)
+    out = ws.mat(t + "out", N, E)
+    linear_fwd(ws, h_p, w2_p, P[prefix + ".fc2.bias"], out, N, E, F)
+    return out
+
+
+def feature_proj_backward(ws: Workspace, P, G, prefix: str, dout: torch.Tensor, N: int, Kin: int, E: int):
+    """Backward of feature_proj_forward(save=True): parameter gradients of prefix.fc1 / fc2 (the raw features are data)."""
+    F, Kp = 4 * E, -(-Kin // 64) * 64
+    t = "fp:" + prefix
+    x_p, w2_p, h_p, z = ws.planes(t + "x", N, Kp), ws.planes(t + "w2", E, F), ws.planes(t + "h", N, F), ws.mat(t + "z", N, F)
+    dout_p = ops.split_planes(dout, ws.planes(t + "dout", N, E))
+    linear_wgrad(ws, dout_p, h_p, G[prefix + ".fc2.weight"], G[prefix + ".fc2.bias"], N, F, E)
+    dz_p = ws.planes(t + "dz", N, F)
+    linear_dgrad(ws, dout_p, w2_p, None, N, F, E, act=2, aux_z=z, out_planes=dz_p)
+    dw1 = ws.mat(t + "dw1", F, Kp)
+    linear_wgrad(ws, dz_p, x_p, dw1, G[prefix + ".fc1.bias"], N, Kp, F)
+    G[prefix + ".fc1.weight"].copy_(dw1[:, :Kin])

@@ -853,6 +853,42 @@ def gen_reward_trad():
     _save("reward_trad_step.npz", **arrays)
 
 
+def gen_trad2():
+    """finetune/pointwise_2data_trad.py (BASELINE configs[0]'s 136-dim MLP ranker; 46-dim for MQ2008): four train_model steps
+    alternating the two feature widths (136, 46, 136, 46), dropout off -- loss, lr and sampled weights per step (the projection
+    a batch does not use must stay untouched: upstream its .grad is None and AdamW skips it) + an inference pass per width."""
+    import pointwise_2data_trad as p2
+    bs, docs, steps = 2, 20, 4
+    args = _ns(mode="reg", labels_num=3, optimizer="adamw", scheduler="linear", learning_rate=1e-3, train_steps=21, warmup=0.1)
+    model = p2.Classifier(args, None)
+    assert _spec_of(model) == [[n, list(sh)] for n, sh in O.trad2_param_spec()]
+    _load(model, O.seeded_params(O.trad2_param_spec(), seed=47))
+    opt, sch = p2.build_optimizer(args, model)
+    model.eval()
+    named = dict(model.named_parameters())
+    names = ["text_proj.fc1.weight", "text_proj.fc2.bias", "text_proj3.fc1.weight", "text_proj3.fc2.weight", "text_proj3.fc1.bias",
+             "xit.0.0.0.fn.1.queries.weight", "out_layer.fc1.weight", "head.weight"]
+    idx = _sampled(named, names, 477)
+    arrays = {"bs": np.array(bs), "docs": np.array(docs), "steps": np.array(steps)}
+    for n in names:
+        arrays["idx." + n] = idx[n]
+    g = torch.Generator().manual_seed(48)
+    for step in range(steps):
+        width = 136 if step % 2 == 0 else 46
+        feats = torch.randn(bs, docs, width, generator=g)
+        tgts = torch.randint(0, 3, (bs, docs), generator=g).float()
+        arrays[f"feats_{step}"], arrays[f"tgts_{step}"] = feats, tgts
+        arrays[f"lr_{step}"] = np.array(opt.param_groups[0]["lr"])
+        loss = p2.train_model(args, model, opt, sch, feats, None, tgts)
+        arrays[f"loss_{step}"] = loss.detach().clone()
+        for n in names:
+            arrays[f"w{step}." + n] = named[n].detach().flatten()[idx[n]].clone()
+    with torch.no_grad():
+        arrays["eval_logits_136"] = model(arrays["feats_0"], None, None).clone()
+        arrays["eval_logits_46"] = model(arrays["feats_1"], None, None).clone()
+    _save("trad2_step.npz", **arrays)
+
+
 def gen_encoder_full():
     """ViT-B/16 and RoBERTa-base stacks from the shipped JSON configs, seeded weights, eval."""
     from tencentpretrain.embeddings import Embedding, str2embedding
@@ -905,7 +941,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls, ppo_trad=gen_ppo_trad, reward_trad=gen_reward_trad)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls, ppo_trad=gen_ppo_trad, reward_trad=gen_reward_trad, trad2=gen_trad2)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

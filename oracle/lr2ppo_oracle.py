@@ -681,3 +681,17 @@ def trad_critic_forward(P: Params, text_emb, index, n_pos: Optional[int] = None,
     drop2 = None if drop is None else dict(drop, site_base=int(drop.get("site_base", 0)) + 3)
     x = xit(P, "xitt", x, x, drop2)
     return linear(P, "head", x)[:, -1].reshape(bs)
+
+
+def trad2_param_spec(feat: int = FEAT):
+    """finetune/pointwise_2data_trad.py:130-145: text_proj = Mlp(46, 3072, 768), text_proj3 = Mlp(136, 3072, 768), then
+    pointwise_trad's head."""
+    return _mlp_spec("text_proj", 46, 4 * feat, feat) + _mlp_spec("text_proj3", 136, 4 * feat, feat) + trad_param_spec(feat)
+
+
+def trad2_forward(P: Params, text_emb: torch.Tensor, tgts=None, drop=None):
+    """pointwise_2data_trad.Classifier.forward, mode 'reg' (:146-170): raw LETOR rows [bs, docs, 46 | 136] through the
+    projection of their width, then trad_forward's body."""
+    proj = {46: "text_proj", 136: "text_proj3"}[text_emb.shape[-1]]
+    feat = mlp(P, proj, text_emb.to(torch.float32))
+    return trad_forward(P, feat, tgts, drop)

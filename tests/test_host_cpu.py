@@ -190,7 +190,14 @@ def test_stage1_stage2_modules_mirror_the_reference_surface():
     for n in ("RankLoss", "ActorCritic", "Actor", "Critic", "Reward", "load_or_initialize_parameters",
               "load_or_initialize_parameters_reward", "build_optimizer", "clipped_value_loss", "train_model", "evaluate"):
         assert hasattr(ppo_trad, n), n                                       # finetune/ppo_trad.py's public names
+    from lr2ppo_amd.finetune import pointwise_2data_trad as p2, reward_trad as rt
+    for mod, names in ((p2, ("Mlp", "Classifier", "load_or_initialize_parameters", "build_optimizer", "train_model")),
+                       (rt, ("Classifier", "load_or_initialize_parameters", "build_optimizer", "train_model", "evaluate"))):
+        for n in names:
+            assert hasattr(mod, n), (mod.__name__, n)
     a = argparse.Namespace(mode="reg", labels_num=3)
+    assert [(k, tuple(v.shape)) for k, v in p2.Classifier(a, None).state_dict().items()] == O.trad2_param_spec()
+    assert [(k, tuple(v.shape)) for k, v in rt.Classifier(a, None).state_dict().items()] == O.trad_head_param_spec("reward")
     for cls_, kind in ((ppo_trad.Actor, "actor"), (ppo_trad.Critic, "critic"), (ppo_trad.Reward, "reward")):
         m = cls_(a, None)
         assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == O.trad_head_param_spec(kind)   # pinned by gen_ppo_trad
