@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-online", action="store_true",
                     help="skip the second timed loop (frames + token ids -> ViT-B/16 + RoBERTa-base -> PPO step)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-stage1", action="store_true", help="skip the secondary BASELINE configs[1] figure (stage-1 step at 32 x 20 tags)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="one HIP stream for the whole PPO step (LR2_PPO_STREAMS=0): every launch runs alone, so a kernel trace "
                          "of this command shows exclusive per-kernel durations; the default schedule runs the critic beside the actor")
@@ -323,6 +324,48 @@ def main():
             "includes": "uint8 normalise + patchify + patch projection, token embedding, 2 x 12 encoder layers, pooling; the image "
                         "stack's last layer is evaluated for the pooled [CLS] row only (keys / values for all rows) and "
                         "algorithmic_tflop counts it that way"}
+        # BASELINE configs[1] as written: ViT-B/16 + RoBERTa-base in front of finetune/pointwise.py's Classifier (the Actor
+        # architecture, SmoothL1, AdamW, per-step scheduler) at batch 32 x 20 tags (pointwise.sh:28): uint8 frames + token ids
+        # -> features (text encoder over 640 sequences) -> one stage-1 train step at M = 125 440 token rows.  Measured like
+        # the loops above (synchronize on both sides); a secondary figure, never `value`.
+        if not a.no_stage1:
+            from lr2ppo_amd.finetune import pointwise
+            pargs = argparse.Namespace(**{**vars(margs), "train_steps": 1000, "batch_size": a.batch})
+            torch.manual_seed(9)
+            pmodel = pointwise.Classifier(pargs, None).to(dev)
+            with torch.no_grad():
+                for p in pmodel.parameters():
+                    p.normal_(0, 0.02)
+            popt, psch = pointwise.build_optimizer(pargs, pmodel)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for _ in range(20):
+                    psch.step()
+            pmodel.train()
+            praw = [synthetic_raw_batch(a.batch, 20, device=dev, generator=graw) for _ in range(2)]
+
+            def stage1_step(i):
+                frames, ids, seg, tg = praw[i % len(praw)]
+                text, img = fx.extract(frames, ids, seg, check_ids=False)
+                return pointwise.train_model(pargs, pmodel, popt, psch, text, img, tg)
+
+            for i in range(2):
+                l1 = stage1_step(i)
+            fence()
+            n1 = max(3, min(a.steps, 6))
+            t0 = time.perf_counter()
+            for i in range(n1):
+                l1 = stage1_step(i)
+            fence()
+            dt1 = time.perf_counter() - t0
+            if not torch.isfinite(l1):
+                raise SystemExit("bench: non-finite stage-1 loss")
+            out["config"]["stage1_pointwise_with_online_feature_extraction"] = {
+                "ms_per_step": round(dt1 / n1 * 1e3, 3), "steps_per_sec": round(n1 / dt1, 3), "steps": n1, "measured": True,
+                "workload": f"BASELINE configs[1]: frames uint8 [{a.batch},16,3,224,224] + token ids [{a.batch},20,196] -> ViT-B/16 + "
+                            "RoBERTa-base (random weights, inference) -> finetune/pointwise.py train step (Actor architecture, "
+                            f"{a.batch} x 20 tags, dropout on, fused out_layer.fc1 update)"}
+            del pmodel, popt, psch, praw
         del fx, raw
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample (one untimed warm-up step
     # that allocates the Adam state, then the measured step(s) at the benchmark batch -- no extrapolation) ----
