@@ -301,22 +301,22 @@ class TransformerEncoder(nn.Module):
                                   rows=M, D=E, dx_planes=dff_p, drop=drop(s0 + 2), mode=1, eps=ln2.eps)
                 ffn_in_p = S["inter_p"]
             engine.linear_wgrad(ws, dff_p, S["ff_p"], G[ffn.linear_2.weight], G[ffn.linear_2.bias], M, F, E)
-            engine.linear_dgrad(ws, dff_p, w["w2"], None, M, F, E, act=2, aux_z=S["z"], out_planes=dz_p)
+            engine.linear_dgrad(ws, dff_p, w["w2"], None, M, F, E, act=2, aux_z=S["z"], out_planes=dz_p, w_f32=ffn.linear_2.weight.data)
             engine.linear_wgrad(ws, dz_p, ffn_in_p, G[ffn.linear_1.weight], G[ffn.linear_1.bias], M, E, F)
             d_t1, dao_p = mat("d_t1", M, E), pl("dao_p", M, E)
             if pre:
                 d_x2 = mat("d_x2", M, E)
-                engine.linear_dgrad(ws, dz_p, w["w1"], d_x2, M, E, F)
+                engine.linear_dgrad(ws, dz_p, w["w1"], d_x2, M, E, F, w_f32=ffn.linear_1.weight.data)
                 ops.layernorm_bwd(d_x2, S["t1"], ln2.gamma.data, S["m2"], S["r2"], d_t1, partials, G[ln2.gamma], G[ln2.beta],
                                   rows=M, D=E, resid_grad=dh, dx_planes=dao_p, drop=drop(s0 + 1), mode=1, eps=ln2.eps)
             else:
                 d_inter = mat("d_x2", M, E)
-                engine.linear_dgrad(ws, dz_p, w["w1"], d_inter, M, E, F, resid=d_t2)
+                engine.linear_dgrad(ws, dz_p, w["w1"], d_inter, M, E, F, resid=d_t2, w_f32=ffn.linear_1.weight.data)
                 ops.layernorm_bwd(d_inter, S["t1"], ln1.gamma.data, S["m1"], S["r1"], d_t1, partials, G[ln1.gamma], G[ln1.beta],
                                   rows=M, D=E, dx_planes=dao_p, drop=drop(s0 + 1), mode=1, eps=ln1.eps)
             engine.linear_wgrad(ws, dao_p, S["o_p"], G[att.final_linear.weight], G[att.final_linear.bias], M, E, E)
             do_p, dqkv_p = pl("do_p", M, E), pl("dqkv_p", M, 3 * E)
-            engine.linear_dgrad(ws, dao_p, w["wo"], None, M, E, E, out_planes=do_p)
+            engine.linear_dgrad(ws, dao_p, w["wo"], None, M, E, E, out_planes=do_p, w_f32=att.final_linear.weight.data)
             ops.self_attn_bwd(S["qkv_p"], do_p, seg, dqkv_p, lse_ws, dsum_ws, batch=B, heads=H, L=L, head_dim=hd, scale=scale,
                               drop=drop(s0))
             engine.linear_wgrad(ws, dqkv_p, S["x_p"], dwqkv, dbqkv, M, E, 3 * E)

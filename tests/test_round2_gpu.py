@@ -549,3 +549,35 @@ def test_forward_first_token_is_row_zero_of_the_full_forward(dev, tag, hidden, h
     out.sum().backward()
     assert xg.grad is not None and xg.grad.abs().sum() > 0
     assert (out.detach() - full[:, 0, :]).abs().max().item() < 2e-5 * max(1.0, full.abs().max().item())
+
+
+def test_large_m_dgrad_through_transposed_weight_matches_nn_form(dev):
+    """engine.linear_dgrad with w_f32: at M large enough for the 256 x 256 kernel the input gradient runs as dy @ (W^T)^T on a
+    scratch transpose of the weight -- same products as the NN form on W (different summation order), with the GELU' epilogue
+    (planes output), the plain fp32 output and the accumulate form."""
+    from lr2ppo_amd import engine, ops
+    g = torch.Generator().manual_seed(77)
+    M, E, F = 77824, 768, 3072            # 304 x 3 tiles of 256 x 256 on the narrow output: 89 % of four rounds
+    assert ops.use_gemm256(M, F, E) and ops.use_gemm256(M, E, F)
+    ws = engine.Workspace(dev)
+    w2 = (torch.randn(E, F, generator=g) * 0.05).to(dev)              # linear_2.weight [out = E, in = F]
+    dy = torch.randn(M, E, generator=g).to(dev)
+    z = torch.randn(M, F, generator=g).to(dev)
+    dy_p, w2_p = _planes(ops, dy, dev), _planes(ops, w2, dev)
+    a, b = ops.Planes.empty(M, F, dev), ops.Planes.empty(M, F, dev)
+    engine.linear_dgrad(ws, dy_p, w2_p, None, M, F, E, act=2, aux_z=z, out_planes=a)
+    engine.linear_dgrad(ws, dy_p, w2_p, None, M, F, E, act=2, aux_z=z, out_planes=b, w_f32=w2)
+    ra, rb = a.to_float(), b.to_float()
+    assert (ra - rb).abs().max().item() < 3e-5 * max(1.0, ra.abs().max().item())
+    w1 = (torch.randn(F, E, generator=g) * 0.05).to(dev)              # linear_1.weight [out = F, in = E]
+    dz_p, w1_p = _planes(ops, z, dev), _planes(ops, w1, dev)
+    o1, o2 = torch.empty(M, E, device=dev), torch.empty(M, E, device=dev)
+    engine.linear_dgrad(ws, dz_p, w1_p, o1, M, E, F)
+    engine.linear_dgrad(ws, dz_p, w1_p, o2, M, E, F, w_f32=w1)
+    assert (o1 - o2).abs().max().item() < 3e-5 * max(1.0, o1.abs().max().item())
+    ref = z[:64].double() @ w1.double()
+    assert (o2[:64].double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    base = torch.randn(M, E, generator=g).to(dev)
+    o3 = base.clone()
+    engine.linear_dgrad(ws, dz_p, w1_p, o3, M, E, F, accumulate=True, w_f32=w1)
+    assert (o3 - (base + o2)).abs().max().item() < 1e-4 * max(1.0, o2.abs().max().item())
