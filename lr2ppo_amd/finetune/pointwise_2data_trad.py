@@ -68,6 +68,7 @@ class Classifier(pt.Classifier):
         ops.head_fwd(g2, P["head.weight"], P["head.bias"], logits, rows=N, D=FEAT)
         if save:
             self._saved = (x0, N, drop, Kin)
+            self._unused_prefixes = tuple(v + "." for k, v in PROJ.items() if k != Kin)     # no gradient upstream: .grad stays None
         return logits.view(-1, 1)
 
     @torch.no_grad()

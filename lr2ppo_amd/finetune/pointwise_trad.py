@@ -117,7 +117,9 @@ class _TradFn(torch.autograd.Function):
         m = ctx.model
         m.engine_backward(dlogits.contiguous())
         G = m.grad_buffers()
-        return (None, None) + tuple(G[n].clone() if p.requires_grad else None for n, p in m.named_parameters())
+        unused = tuple(getattr(m, "_unused_prefixes", ()))      # pointwise_2data_trad: the projection this batch did not go through
+        return (None, None) + tuple(G[n].clone() if (p.requires_grad and not n.startswith(unused)) else None
+                                    for n, p in m.named_parameters())
 
 
 def load_or_initialize_parameters(args, model):

@@ -388,3 +388,26 @@ def test_pointwise_2data_trad_dropout_gradients_match_oracle(dev):
             ref_g = Pg[n].grad
             err = (named[n].grad.cpu() - ref_g).abs().max().item()
             assert err < 1e-6 + 2e-3 * ref_g.abs().max().item(), f"width {width} grad {n}: {err} vs {ref_g.abs().max().item()}"
+
+
+def test_pointwise_2data_trad_autograd_dropin_leaves_unused_projection_without_gradient(dev):
+    """loss.backward() through the nn.Module path: the projection the batch did not use keeps .grad = None (as upstream, where
+    it is not part of the graph), the used one and the head receive gradients equal to the engine path's."""
+    from lr2ppo_amd.finetune import pointwise_2data_trad as p2
+    args = argparse.Namespace(mode="reg", labels_num=3)
+    model = p2.Classifier(args, None)
+    model.load_state_dict(O.seeded_params(O.trad2_param_spec(), seed=53), strict=True)
+    model = model.to(dev).eval()
+    g = torch.Generator().manual_seed(54)
+    feats, tgts = torch.randn(2, 5, 136, generator=g).to(dev), torch.randint(0, 3, (2, 5), generator=g).float().to(dev)
+    loss, logits = model(feats, None, tgts)
+    loss.backward()
+    named = dict(model.named_parameters())
+    assert named["text_proj.fc1.weight"].grad is None and named["text_proj.fc2.bias"].grad is None
+    assert named["text_proj3.fc1.weight"].grad is not None and named["text_proj3.fc1.weight"].grad.abs().sum() > 0
+    Pg = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in named.items()}
+    ref_loss, _ = O.trad2_forward(Pg, feats.cpu(), tgts.cpu())
+    ref_loss.backward()
+    for n in ("text_proj3.fc1.weight", "xit.1.0.weight", "head.weight"):
+        ref_g = Pg[n].grad
+        assert (named[n].grad.cpu() - ref_g).abs().max().item() < 1e-6 + 2e-3 * ref_g.abs().max().item(), n
