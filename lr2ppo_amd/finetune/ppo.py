@@ -927,7 +927,7 @@ class SyntheticMovieNet(Dataset):
 
 def get_dataloader(args, dataset, num_tasks, global_rank, is_train=False):
     sampler = DistributedSampler(dataset, num_replicas=num_tasks, rank=global_rank, shuffle=is_train)
-    workers = getattr(args, "num_workers", 32 if not isinstance(dataset, SyntheticMovieNet) else 2)
+    workers = getattr(args, "num_workers", 32 if isinstance(dataset, MovieNet) else 2)        # synthetic sets: 2 workers
     return DataLoader(dataset=dataset, batch_size=args.batch_size if is_train else 1, sampler=sampler,
                       num_workers=workers, drop_last=False)
 
@@ -980,10 +980,30 @@ def main(argv=None):
     misc.init_distributed_mode(args)
     misc.setup_seed(args.seed + misc.get_rank())
     args.is_master = misc.is_main_process()
-    num_tasks, global_rank = misc.get_world_size(), misc.get_rank()
+    return run_training(args, vit_args, ActorCritic, Reward, None, None)
 
-    model = ActorCritic(args, vit_args)
-    reward_model = Reward(args, vit_args)
+
+class _MappedLoader:
+    """A DataLoader whose batches go through `fn` (the `_trad` readers yield (ground_truths, query_id, features))."""
+
+    def __init__(self, loader, fn):
+        self.loader, self.fn, self.sampler = loader, fn, loader.sampler
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        return (self.fn(b) for b in self.loader)
+
+
+def run_training(args, vit_args, actor_critic_cls, reward_cls, make_sets, batch_map):
+    """The stage-3 loop of finetune/ppo.py:790-915 (and of ppo_trad.py:700-849, which repeats it): models, optimizers, rollouts
+    into `memories`, an update cycle every `update_timesteps` rollouts, validation and checkpoint after each cycle.
+    make_sets() -> (trainset, valset) (None: LRMovieNet / SyntheticMovieNet); batch_map: loader batch -> (text_emb, img_emb,
+    tgts) (None: identity)."""
+    num_tasks, global_rank = misc.get_world_size(), misc.get_rank()
+    model = actor_critic_cls(args, vit_args)
+    reward_model = reward_cls(args, vit_args)
     load_or_initialize_parameters(args, model.actor)
     load_or_initialize_parameters_reward(args, model.critic)
     load_or_initialize_parameters_reward(args, reward_model)
@@ -996,14 +1016,19 @@ def main(argv=None):
         for p in list(model.parameters()) + list(reward_model.parameters()):
             dist.broadcast(p.data, src=0)
 
-    def make_sets():
-        if args.synthetic_items > 0:
-            return (SyntheticMovieNet(args.synthetic_items, 2, args.max_imgs, args.seed),
-                    SyntheticMovieNet(args.synthetic_val_items, 20, args.max_imgs, args.seed + 1))
-        return MovieNet(args, args.train_path, is_train=True), MovieNet(args, args.dev_path, is_train=False)
+    if make_sets is None:
+        def make_sets():
+            if args.synthetic_items > 0:
+                return (SyntheticMovieNet(args.synthetic_items, 2, args.max_imgs, args.seed),
+                        SyntheticMovieNet(args.synthetic_val_items, 20, args.max_imgs, args.seed + 1))
+            return MovieNet(args, args.train_path, is_train=True), MovieNet(args, args.dev_path, is_train=False)
+
+    def loader(dataset, is_train):
+        dl = get_dataloader(args, dataset, num_tasks, global_rank, is_train=is_train)
+        return dl if batch_map is None else _MappedLoader(dl, batch_map)
 
     trainset, valset = make_sets()
-    val_loader = get_dataloader(args, valset, num_tasks, global_rank, is_train=False)
+    val_loader = loader(valset, False)
     args.train_steps = int(len(trainset) * args.epochs_num / args.batch_size) + 1
     if args.is_master:
         args.logger.info("Batch size: {}".format(args.batch_size))
@@ -1015,11 +1040,12 @@ def main(argv=None):
         args.logger.info("Start training.")
     for epoch in range(1, args.epochs_num):            # range(1, N): as upstream (quirk 18)
         trainset, _ = make_sets()
-        train_loader = get_dataloader(args, trainset, num_tasks, global_rank, is_train=True)
+        train_loader = loader(trainset, True)
         train_loader.sampler.set_epoch(epoch)
         memories = []
         for text_emb, img_emb, tgts in train_loader:
-            text_emb, img_emb, tgts = text_emb.to(args.device), img_emb.to(args.device), tgts.to(args.device)
+            text_emb, tgts = text_emb.to(args.device), tgts.to(args.device)
+            img_emb = img_emb.to(args.device) if img_emb is not None else None
             model.eval()
             state = None
             for timestep in range(args.max_timesteps):

@@ -82,17 +82,48 @@ def evaluate(args, val_loader, step=0, split="test", num_tasks=None):
 
 class SyntheticLTR(Dataset):
     """Queries of LTRDataset's item layout (ppo_trad.py:89-94): (ground_truths [docs], query_id, features [docs, 768]); every
-    query resampled to exactly `docs` documents like datasets_trad/convert_to_h5py.py:17-23."""
+    query resampled to exactly `docs` documents like datasets_trad/convert_to_h5py.py:17-23.  pairs=True: training items, a
+    random ordered pair of the query's documents (ppo_trad.py:77-82)."""
 
-    def __init__(self, n_queries: int, docs: int = 20, seed: int = 7):
-        self.n, self.docs, self.seed = n_queries, docs, seed
+    def __init__(self, n_queries: int, docs: int = 20, seed: int = 7, pairs: bool = False):
+        self.n, self.docs, self.seed, self.pairs = n_queries, docs, seed, pairs
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed * 1000003 + i)
-        return torch.randint(0, 3, (self.docs,), generator=g), i, torch.randn(self.docs, ppo.FEAT, generator=g)
+        gt, feats = torch.randint(0, 3, (self.docs,), generator=g), torch.randn(self.docs, ppo.FEAT, generator=g)
+        if self.pairs:
+            pair = torch.randperm(self.docs, generator=g)[:2]
+            gt, feats = gt[pair], feats[pair]
+        return gt, i, feats
+
+
+def main(argv=None):
+    """Entry point: finetune/ppo_trad.py's loop (:700-849 = finetune/ppo.py's) over SyntheticLTR queries -- the LETOR h5
+    files need h5py + the pandas-made conversion of datasets_trad/.
+        python -m lr2ppo_amd.finetune.ppo_trad --synthetic_items 64 --batch_size 8 --update_timesteps 4 --max_cycles 2 ..."""
+    import argparse
+    from . import misc
+    parser = ppo.build_parser()
+    args = parser.parse_args(argv)
+    if args.synthetic_items <= 0:
+        raise SystemExit("ppo_trad: only --synthetic_items N is available here (the LETOR h5 reader is not rebuilt)")
+    args.labels_num = 3
+    args.fuse_fc1_update = False
+    misc.init_distributed_mode(args)
+    misc.setup_seed(args.seed + misc.get_rank())
+    args.is_master = misc.is_main_process()
+
+    def make_sets():
+        return (SyntheticLTR(args.synthetic_items, 20, args.seed, pairs=True), SyntheticLTR(args.synthetic_val_items, 20, args.seed + 1))
+
+    def batch_map(b):
+        ground_truths, _, features = b
+        return features.to(torch.float32), None, ground_truths
+
+    return ppo.run_training(args, argparse.Namespace(**vars(args)), ActorCritic, Reward, make_sets, batch_map)
 
 
 class _Loader:
@@ -101,3 +132,7 @@ class _Loader:
 
     def __iter__(self):
         return self.make()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,5 +18,9 @@ python -m lr2ppo_amd.finetune.ppo $COMMON --mode reg --epochs_num 2 --critic_lea
   --update_timesteps 2 --kl_div_loss_weight 0.001 --entropy_weight 0.001 --value_clip 0.5 --synthetic_items 4 \
   --synthetic_val_items 3 --max_cycles 1 --pretrained_model_path "$OUT/stage1.bin" --reward_model_path "$OUT/stage2.bin" \
   --output_model_path "$OUT/stage3.bin" --log_path "$OUT/stage3.log"
+echo "== stage 3 at sequence length 1 (ppo_trad twin), synthetic LETOR-shaped queries"
+python -m lr2ppo_amd.finetune.ppo_trad $COMMON --mode reg --epochs_num 2 --critic_learning_rate 1e-4 --max_timesteps 1 \
+  --update_timesteps 2 --kl_div_loss_weight 0.001 --entropy_weight 0.001 --value_clip 0.5 --synthetic_items 8 \
+  --synthetic_val_items 3 --max_cycles 1 --output_model_path "$OUT/stage3_trad.bin" --log_path "$OUT/stage3_trad.log"
 ls -la "$OUT"
 echo CLI_SMOKE_OK
