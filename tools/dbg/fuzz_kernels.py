@@ -1,0 +1,117 @@
+"""Randomised shape sweep of the GEMM family and the self-attention kernels against fp64 (run on the GPU box; seeds fixed).
+    python tools/dbg/fuzz_kernels.py [--n 150] [--seed 0]"""
+import argparse, math, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import numpy as np
+import torch
+from lr2ppo_amd import ops
+from oracle import lr2ppo_oracle as O
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=150)
+ap.add_argument("--seed", type=int, default=0)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(a.seed)
+g = torch.Generator().manual_seed(a.seed)
+
+
+def planes(x):
+    return ops.split_planes(x.to(dev).contiguous(), ops.Planes.empty(x.shape[0], x.shape[1], dev))
+
+
+bad = 0
+# ---- GEMM: forms x operand kinds x tile choices x epilogues ----
+for it in range(a.n):
+    form = ["NT", "NN", "TN"][int(rng.integers(0, 3))]
+    M = int(rng.integers(1, 1400))
+    N = int(rng.integers(1, 300)) * 4
+    K = int(rng.integers(1, 12)) * 64
+    bm = [None, 64, 128, 256][int(rng.integers(0, 4))]
+    ta, tb = form == "TN", form in ("NN", "TN")
+    if ta:
+        M = (M + 7) // 8 * 8            # A is [K, M]: 16-byte rows of the planes / fp32 operand
+    if tb:
+        N = (N + 7) // 8 * 8            # B is [K, N]
+    if bm == 256 and form != "NT":
+        bm = None
+    A = torch.randn((K, M) if ta else (M, K), generator=g)
+    B = torch.randn((K, N) if tb else (N, K), generator=g) * 0.1
+    ref = (A.t() if ta else A).double() @ (B if tb else B.t()).double()
+    use_planes = bool(rng.integers(0, 2)) or bm == 256
+    Ad, Bd = (planes(A), planes(B)) if use_planes else (A.to(dev), B.to(dev))
+    epi = int(rng.integers(0, 4))
+    bias = torch.randn(N, generator=g) if epi in (1, 2) else None
+    resid = torch.randn(M, N, generator=g) if epi == 2 else None
+    out = torch.full((M, N), float("nan"), device=dev)
+    pl = ops.Planes.empty(M, N, dev) if epi == 3 else None
+    splits = None
+    if bm is not None:
+        splits = 1 if bm == 256 else ops.choose_tiling(M, N, K, ta, tb)[1]
+    ws = torch.empty(64 * M * N, device=dev) if (splits or 0) != 1 and M * N < 4_000_000 else None
+    kw = dict(trans_a=ta, trans_b=tb, bias=None if bias is None else bias.to(dev), resid=None if resid is None else resid.to(dev),
+              act=1 if epi == 1 else 0, out_planes=pl, block_m=bm, splits=splits, splitk_ws=ws)
+    try:
+        ops.gemm(Ad, Bd, out, M, N, K, **kw)
+    except Exception as e:                                    # noqa: BLE001
+        print("gemm raised", form, M, N, K, bm, splits, epi, repr(e)[:120], flush=True)
+        bad += 1
+        continue
+    want = ref + (bias.double() if bias is not None else 0.0)
+    if epi == 1:
+        want = O.gelu_erf(want)
+    if resid is not None:
+        want = want + resid.double()
+    err = (out.double().cpu() - want).abs().max().item()
+    tol = 8e-5 * math.sqrt(K) * max(1.0, float(want.abs().max()) / 10)
+    ok = err < tol and (pl is None or (pl.to_float().double().cpu() - want).abs().max().item() < 2 * tol)
+    if not ok:
+        bad += 1
+        print("GEMM MISMATCH", form, M, N, K, "bm", bm, "splits", splits, "planes", use_planes, "epi", epi, "err", err, "tol", tol, flush=True)
+print("gemm cases done", a.n, "bad", bad, flush=True)
+
+# ---- self-attention forward + backward, first-token attention ----
+for it in range(max(10, a.n // 5)):
+    batch, heads = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    L = int(rng.integers(1, 620))
+    drop_p = [0.0, 0.1][int(rng.integers(0, 2))]
+    E = heads * 64
+    qkv = torch.cat([torch.randn(batch * L, E, generator=g) * 0.3, torch.randn(batch * L, E, generator=g) * 0.3,
+                     torch.randn(batch * L, E, generator=g)], dim=1)
+    do = torch.randn(batch * L, E, generator=g)
+    seg = torch.ones(batch, L, dtype=torch.long)
+    cut = int(rng.integers(1, L + 1))
+    seg[-1, cut:] = 0
+    mask = (1.0 - (seg > 0).double()).view(batch, 1, 1, L) * -10000.0
+    seed, site = 1234 + it, 3
+    mult = torch.ones(batch, heads, L, L, dtype=torch.float64)
+    if drop_p > 0:
+        keep = O.dropout_keep_mask(seed, site, batch * heads * L * L, drop_p)
+        mult = torch.from_numpy(np.asarray(keep, dtype=np.float64)).view(batch, heads, L, L) / (1.0 - drop_p)
+    x = qkv.double().requires_grad_(True)
+    qh, kh, vh = (t.reshape(batch, L, heads, 64).transpose(1, 2) for t in x.split(E, dim=1))
+    sc = qh @ kh.transpose(-2, -1) / 8.0 + mask
+    ref_o = ((torch.softmax(sc, dim=-1) * mult) @ vh).transpose(1, 2).reshape(batch * L, E)
+    (ref_o * do.double()).sum().backward()
+    drop = ops.Drop(drop_p, seed, site) if drop_p > 0 else None
+    qkv_p, do_p = planes(qkv), planes(do)
+    o = torch.full((batch * L, E), float("nan"), device=dev)
+    ops.self_attn_fwd(qkv_p, seg.to(dev).view(-1), o, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, drop=drop)
+    e_f = (o.double().cpu() - ref_o.detach()).abs().max().item()
+    dqkv = ops.Planes.empty(batch * L, 3 * E, dev)
+    dqkv.buf.fill_(0x7FC0)
+    w1, w2 = torch.empty(batch * heads * L, device=dev), torch.empty(batch * heads * L, device=dev)
+    ops.self_attn_bwd(qkv_p, do_p, seg.to(dev).view(-1), dqkv, w1, w2, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, drop=drop)
+    e_b = (dqkv.to_float().double().cpu() - x.grad).abs().max().item()
+    sb = max(1.0, float(x.grad.abs().max()))
+    q0 = qkv[:, :E].view(batch, L, E)[:, 0, :].contiguous()
+    kv_p = planes(qkv[:, E:].contiguous())
+    o0 = torch.full((batch, E), float("nan"), device=dev)
+    ops.first_token_attn(q0.to(dev), kv_p, seg.to(dev).view(-1), o0, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125)
+    ref0 = (torch.softmax(sc.detach(), dim=-1) @ vh.detach()).transpose(1, 2).reshape(batch, L, E)[:, 0, :]
+    e_0 = (o0.double().cpu() - ref0).abs().max().item()
+    if not (e_f < 5e-5 and e_b < 1e-4 * sb and e_0 < 5e-5):
+        bad += 1
+        print("ATTN MISMATCH batch", batch, "heads", heads, "L", L, "drop", drop_p, "cut", cut, "fwd", e_f, "bwd", e_b, "first", e_0, flush=True)
+print("attention cases done; total bad", bad, flush=True)
+sys.exit(1 if bad else 0)
