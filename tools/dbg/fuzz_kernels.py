@@ -40,17 +40,23 @@ for it in range(a.n):
     ref = (A.t() if ta else A).double() @ (B if tb else B.t()).double()
     use_planes = bool(rng.integers(0, 2)) or bm == 256
     Ad, Bd = (planes(A), planes(B)) if use_planes else (A.to(dev), B.to(dev))
-    epi = int(rng.integers(0, 4))
+    epi = int(rng.integers(0, 7))
     bias = torch.randn(N, generator=g) if epi in (1, 2) else None
     resid = torch.randn(M, N, generator=g) if epi == 2 else None
     out = torch.full((M, N), float("nan"), device=dev)
     pl = ops.Planes.empty(M, N, dev) if epi == 3 else None
+    aux_z = torch.randn(M, N, generator=g) if epi == 4 else None          # GELU' epilogue (dgrad through a GELU)
+    base = torch.randn(M, N, generator=g) if epi == 5 else None           # accumulate into the output
+    if base is not None:
+        out = base.to(dev).clone()
+    drop = ops.Drop(0.1, seed=4000 + it, site=2) if epi == 6 else None
     splits = None
     if bm is not None:
         splits = 1 if bm == 256 else ops.choose_tiling(M, N, K, ta, tb)[1]
     ws = torch.empty(64 * M * N, device=dev) if (splits or 0) != 1 and M * N < 4_000_000 else None
     kw = dict(trans_a=ta, trans_b=tb, bias=None if bias is None else bias.to(dev), resid=None if resid is None else resid.to(dev),
-              act=1 if epi == 1 else 0, out_planes=pl, block_m=bm, splits=splits, splitk_ws=ws)
+              act=1 if epi == 1 else (2 if epi == 4 else 0), out_planes=pl, block_m=bm, splits=splits, splitk_ws=ws,
+              aux_z=None if aux_z is None else aux_z.to(dev), accumulate=base is not None, drop=drop)
     try:
         ops.gemm(Ad, Bd, out, M, N, K, **kw)
     except Exception as e:                                    # noqa: BLE001
@@ -62,6 +68,14 @@ for it in range(a.n):
         want = O.gelu_erf(want)
     if resid is not None:
         want = want + resid.double()
+    if aux_z is not None:
+        zz = aux_z.double()
+        want = want * (0.5 * (1.0 + torch.erf(zz / math.sqrt(2.0))) + zz * torch.exp(-0.5 * zz * zz) / math.sqrt(2.0 * math.pi))
+    if base is not None:
+        want = want + base.double()
+    if drop is not None:
+        keep = torch.from_numpy(np.asarray(O.dropout_keep_mask(4000 + it, 2, M * N, 0.1), dtype=np.float64)).view(M, N)
+        want = want * keep / 0.9
     err = (out.double().cpu() - want).abs().max().item()
     tol = 8e-5 * math.sqrt(K) * max(1.0, float(want.abs().max()) / 10)
     ok = err < tol and (pl is None or (pl.to_float().double().cpu() - want).abs().max().item() < 2 * tol)
