@@ -177,9 +177,11 @@ def test_head_forward_full_size():
         assert torch.allclose(r, g["reward"], atol=2e-5, rtol=1e-4)
 
 
-def _check_train_steps(gold_name, kind, seed, make_batch, loss_fn, n_out):
+def _check_train_steps(gold_name, kind, seed, make_batch, loss_fn, n_out, steps_checked=2):
+    """The first `steps_checked` of the fixture's steps (step 0 runs at lr 0, step 1 is the first real AdamW update): a full-size
+    head step costs the CPU oracle ~1 minute; the fixture's later steps are checked on the HIP path (tests/test_stages_gpu.py)."""
     g = load_golden(gold_name)
-    bs, tags, steps = int(g["bs"]), int(g["tags"]), int(g["steps"])
+    bs, tags, steps = int(g["bs"]), int(g["tags"]), min(int(g["steps"]), steps_checked)
     P = O.seeded_params(O.head_param_spec(kind), seed=seed)
     batches = [make_batch(g, step, bs, tags) for step in range(steps)]
     for step in range(steps):
@@ -200,19 +202,15 @@ def _check_train_steps(gold_name, kind, seed, make_batch, loss_fn, n_out):
 
 @pytest.mark.slow
 def test_stage1_pointwise_train_steps_match_reference():
-    """three pointwise.train_model steps (Actor architecture + SmoothL1 + per-batch scheduler)."""
-    g, P = _check_train_steps("stage1_step.npz", "actor", 17,
-                              lambda g, step, bs, tags: O.seeded_head_inputs(2000 + step, bs, tags), O.stage1_loss, 1)
-    text, img, _ = O.seeded_head_inputs(2100, int(g["bs"]), int(g["tags"]))
-    with torch.no_grad():
-        logits = O.actor_forward(P, text, img, None)
-    ref = g["eval_logits"].view(-1)
-    assert (logits.view(-1) - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
+    """pointwise.train_model steps (Actor architecture + SmoothL1 + per-batch scheduler): losses, lr and the
+    sampled weights after the first real update.  (The fixture's third step and its evaluation logits: GPU suite.)"""
+    _check_train_steps("stage1_step.npz", "actor", 17,
+                       lambda g, step, bs, tags: O.seeded_head_inputs(2000 + step, bs, tags), O.stage1_loss, 1)
 
 
 @pytest.mark.slow
 def test_stage2_pair_reward_train_steps_match_reference():
-    """three reward_pair_dataloader.train_model steps (two forwards + hinge + AdamW)."""
+    """reward_pair_dataloader.train_model steps (two forwards + hinge + AdamW)."""
     def batch(g, step, bs, tags):
         text, img, _ = O.seeded_head_inputs(3000 + step, bs, tags)
         return text, img, g[f"chosen_{step}"], g[f"reject_{step}"]
