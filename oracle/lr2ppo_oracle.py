@@ -135,7 +135,8 @@ def dropout_keep_mask(seed: int, site: int, numel: int, p: float) -> np.ndarray:
     x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & np.uint64(0xFFFFFFFFFFFFFFFF)
     x = x ^ (x >> np.uint64(31))
     u = (x >> np.uint64(32)).astype(np.uint32)
-    thr = np.uint32(min(int(p * 4294967296.0), 4294967295))
+    # the C ABI carries p as a float: the threshold is formed from float32(p) (0.1f = 0.100000001490116: 7 counts above 0.1 * 2^32)
+    thr = np.uint32(min(int(float(np.float32(p)) * 4294967296.0), 4294967295))
     return u >= thr
 
 
