@@ -128,4 +128,87 @@ for it in range(max(10, a.n // 5)):
         bad += 1
         print("ATTN MISMATCH batch", batch, "heads", heads, "L", L, "drop", drop_p, "cut", cut, "fwd", e_f, "bwd", e_b, "first", e_0, flush=True)
 print("attention cases done; total bad", bad, flush=True)
+# ---- LayerNorm forward / backward (both semantics), XiT attention, PPO loss ----
+def close(a, b, atol, rtol):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return bool(((a - b).abs() <= atol + rtol * b.abs()).all())
+
+
+for it in range(max(10, a.n // 5)):
+    rows, D = int(rng.integers(1, 1500)), int(rng.integers(1, 33)) * 32
+    mode = int(rng.integers(0, 2))
+    drop_p = [0.0, 0.1][int(rng.integers(0, 2))]
+    x, gam, bet = torch.randn(rows, D, generator=g) * 2 + 0.5, torch.randn(D, generator=g), torch.randn(D, generator=g)
+    dy, rg = torch.randn(rows, D, generator=g), torch.randn(rows, D, generator=g)
+    eps = 1e-5 if mode == 0 else 1e-6
+    ln = O.layernorm_torch if mode == 0 else O.layernorm_tp
+    xt, gt, bt = x.double().requires_grad_(True), gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    ref = ln(xt, gt, bt)
+    ref.backward(dy.double())
+    out, mean, rstd = torch.empty(rows, D, device=dev), torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+    ops.layernorm_fwd(x.to(dev), gam.to(dev), bet.to(dev), out, mean, rstd, rows=rows, D=D, eps=eps, mode=mode)
+    dx, dxm = torch.empty(rows, D, device=dev), ops.Planes.empty(rows, D, dev)
+    dgam, dbet = torch.empty(D, device=dev), torch.empty(D, device=dev)
+    drop = ops.Drop(drop_p, 99 + it, 4) if drop_p > 0 else None
+    ops.layernorm_bwd(dy.to(dev), x.to(dev), gam.to(dev), mean, rstd, dx, torch.empty(256 * 2 * D, device=dev), dgam, dbet, rows=rows,
+                      D=D, resid_grad=rg.to(dev), dx_planes=dxm, drop=drop, mode=mode, eps=eps)
+    ref_dx = xt.grad + rg.double()
+    keep = torch.ones(rows, D, dtype=torch.float64)
+    if drop_p > 0:
+        keep = torch.from_numpy(O.dropout_keep_mask(99 + it, 4, rows * D, drop_p)).view(rows, D).double() / (1 - drop_p)
+    sc = max(1.0, float(ref_dx.abs().max()))
+    ok = (close(out, ref, 2e-5, 2e-5) and close(dx, ref_dx, 3e-5 * sc, 3e-5) and close(dgam, gt.grad, 2e-4 * math.sqrt(rows), 1e-4)
+          and close(dbet, bt.grad, 2e-4 * math.sqrt(rows), 1e-4) and close(dxm.to_float(), ref_dx * keep, 2e-4 * sc, 5e-5))
+    if not ok:
+        bad += 1
+        print("LN MISMATCH rows", rows, "D", D, "mode", mode, "drop", drop_p, flush=True)
+print("layernorm cases done; total bad", bad, flush=True)
+
+for it in range(max(10, a.n // 5)):
+    batch, heads = int(rng.integers(1, 6)), 8
+    Lq, Lk, hd = int(rng.integers(1, 257)), int(rng.integers(1, 17)), int(rng.integers(1, 25)) * 4
+    E = heads * hd
+    q, k = torch.randn(batch, Lq, E, generator=g) * 0.5, torch.randn(batch, Lk, E, generator=g) * 0.5
+    v, do = torch.randn(batch, Lk, E, generator=g), torch.randn(batch, Lq, E, generator=g)
+    scale = 1.0 / math.sqrt(E)
+    qt, kt, vt = (t.double().requires_grad_(True) for t in (q, k, v))
+    qh = qt.view(batch, Lq, heads, hd).permute(0, 2, 1, 3)
+    kh = kt.view(batch, Lk, heads, hd).permute(0, 2, 1, 3)
+    vh = vt.view(batch, Lk, heads, hd).permute(0, 2, 1, 3)
+    ref = ((torch.softmax(qh @ kh.transpose(-1, -2), dim=-1) * scale) @ vh).permute(0, 2, 1, 3).reshape(batch, Lq, E)
+    ref.backward(do.double())
+    qd, kd, vd = q.to(dev).view(-1, E), k.to(dev).view(-1, E), v.to(dev).view(-1, E)
+    o = torch.empty(batch * Lq, E, device=dev)
+    ops.xattn_fwd(qd, kd, vd, o, batch=batch, heads=heads, Lq=Lq, Lk=Lk, head_dim=hd, post_scale=scale)
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.xattn_bwd(qd, kd, vd, do.to(dev).view(-1, E), dq, dk, dv, batch=batch, heads=heads, Lq=Lq, Lk=Lk, head_dim=hd, post_scale=scale)
+    ok = (close(o, ref.view(-1, E), 1e-6, 2e-5) and close(dq, qt.grad.view(-1, E), 2e-6, 2e-4) and close(dk, kt.grad.view(-1, E), 2e-5, 2e-4)
+          and close(dv, vt.grad.view(-1, E), 2e-5, 2e-4))
+    if not ok:
+        bad += 1
+        print("XATTN MISMATCH batch", batch, "Lq", Lq, "Lk", Lk, "hd", hd, flush=True)
+print("xattn cases done; total bad", bad, flush=True)
+
+for it in range(max(10, a.n // 5)):
+    B, T = int(rng.integers(1, 65)), int(rng.integers(2, 5))
+    scores = torch.randn(B, T, generator=g) * 0.3
+    old = scores + torch.randn(B, T, generator=g) * 0.05
+    rewards, old_value = torch.randn(B, generator=g) * 0.2, torch.randn(B, generator=g) * 0.2
+    value = old_value + torch.randn(B, generator=g) * 0.6
+    state = torch.stack([torch.randperm(T, generator=g) for _ in range(B)])
+    nxt = torch.cat([torch.arange(2).unsqueeze(0).repeat(B, 1), state], dim=1)
+    st, vt = scores.clone().requires_grad_(True), value.clone().requires_grad_(True)
+    loss, vloss, ex = O.ppo_update_math(st, vt, old, rewards, old_value, nxt, 0.001, 0.001, 0.5)
+    loss.backward()
+    vloss.backward()
+    scal, per = torch.empty(4, device=dev), torch.empty(4, B, device=dev)
+    ds, dv = torch.empty(B, T, device=dev), torch.empty(B, device=dev)
+    ops.ppo_loss(scores.to(dev), old.to(dev), rewards.to(dev), old_value.to(dev), value.to(dev), nxt.to(dev), scal, per, ds, dv, B=B, T=T,
+                 kl_w=0.001, ent_w=0.001, value_clip=0.5)
+    ok = (close(scal[0], loss, 2e-7, 2e-5) and close(scal[1], vloss, 2e-7, 2e-5) and close(scal[2], ex["rank_loss"], 2e-7, 2e-5)
+          and close(per[3], ex["advantages"], 2e-7, 2e-5) and close(ds, st.grad, 2e-8, 2e-4) and close(dv, vt.grad, 2e-8, 2e-4))
+    if not ok:
+        bad += 1
+        print("PPO LOSS MISMATCH B", B, "T", T, flush=True)
+print("ppo loss cases done; total bad", bad, flush=True)
 sys.exit(1 if bad else 0)
