@@ -10,6 +10,7 @@ from oracle import lr2ppo_oracle as O
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=150)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--heads", type=int, default=0, help="random (batch, tags, index) cases of the full-size Actor / Critic / Reward vs the oracle")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(a.seed)
@@ -211,4 +212,32 @@ for it in range(max(10, a.n // 5)):
         bad += 1
         print("PPO LOSS MISMATCH B", B, "T", T, flush=True)
 print("ppo loss cases done; total bad", bad, flush=True)
+# ---- full-size heads: random batch / tag counts / index orders (duplicates allowed) against the CPU oracle ----
+if a.heads:
+    import argparse as _ap
+    from lr2ppo_amd.finetune import ppo
+    hargs = _ap.Namespace(mode="reg", labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768)
+    models = {}
+    for kind, cls, sd in (("actor", ppo.Actor, 7), ("critic", ppo.Critic, 8), ("reward", ppo.Reward, 9)):
+        P = O.seeded_params(O.head_param_spec(kind), seed=sd)
+        m = cls(hargs, None)
+        m.load_state_dict(P, strict=True)
+        models[kind] = (m.to(dev).eval(), P)
+    for it in range(a.heads):
+        bs, tags = int(rng.integers(1, 4)), int(rng.integers(1, 5))
+        text, img, _ = O.seeded_head_inputs(7000 + it, bs, tags)
+        idx_c = torch.from_numpy(rng.integers(0, tags, size=(bs, int(rng.integers(1, 5))))).long()
+        idx_r = torch.from_numpy(rng.integers(0, tags, size=(bs, 4))).long()
+        with torch.no_grad():
+            got_a = models["actor"][0](text.to(dev), img.to(dev), None).cpu()
+            got_c = models["critic"][0](text.to(dev), img.to(dev), None, idx_c.to(dev)).cpu()
+            got_r = models["reward"][0](text.to(dev), img.to(dev), None, idx_r.to(dev)).cpu()
+            ref_a = O.actor_forward(models["actor"][1], text, img, None)
+            ref_c = O.critic_forward(models["critic"][1], text, img, idx_c)
+            ref_r = O.reward_forward(models["reward"][1], text, img, idx_r)
+        errs = [(got_a.view(-1) - ref_a.view(-1)).abs().max().item(), (got_c - ref_c).abs().max().item(), (got_r - ref_r).abs().max().item()]
+        if max(errs) > 1e-4:
+            bad += 1
+            print("HEAD MISMATCH bs", bs, "tags", tags, "idx_c", idx_c.tolist(), "errs", errs, flush=True)
+    print("head cases done; total bad", bad, flush=True)
 sys.exit(1 if bad else 0)
