@@ -10,6 +10,7 @@ from oracle import lr2ppo_oracle as O
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=150)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--encoders", type=int, default=0, help="random small TransformerEncoder configs: forward, first-token forward and backward vs the oracle")
 ap.add_argument("--heads", type=int, default=0, help="random (batch, tags, index) cases of the full-size Actor / Critic / Reward vs the oracle")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -212,6 +213,53 @@ for it in range(max(10, a.n // 5)):
         bad += 1
         print("PPO LOSS MISMATCH B", B, "T", T, flush=True)
 print("ppo loss cases done; total bad", bad, flush=True)
+# ---- TransformerEncoder at random small configurations: inference forward, first-token forward, training backward ----
+if a.encoders:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+    from test_encoder_gpu import _args, ROBERTA
+    from lr2ppo_amd.tencentpretrain.encoders import str2encoder
+    for it in range(a.encoders):
+        heads = int(rng.integers(1, 5))
+        hidden, ff = heads * 64, int(rng.integers(1, 5)) * 64 * heads
+        layers, tag = int(rng.integers(1, 3)), ["pre", "post"][int(rng.integers(0, 2))]
+        B, L = int(rng.integers(1, 4)), int(rng.integers(2, 330))
+        ea = _args(**{**ROBERTA, "hidden_size": hidden, "emb_size": hidden, "feedforward_size": ff, "heads_num": heads,
+                      "layers_num": layers, "layernorm_positioning": tag, "dropout": 0.0})
+        enc = str2encoder["transformer"](ea)
+        spec = [(n, tuple(p.shape)) for n, p in enc.named_parameters()]
+        P = O.seeded_params(spec, seed=500 + it, std=0.08, skip_gamma_beta=False)
+        enc.load_state_dict(P, strict=True)
+        enc = enc.to(dev).eval()
+        x = torch.randn(B, L, hidden, generator=g)
+        seg = torch.ones(B, L, dtype=torch.long)
+        seg[-1, int(rng.integers(1, L + 1)):] = 0
+        w = torch.randn(B, L, hidden, generator=g)
+        Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+        xr = x.clone().requires_grad_(True)
+        ref = O.transformer_encoder(Pg, xr, seg, layers, heads, tag == "pre")
+        (ref * w).sum().backward()
+        with torch.no_grad():
+            got = enc(x.to(dev), seg.to(dev))
+            first = enc.forward_first_token(x.to(dev), seg.to(dev))
+        xd = x.to(dev).requires_grad_(True)
+        for prm in enc.parameters():
+            prm.grad = None
+        (enc(xd, seg.to(dev)) * w.to(dev)).sum().backward()
+        sc = max(1.0, float(ref.detach().abs().max()))
+        e_f = (got.cpu() - ref.detach()).abs().max().item() / sc
+        e_1 = (first.cpu() - ref.detach()[:, 0, :]).abs().max().item() / sc
+        e_x = (xd.grad.cpu() - xr.grad).abs().max().item() / max(1.0, float(xr.grad.abs().max()))
+        e_p = 0.0
+        for n, prm in enc.named_parameters():
+            if n.endswith("linear_layers.1.bias"):          # key-projection bias: analytically zero gradient (rounding noise on both sides)
+                continue
+            rg = Pg[n].grad
+            e_p = max(e_p, (prm.grad.cpu() - rg).abs().max().item() / max(1.0, float(rg.abs().max())))
+        if max(e_f, e_1) > 2e-4 or max(e_x, e_p) > 2e-3:
+            bad += 1
+            print("ENCODER MISMATCH", dict(heads=heads, ff=ff, layers=layers, ln=tag, B=B, L=L), "fwd", e_f, "first", e_1, "dx", e_x, "dparam", e_p, flush=True)
+    print("encoder cases done; total bad", bad, flush=True)
+
 # ---- full-size heads: random batch / tag counts / index orders (duplicates allowed) against the CPU oracle ----
 if a.heads:
     import argparse as _ap
