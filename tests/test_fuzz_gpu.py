@@ -1,5 +1,6 @@
 """Randomised shape sweep of the GEMM family (forms x operand kinds x tile choices x fused epilogues) and of the self-attention
-forward / backward / first-token kernels against fp64 formulas: tools/dbg/fuzz_kernels.py with a fixed seed, as a child process."""
+forward / backward / first-token kernels, LayerNorm, XiT attention, the PPO loss and six random small TransformerEncoder
+configurations against fp64 formulas / the oracle: tools/dbg/fuzz_kernels.py with a fixed seed, as a child process."""
 import os
 import subprocess
 import sys
@@ -11,7 +12,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_randomised_gemm_and_attention_shapes_match_fp64(dev):
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "dbg", "fuzz_kernels.py"), "--n", "120", "--seed", "11"],
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "dbg", "fuzz_kernels.py"), "--n", "120", "--seed", "11", "--encoders", "6"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "bad 0" in r.stdout
