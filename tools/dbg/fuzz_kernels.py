@@ -11,6 +11,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=150)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--encoders", type=int, default=0, help="random small TransformerEncoder configs: forward, first-token forward and backward vs the oracle")
+ap.add_argument("--trad", type=int, default=0, help="random (queries, documents, index) cases of the sequence-length-1 heads (ppo_trad / pointwise_2data_trad)")
 ap.add_argument("--heads", type=int, default=0, help="random (batch, tags, index) cases of the full-size Actor / Critic / Reward vs the oracle")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -259,6 +260,33 @@ if a.encoders:
             bad += 1
             print("ENCODER MISMATCH", dict(heads=heads, ff=ff, layers=layers, ln=tag, B=B, L=L), "fwd", e_f, "first", e_1, "dx", e_x, "dparam", e_p, flush=True)
     print("encoder cases done; total bad", bad, flush=True)
+
+# ---- sequence-length-1 heads (`_trad` twins): random query / document counts, index orders, both LETOR feature widths ----
+if a.trad:
+    import argparse as _ap2
+    from lr2ppo_amd.finetune import ppo_trad, pointwise_2data_trad as p2
+    targs = _ap2.Namespace(mode="reg", labels_num=3)
+    Pa, Pc = O.seeded_params(O.trad_head_param_spec("actor"), seed=61), O.seeded_params(O.trad_head_param_spec("critic"), seed=62)
+    P2 = O.seeded_params(O.trad2_param_spec(), seed=63)
+    for Pd in (Pa, Pc, P2):
+        Pd["head.weight"] = Pd["head.weight"] * 20.0
+    actor, critic, two = ppo_trad.Actor(targs, None), ppo_trad.Critic(targs, None), p2.Classifier(targs, None)
+    actor.load_state_dict(Pa, strict=True), critic.load_state_dict(Pc, strict=True), two.load_state_dict(P2, strict=True)
+    actor, critic, two = actor.to(dev).eval(), critic.to(dev).eval(), two.to(dev).eval()
+    for it in range(a.trad):
+        bs, docs = int(rng.integers(1, 9)), int(rng.integers(1, 41))
+        feats = torch.randn(bs, docs, 768, generator=g)
+        idx = torch.from_numpy(rng.integers(0, docs, size=(bs, int(rng.integers(1, 5))))).long()
+        width = [46, 136][int(rng.integers(0, 2))]
+        raw = torch.randn(bs, docs, width, generator=g)
+        with torch.no_grad():
+            e1 = (actor(feats.to(dev), None, None).cpu().view(-1) - O.trad_actor_forward(Pa, feats)).abs().max().item()
+            e2 = (critic(feats.to(dev), None, None, idx.to(dev)).cpu() - O.trad_critic_forward(Pc, feats, idx)).abs().max().item()
+            e3 = (two(raw.to(dev), None, None).cpu().view(-1) - O.trad2_forward(P2, raw).view(-1)).abs().max().item()
+        if max(e1, e2, e3) > 2e-4:
+            bad += 1
+            print("TRAD MISMATCH bs", bs, "docs", docs, "idx", idx.shape, "width", width, "errs", (e1, e2, e3), flush=True)
+    print("trad cases done; total bad", bad, flush=True)
 
 # ---- full-size heads: random batch / tag counts / index orders (duplicates allowed) against the CPU oracle ----
 if a.heads:
