@@ -29,8 +29,10 @@ def small_models():
     max_imgs=1, the smallest the architecture allows -- only that layer's input width depends on max_imgs)."""
     from lr2ppo_amd.finetune import ppo
     small = argparse.Namespace(**{**ARGS, "max_imgs": 1})
-    ac = ppo.ActorCritic(small, None)
-    return {"actor": ac.actor, "critic": ac.critic, "reward": ppo.Reward(small, None), "actor_critic": ac}
+    with torch.device("meta"):         # names, shapes, grouping and argument checks need no storage (3 x 2 GB and their init otherwise)
+        ac = ppo.ActorCritic(small, None)
+        reward = ppo.Reward(small, None)
+    return {"actor": ac.actor, "critic": ac.critic, "reward": reward, "actor_critic": ac}
 
 
 def test_state_dict_keys_match_reference_checkpoints(small_models):
@@ -146,11 +148,12 @@ def test_no_cpu_fallback_and_bad_arguments_are_errors(native, small_models):
     actor = small_models["actor"]
     with pytest.raises(TypeError):
         actor(torch.zeros(1, 2, 196, 768), torch.zeros(1, 2, 1, 768), None)     # CPU tensors: refuse, don't emulate
-    with pytest.raises(ValueError):
-        ppo.Actor(argparse.Namespace(**{**ARGS, "mode": "rank"}), None)          # 'reg' and 'cls' only (ppo.py:209-212)
-    assert ppo.Actor(argparse.Namespace(**{**ARGS, "mode": "cls"}), None).n_out == 3
-    with pytest.raises(ValueError):
-        ppo.Actor(argparse.Namespace(**{**ARGS, "seq_length": 128}), None)
+    with torch.device("meta"):
+        with pytest.raises(ValueError):
+            ppo.Actor(argparse.Namespace(**{**ARGS, "mode": "rank"}), None)          # 'reg' and 'cls' only (ppo.py:209-212)
+        assert ppo.Actor(argparse.Namespace(**{**ARGS, "mode": "cls"}), None).n_out == 3
+        with pytest.raises(ValueError):
+            ppo.Actor(argparse.Namespace(**{**ARGS, "seq_length": 128}), None)
     # the C entry points validate before launching anything (no GPU is touched by a rejected call)
     lib = native.lib()
     assert lib.lr2_gemm(None, None, 1, 128, 64, 64, 64, 0, 0, 0, 0, 0, 0, 0, 0, None, None, 1, 128, 3, None) == -1
