@@ -12,6 +12,7 @@ ap.add_argument("--n", type=int, default=150)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--encoders", type=int, default=0, help="random small TransformerEncoder configs: forward, first-token forward and backward vs the oracle")
 ap.add_argument("--trad", type=int, default=0, help="random (queries, documents, index) cases of the sequence-length-1 heads (ppo_trad / pointwise_2data_trad)")
+ap.add_argument("--head-grads", type=int, default=0, help="train-mode (dropout pinned) value + gradients of the full-size Critic for random (batch, tags, index) vs the oracle's autograd")
 ap.add_argument("--heads", type=int, default=0, help="random (batch, tags, index) cases of the full-size Actor / Critic / Reward vs the oracle")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -287,6 +288,40 @@ if a.trad:
             bad += 1
             print("TRAD MISMATCH bs", bs, "docs", docs, "idx", idx.shape, "width", width, "errs", (e1, e2, e3), flush=True)
     print("trad cases done; total bad", bad, flush=True)
+
+# ---- full-size Critic in train mode: value and gradients for random batch / tags / index (duplicates) vs oracle autograd ----
+if a.head_grads:
+    import argparse as _ap3
+    from lr2ppo_amd import runtime
+    from lr2ppo_amd.finetune import ppo as _ppo
+    hargs = _ap3.Namespace(mode="reg", labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768)
+    Pc = O.seeded_params(O.head_param_spec("critic"), seed=8)
+    critic = _ppo.Critic(hargs, None)
+    critic.load_state_dict(Pc, strict=True)
+    critic = critic.to(dev).train()
+    names = ["text_proj.fc1.weight", "img_proj.fc2.weight", "xit.0.0.0.fn.1.keys.weight", "xit.0.0.1.fn.1.0.weight", "xit.1.0.weight",
+             "out_layer.fc1.weight", "out_layer.fc1.bias", "out_layer.fc2.weight", "pos_emb.weight", "xitt.0.0.0.fn.1.queries.weight",
+             "xitt.0.0.1.fn.1.3.bias", "head.weight", "head.bias"]
+    for it in range(a.head_grads):
+        bs, tags = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        text, img, _ = O.seeded_head_inputs(8000 + it, bs, tags)
+        index = torch.from_numpy(rng.integers(0, tags, size=(bs, int(rng.integers(1, 5))))).long()
+        wv = torch.randn(bs, generator=g)
+        runtime.set_dropout_seed(3000 + it, calls=1)
+        seed = runtime.peek_drop_seed()
+        value = critic.engine_forward(text.to(dev), img.to(dev), index.to(dev), save=True)
+        critic.engine_backward(wv.to(dev))
+        Pg = {k: v.clone().requires_grad_(True) for k, v in Pc.items()}
+        ref_v = O.critic_forward(Pg, text, img, index, drop={"p": 0.1, "seed": seed, "site_base": 0})
+        (ref_v * wv).sum().backward()
+        G = critic.grad_buffers()
+        e_v = (value.cpu() - ref_v.detach()).abs().max().item()
+        e_g = max((G[n].cpu() - Pg[n].grad).abs().max().item() / max(1e-12, float(Pg[n].grad.abs().max())) for n in names
+                  if float(Pg[n].grad.abs().max()) > 0)
+        if e_v > 1e-4 or e_g > 3e-3:
+            bad += 1
+            print("HEAD GRAD MISMATCH bs", bs, "tags", tags, "index", index.tolist(), "value err", e_v, "rel grad err", e_g, flush=True)
+    print("head gradient cases done; total bad", bad, flush=True)
 
 # ---- full-size heads: random batch / tag counts / index orders (duplicates allowed) against the CPU oracle ----
 if a.heads:
