@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 12
+#define LR2_ABI_VERSION 13
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -270,13 +270,18 @@ int lr2_adamw_multi(const lr2_adamw_chunk* table_dev, int n_chunks, double lr, d
 int lr2_text_embed(const int64_t* src, const int64_t* seg, const void* word, const void* pos, const void* seg_table,
                    void* out, int rows, int L, int D, int64_t vocab, int n_seg, int* err_flag, void* stream);
 /* Backward of lr2_text_embed's word / segment gathers (the position table's gradient is lr2_period_rows_grad), deterministic:
- * `order` = stable argsort of the token ids, `sorted_ids` = ids in that order; dword[tok, :] = sum of dx rows carrying tok, added
- * in original row order (rows of dword for absent tokens are NOT written: zero the table first); dseg[s, :] = sum of dx rows with
- * segment s via `seg_partials` (fp32 scratch, ceil(rows / LR2_TEXT_EMBED_BWD_ROWS_PER_BLOCK) * n_seg * D floats).  No atomics.
+ * `order` = stable argsort of the token ids, `sorted_ids` = ids in that order; dword[tok, :] = sum of dx rows carrying tok (rows of
+ * dword for PRESENT tokens are overwritten, rows for absent tokens are NOT written: zero the table first).  A run of equal ids is
+ * summed in original row order inside pieces of LR2_TEXT_EMBED_BWD_WORD_SEG sorted positions, the pieces of a long run (the padding
+ * id) in piece order through `word_partials` (fp32 scratch, 2 * ceil(rows / LR2_TEXT_EMBED_BWD_WORD_SEG) * D floats) -- a fixed
+ * order, and no single workgroup walks a long run alone.  dseg[s, :] = sum of dx rows with segment s via `seg_partials` (fp32
+ * scratch, ceil(rows / LR2_TEXT_EMBED_BWD_ROWS_PER_BLOCK) * n_seg * D floats).  No atomics.
  * replaces: autograd of nn.Embedding in tencentpretrain/embeddings/{word,seg}_embedding.py. */
 #define LR2_TEXT_EMBED_BWD_ROWS_PER_BLOCK 64
+#define LR2_TEXT_EMBED_BWD_WORD_SEG 256
 int lr2_text_embed_bwd(const void* dx, const int64_t* sorted_ids, const int64_t* order, const int64_t* seg, void* dword,
-                       void* dseg, void* seg_partials, int rows, int D, int64_t vocab, int n_seg, void* stream);
+                       void* dseg, void* seg_partials, void* word_partials, int rows, int D, int64_t vocab, int n_seg,
+                       void* stream);
 /* dst = dropout_mask(src) / (1 - p), fp32, mask element index = flat element index (src == dst allowed).
  * replaces: self.dropout of tencentpretrain/embeddings/embedding.py:33 and its autograd. */
 int lr2_dropout_apply(const void* src, void* dst, uint64_t n, float drop_p, uint64_t drop_seed, uint32_t drop_site,
@@ -294,7 +299,8 @@ int lr2_patchify_planes(const void* img, int is_u8, void* out_hi, uint64_t lo_of
                         const float* mean3, const float* std3, void* stream);
 /* NDCG@ks[q] per ragged item i (elements offsets[i] .. offsets[i+1], at most 64): sort by score descending (stable), gain
  * 2^rel - 1, discount disc[j] (= log2(j + 2), device fp32 table supplied by the caller), sequential fp32 sums, 1 when the ideal
- * DCG <= 1e-6.  out: fp32 [n_items, n_k].
+ * DCG <= 1e-6.  out: fp32 [n_items, n_k].  An item with more than 64 elements, or with a label outside [0, 62] (2^rel - 1 in
+ * int64), gets a row of NaN -- never a truncated or wrapped value (the entry point cannot see device-side sizes without a sync).
  * replaces: finetune/ppo.py:651-659 + ndcg.py:28-65 (AverageNDCGMeter.return_ndcg_at_k). */
 int lr2_ndcg(const void* scores, const int64_t* gold, const int64_t* offsets, const void* disc, const int64_t* ks, int n_k,
              void* out, int n_items, void* stream);

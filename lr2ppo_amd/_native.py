@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(CSRC, "liblr2ppo_hip.so")
 SOURCES = ["gemm.hip", "gemm256.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
 
-ABI_VERSION = 12     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
+ABI_VERSION = 13     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
 
 _lock = threading.Lock()
 _lib = None
@@ -91,7 +91,7 @@ SIGNATURES = {
     "lr2_split_planes": [_P, _P, _U64, _U64, _P],
     "lr2_dropout_planes": [_P, _P, _U64, _U64, _F, _U64, _U32, _P],
     "lr2_dropout_apply": [_P, _P, _U64, _F, _U64, _U32, _P],
-    "lr2_text_embed_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, C.c_int64, _I, _P],
+    "lr2_text_embed_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, C.c_int64, _I, _P],
     "lr2_split_planes_t": [_P, _P, _U64, _I, _I, _P],
     "lr2_split_planes_multi": [_P, _I, _P],
     "lr2_layernorm_fwd": [_P, _P, _P, _P, _P, _U64, _P, _P, _I, _I, _F, _I, _I, _U64, _P],

@@ -92,24 +92,56 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
 
 // Backward of the word / segment embedding gathers, deterministic (no float atomics: run-to-run identical bits).
 // Word table: the caller passes the rows sorted by token id (`order` = stable argsort of the ids, `sorted_ids` = ids in
-// that order).  Workgroup r owns the run of equal ids that STARTS at sorted position r (others exit at once) and adds
-// its rows in sorted order -- i.e. in original row order, the order a sequential scatter-add would use.
+// that order).  A run of equal ids is cut at the multiples of WORD_SEG sorted positions into PIECES; workgroup r owns the piece
+// that starts at sorted position r (a run start, or a multiple of WORD_SEG inside a run; every other workgroup exits at once)
+// and adds its rows in sorted order = original row order.  A run that is one piece (every ordinary token) is written straight
+// to its table row.  A longer run (the padding id of a 640 x 196 batch is ~1e5 rows) leaves one partial per piece --
+// slot 2c+1 for the piece holding the run's start in chunk c, slot 2c for a piece that starts chunk c -- and
+// text_embed_bwd_word_finish adds the partials of a run in piece order: fixed order, chip-wide parallel.
+constexpr int WORD_SEG = LR2_TEXT_EMBED_BWD_WORD_SEG;
 __global__ __launch_bounds__(256) void text_embed_bwd_word_kernel(const float* __restrict__ dx, const int64_t* __restrict__ sorted_ids,
                                                                   const int64_t* __restrict__ order, float* __restrict__ dword,
-                                                                  int rows, int D, int64_t vocab) {
+                                                                  float* __restrict__ partials, int rows, int D, int64_t vocab) {
   const int r = blockIdx.x;
   const int64_t tok = sorted_ids[r];
-  if (r > 0 && sorted_ids[r - 1] == tok) return;
+  const bool run_start = (r == 0) || sorted_ids[r - 1] != tok;
+  if (!run_start && (r % WORD_SEG) != 0) return;
   if (tok < 0 || tok >= vocab) return;          // flagged by the forward; never written
+  const int cut = min(rows, (r / WORD_SEG + 1) * WORD_SEG);
   int end = r + 1;
-  while (end < rows && sorted_ids[end] == tok) ++end;
+  while (end < cut && sorted_ids[end] == tok) ++end;
+  const bool run_ends = (end == rows) || sorted_ids[end] != tok;
+  float* dst = (run_start && run_ends) ? dword + (size_t)tok * D
+                                       : partials + ((size_t)2 * (r / WORD_SEG) + (run_start ? 1 : 0)) * D;
   for (int c = threadIdx.x * 4; c < D; c += 256 * 4) {
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = r; j < end; ++j) {
       const float4 v = *reinterpret_cast<const float4*>(dx + (size_t)order[j] * D + c);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
-    *reinterpret_cast<float4*>(dword + (size_t)tok * D + c) = a;
+    *reinterpret_cast<float4*>(dst + c) = a;
+  }
+}
+// One workgroup per chunk c of WORD_SEG sorted positions: if the run that crosses the chunk's upper boundary STARTS in this chunk,
+// sum its pieces (slot 2c+1, then slots 2(c+1), 2(c+2), ... while the run goes on) into the table row.
+__global__ __launch_bounds__(256) void text_embed_bwd_word_finish(const int64_t* __restrict__ sorted_ids, const float* __restrict__ partials,
+                                                                  float* __restrict__ dword, int rows, int D, int64_t vocab) {
+  const int c = blockIdx.x;
+  const int last = (c + 1) * WORD_SEG - 1;
+  if (last + 1 >= rows) return;                                  // nothing beyond this chunk
+  const int64_t tok = sorted_ids[last];
+  if (sorted_ids[last + 1] != tok) return;                        // no run crosses the boundary
+  if (c > 0 && sorted_ids[c * WORD_SEG - 1] == tok) return;       // the run started in an earlier chunk: finished there
+  if (tok < 0 || tok >= vocab) return;
+  int n_cont = 0;                                                 // continuation pieces: chunks c+1 .. c+n_cont
+  while ((c + 1 + n_cont) * WORD_SEG < rows && sorted_ids[(c + 1 + n_cont) * WORD_SEG] == tok) ++n_cont;
+  for (int col = threadIdx.x * 4; col < D; col += 256 * 4) {
+    float4 a = *reinterpret_cast<const float4*>(partials + ((size_t)2 * c + 1) * D + col);
+    for (int k = 1; k <= n_cont; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(partials + (size_t)2 * (c + k) * D + col);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dword + (size_t)tok * D + col) = a;
   }
 }
 // Segment table (n_seg <= 4 rows): per-workgroup partial sums over a contiguous chunk of rows, [block][n_seg][D];
@@ -726,13 +758,15 @@ __global__ __launch_bounds__(64) void ndcg_kernel(const float* __restrict__ scor
   const int item = blockIdx.x * 64 + threadIdx.x;
   if (item >= n_items) return;
   const int64_t o0 = offsets[item];
-  int T = (int)(offsets[item + 1] - o0);
-  if (T > NDCG_MAX_T) T = NDCG_MAX_T;
+  const int64_t T64 = offsets[item + 1] - o0;
+  bool bad = T64 < 0 || T64 > NDCG_MAX_T;   // an item this kernel cannot rank: its row is NaN, never a truncated NDCG
+  const int T = bad ? 0 : (int)T64;
   float sc[NDCG_MAX_T];
   int64_t by_score[NDCG_MAX_T], ideal[NDCG_MAX_T];
   for (int i = 0; i < T; ++i) {           // insertion sorts (T <= 64, typically 20)
     const float s = scores[o0 + i];
     const int64_t g = gold[o0 + i];
+    bad |= (g < 0 || g > 62);             // gain 2^rel - 1 in int64 (ndcg.py:28): a shift by < 0 or >= 63 is undefined
     int j = i;
     while (j > 0 && sc[j - 1] < s) { sc[j] = sc[j - 1]; by_score[j] = by_score[j - 1]; --j; }
     sc[j] = s; by_score[j] = g;
@@ -745,10 +779,10 @@ __global__ __launch_bounds__(64) void ndcg_kernel(const float* __restrict__ scor
     const int n = (int)(k < (int64_t)T ? k : (int64_t)T);
     float pred = 0.f, tru = 0.f;
     for (int i = 0; i < n; ++i) {
-      pred += (float)((1ll << by_score[i]) - 1) / disc[i];
-      tru += (float)((1ll << ideal[i]) - 1) / disc[i];
+      pred += (float)((1ll << (by_score[i] & 63)) - 1) / disc[i];
+      tru += (float)((1ll << (ideal[i] & 63)) - 1) / disc[i];
     }
-    out[(size_t)item * n_k + q] = (tru <= 1e-6f) ? 1.0f : pred / tru;
+    out[(size_t)item * n_k + q] = bad ? __builtin_nanf("") : ((tru <= 1e-6f) ? 1.0f : pred / tru);
   }
 }
 
@@ -852,14 +886,21 @@ extern "C" int lr2_dropout_apply(const void* src, void* dst, uint64_t n, float d
 }
 
 extern "C" int lr2_text_embed_bwd(const void* dx, const int64_t* sorted_ids, const int64_t* order, const int64_t* seg,
-                                  void* dword, void* dseg, void* seg_partials, int rows, int D, int64_t vocab, int n_seg,
-                                  void* stream) {
-  if (!dx || !sorted_ids || !order || !seg || !dword || !dseg || !seg_partials || rows <= 0 || D <= 0) return LR2_ERR_ARG;
+                                  void* dword, void* dseg, void* seg_partials, void* word_partials, int rows, int D,
+                                  int64_t vocab, int n_seg, void* stream) {
+  if (!dx || !sorted_ids || !order || !seg || !dword || !dseg || !seg_partials || !word_partials || rows <= 0 || D <= 0)
+    return LR2_ERR_ARG;
   if (D % 4 || n_seg < 1 || n_seg > 4) return LR2_ERR_SHAPE;
   hipStream_t s = (hipStream_t)stream;
-  LR2_LAUNCH(text_embed_bwd_word_kernel, dim3(rows), dim3(256), 0, s, (const float*)dx, sorted_ids, order, (float*)dword, rows,
-             D, vocab);
+  LR2_LAUNCH(text_embed_bwd_word_kernel, dim3(rows), dim3(256), 0, s, (const float*)dx, sorted_ids, order, (float*)dword,
+             (float*)word_partials, rows, D, vocab);
   if (lr2_launch_status(__func__)) return LR2_ERR_LAUNCH;
+  const int chunks = (rows + WORD_SEG - 1) / WORD_SEG;
+  if (chunks > 1) {
+    LR2_LAUNCH(text_embed_bwd_word_finish, dim3(chunks - 1), dim3(256), 0, s, sorted_ids, (const float*)word_partials,
+               (float*)dword, rows, D, vocab);
+    if (lr2_launch_status(__func__)) return LR2_ERR_LAUNCH;
+  }
   const int rows_per_block = LR2_TEXT_EMBED_BWD_ROWS_PER_BLOCK;
   const int nb = (rows + rows_per_block - 1) / rows_per_block;
   LR2_LAUNCH(text_embed_bwd_seg_kernel, dim3(nb), dim3(256), 0, s, (const float*)dx, seg, (float*)seg_partials, rows, D, n_seg,

@@ -400,9 +400,13 @@ def trunk_forward(ws: Workspace, P, W, text, img, bs: int, tags: int, n_img: int
 
 
 def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *, drop: Optional[DropCfg] = None,
-                   img_shared: bool = False, dp=None, fc1_update=None, fc1_early: bool = False):
-    """Backward of trunk_forward(save=True); fills G[...] for every trunk parameter (inputs get no gradient:
-    text/img embeddings are data, finetune/ppo.py:827-835).  dg2: fp32 [bs*tags, E].
+                   img_shared: bool = False, dp=None, fc1_update=None, fc1_early: bool = False, input_grads: bool = False):
+    """Backward of trunk_forward(save=True); fills G[...] for every trunk parameter.  dg2: fp32 [bs*tags, E].
+    input_grads: also return (d text [bs*tags*196, E], d img [Mi_src, E]) as fresh fp32 tensors -- the gradients the
+    reference's autograd hands to whatever produced text_emb / img_emb (encoders being fine-tuned behind the head:
+    finetune/ppo.py:214-232 is plain autograd, tencentpretrain/models/model.py:32-41).  Two NN GEMMs on operands the
+    backward already holds (dz1 x text_proj.fc1.weight, dzi x img_proj.fc1.weight); the PPO loop feeds pre-extracted
+    features (finetune/ppo.py:827-835) and leaves it off.
     fc1_update (ops.AdamArgs): apply the optimizer step of out_layer.fc1.weight inside its weight-gradient GEMM, issued
     after the last reader of the old weight (the input-gradient GEMM); G[out_layer.fc1.weight] is then left untouched.
     fc1_early: issue that fused update right behind the input-gradient GEMM instead of at the very end -- same operands, same
@@ -424,7 +428,7 @@ def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *
     linear_wgrad(ws, dg2p, g1, G["out_layer.fc2.weight"], G["out_layer.fc2.bias"], N, F, E)
     dzo = ws.planes("dzo", N, F)
     linear_dgrad(ws, dg2p, W["out_layer.fc2.weight"], None, N, F, E, act=2, aux_z=zo, out_planes=dzo)
-    if dp is not None and dp.world > 1:
+    if dp is not None and dp.active:
         # Data parallel: dW_fc1 = sum over ranks of dzo_r^T flat_r is a rank-(N*world) product of two thin factors.
         # All-gather the factors (42 MB per rank) instead of all-reducing the 2 GB product; the gathers run on the
         # communication stream while the rest of backward proceeds, the K = N*world wgrad GEMM is issued last.
@@ -465,6 +469,10 @@ def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *
     linear_dgrad(ws, dtf_p, W["text_proj.fc2.weight"], None, Mt, F, E, act=2, aux_z=z1, out_planes=dz1,
                  w_f32=P["text_proj.fc2.weight"])
     linear_wgrad(ws, dz1, text, G["text_proj.fc1.weight"], G["text_proj.fc1.bias"], Mt, E, F)
+    d_text = d_img = None
+    if input_grads:
+        d_text = torch.empty(Mt, E, dtype=torch.float32, device=ws.device)
+        linear_dgrad(ws, dz1, W["text_proj.fc1.weight"], d_text, Mt, E, F, w_f32=P["text_proj.fc1.weight"])
     # img_proj
     if shared:
         dimf_src = ws.mat("dimf_src", Mi_src, E)   # sum the per-tag gradients of the shared image tokens
@@ -476,12 +484,16 @@ def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *
     dzi = ws.planes("dzi", Mi_src, F)
     linear_dgrad(ws, dimf_p, W["img_proj.fc2.weight"], None, Mi_src, F, E, act=2, aux_z=zi, out_planes=dzi)
     linear_wgrad(ws, dzi, img, G["img_proj.fc1.weight"], G["img_proj.fc1.bias"], Mi_src, E, F)
+    if input_grads:
+        d_img = torch.empty(Mi_src, E, dtype=torch.float32, device=ws.device)
+        linear_dgrad(ws, dzi, W["img_proj.fc1.weight"], d_img, Mi_src, E, F, w_f32=P["img_proj.fc1.weight"])
     if (fc1_pending is not None or fc1_update is not None) and not early:
         if fc1_pending is not None:
             dzo_all, flat_all = dp.gather_planes_finish(fc1_pending[0]), dp.gather_planes_finish(fc1_pending[1])
             fused_fc1_update(dzo_all, flat_all, N * dp.world, 1.0 / dp.world)            # already the rank average
         else:
             fused_fc1_update(dzo, flat, N, 1.0)
+    return d_text, d_img
 
 
 # ---------------------------------------------------------------------------------------------

@@ -130,6 +130,72 @@ class FeatureExtractor(nn.Module):
         text_emb = self.text_features(ids, seg)
         return text_emb, img_emb
 
+    # ---- explicit training schedule: the encoders fine-tuned behind a head, no autograd graph ------------------------------
+    # forward_train keeps what the hand-written backward needs (one arena per stack), backward_train takes the head's input
+    # gradients (engine_backward(input_grads=True)) and writes every encoder / embedding gradient into persistent flat buffers
+    # that bind_grads() exposes as p.grad.  Same kernels and numerics as the autograd route (Actor(*fx(frames, ids, seg)) with
+    # loss.backward()), which stays available; this one allocates nothing per step but the activation arenas.
+    def _stacks(self):
+        return ((self.image.embedding, self.image.encoder), (self.text.embedding, self.text.encoder))
+
+    def bind_grads(self):
+        """p.grad of every encoder / embedding parameter -> its slice of the module's persistent gradient buffer."""
+        for emb, enc in self._stacks():
+            for mod in (emb, enc):
+                for q, g in mod.grad_buffers().items():
+                    if q.grad is None or q.grad.data_ptr() != g.data_ptr():
+                        q.grad = g
+
+    def grad_flats(self):
+        """The four flat gradient buffers (image embedding / encoder, text embedding / encoder): what a data-parallel run
+        all-reduces, one collective each."""
+        out = []
+        for emb, enc in self._stacks():
+            for mod in (emb, enc):
+                mod.grad_buffers()
+                out.append(mod._gflat)
+        return out
+
+    @torch.no_grad()
+    def forward_train(self, frames, ids, seg=None):
+        """-> (text_emb [B, T, L, E], img_emb [B, n_img, E], ctx) with dropout at the reference's sites when self.training
+        (embedding dropout, attention probabilities, dropout_1, dropout_2: embeddings/embedding.py:33, layers/transformer.py:50-73,
+        multi_headed_attn.py:68); ctx goes to backward_train."""
+        if not frames.is_cuda or not ids.is_cuda:
+            raise TypeError("lr2ppo_amd: frames / ids must live on the HIP device (no CPU path)")
+        B, n_img = frames.shape[:2]
+        T, L = ids.shape[1:]
+        if L != self.seq_length:
+            raise ValueError(f"token sequences must have length {self.seq_length} (finetune/ppo.py:219-220), got {L}")
+        if seg is None:
+            seg = torch.ones_like(ids)
+        vseg = torch.ones(B * n_img, self.vit_args.max_seq_length, dtype=torch.int64, device=frames.device)
+        e_img, s_img_emb = self.image.embedding._run(frames.reshape(B * n_img, *frames.shape[2:]), vseg, save=True)
+        h_img, s_img_enc = self.image.encoder._forward_train(e_img, vseg)
+        img_emb = h_img[:, 0, :].reshape(B, n_img, -1).contiguous()      # pooling 'first' with seg == 1 (utils/misc.py:23-35)
+        tseg = seg.reshape(B * T, L)
+        e_txt, s_txt_emb = self.text.embedding._run(ids.reshape(B * T, L), tseg, save=True)
+        h_txt, s_txt_enc = self.text.encoder._forward_train(e_txt, tseg)
+        text_emb = h_txt.reshape(B, T, L, -1).clone()                    # not a view of the activation arena
+        ctx = {"img": (s_img_emb, s_img_enc, tuple(h_img.shape)), "txt": (s_txt_emb, s_txt_enc)}
+        return text_emb, img_emb, ctx
+
+    @torch.no_grad()
+    def backward_train(self, ctx, d_text, d_img):
+        """Gradients of every encoder / embedding parameter for the forward that produced ctx, given d loss / d text_emb and
+        d loss / d img_emb; written into the persistent buffers (bind_grads())."""
+        s_txt_emb, s_txt_enc = ctx.pop("txt")
+        B_, L, E = s_txt_enc["dims"][:3]
+        d_emb, _ = self.text.encoder._backward_train(s_txt_enc, d_text.reshape(B_, L, E).contiguous(),
+                                                     G=self.text.encoder.grad_buffers())
+        self.text.embedding._backward(s_txt_emb, d_emb, G_out=self.text.embedding.grad_buffers())
+        del s_txt_enc, s_txt_emb, d_emb
+        s_img_emb, s_img_enc, hshape = ctx.pop("img")
+        dout = torch.zeros(hshape, device=d_img.device)                  # only the pooled [CLS] row carries a gradient
+        dout[:, 0, :] = d_img.reshape(-1, hshape[-1])
+        d_emb, _ = self.image.encoder._backward_train(s_img_enc, dout, G=self.image.encoder.grad_buffers())
+        self.image.embedding._backward(s_img_emb, d_emb, G_out=self.image.embedding.grad_buffers())
+
     @torch.no_grad()
     def extract(self, frames, ids, seg=None, check_ids: bool = True):
         """Inference-mode forward (the encoders are frozen feature extractors in front of the PPO loop)."""
@@ -154,3 +220,61 @@ def synthetic_raw_batch(batch: int, tags: int, n_img: int = 16, seq_length: int 
     seg = (torch.arange(seq_length, device=device).view(1, 1, -1) < lens).to(torch.int64)
     tgts = torch.randint(0, 3, (batch, tags), device=device, generator=generator)
     return frames, ids, seg, tgts
+
+
+def build_encoder_optimizer(args, fx: FeatureExtractor):
+    """AdamW + schedule over the two encoder stacks with the reference's grouping (weight decay 0.01 except names containing
+    bias / gamma / beta: finetune/ppo.py:381-393, the rule of every TencentPretrain fine-tuning script) -> (optimizer, scheduler)."""
+    from ..tencentpretrain.utils.optimizers import str2optimizer, str2scheduler
+    from .ppo import _grouped
+    opt = str2optimizer[args.optimizer](_grouped(list(fx.named_parameters())), lr=args.learning_rate, correct_bias=False)
+    if args.scheduler == "constant":
+        sch = str2scheduler[args.scheduler](opt)
+    elif args.scheduler == "constant_with_warmup":
+        sch = str2scheduler[args.scheduler](opt, args.train_steps * args.warmup)
+    else:
+        sch = str2scheduler[args.scheduler](opt, args.train_steps * args.warmup, args.train_steps)
+    return opt, sch
+
+
+def finetune_pointwise_step(args, fx: FeatureExtractor, model, optimizer, scheduler, enc_optimizer, enc_scheduler, frames, ids, seg,
+                            tgts):
+    """BASELINE configs[1] with the encoders trained end to end: frames + token ids -> ViT-B/16 + RoBERTa-base (train mode) ->
+    finetune/pointwise.py's Classifier -> SmoothL1 (NLL in 'cls') -> head backward WITH input gradients -> encoder + embedding
+    backward -> AdamW over the head and over both stacks, one scheduler step each.  The composition is the reference's own
+    `encoder(embedding(src, seg), seg)` feeding a target (tencentpretrain/models/model.py:32-41) with the stage-1 head as the
+    target (finetune/pointwise.py:300-313); gradients are averaged over ranks before the steps.  -> loss (0-dim device tensor)."""
+    import torch.distributed as dist
+    from .ppo import _DataParallel
+    dev = frames.device
+    model.bind_grads()
+    fx.bind_grads()
+    dp = _DataParallel()
+    text_emb, img_emb, ctx = fx.forward_train(frames, ids, seg)
+    logits = model.engine_forward(text_emb, img_emb, save=True)
+    loss, dlogits = torch.empty(1, device=dev), torch.empty_like(logits)
+    if model.n_out > 1:
+        ops.nll_loss(logits, tgts.to(device=dev, dtype=torch.int64).contiguous().view(-1), loss, dlogits, rows=logits.shape[0],
+                     C=model.n_out)
+    else:
+        ops.smooth_l1(logits.view(-1), tgts.to(device=dev, dtype=torch.float32).contiguous().view(-1), loss, dlogits.view(-1),
+                      n=logits.numel(), beta=0.3)
+    fuse = getattr(args, "fuse_fc1_update", True) and hasattr(optimizer, "external_update")
+    fa = optimizer.external_update(model.out_layer.fc1.weight) if fuse else None
+    d_text, d_img = model.engine_backward(dlogits, dp, fc1_update=fa, input_grads=True)
+    wh = dp.reduce_start(model)                      # the head's tail all-reduce overlaps the encoder backward
+    del text_emb, logits
+    fx.backward_train(ctx, d_text, d_img)
+    works = []
+    if dp.active:
+        for g in fx.grad_flats():
+            g.div_(dp.world)
+            works.append(dist.all_reduce(g, async_op=True))
+    dp.finish(wh)
+    optimizer.step()
+    for w in works:
+        w.wait()
+    enc_optimizer.step()
+    scheduler.step()
+    enc_scheduler.step()
+    return loss[0]

@@ -72,7 +72,10 @@ class Classifier(pt.Classifier):
         return logits.view(-1, 1)
 
     @torch.no_grad()
-    def engine_backward(self, dlogits):
+    def engine_backward(self, dlogits, input_grads: bool = False):
+        if input_grads:
+            raise NotImplementedError("pointwise_2data_trad.Classifier: the raw LETOR feature rows (46 / 136 columns) are data; "
+                                      "their gradient is not built -- detach text_emb")
         x0, N, drop, Kin = self._saved
         ws, P, G = self._ws, self._P(), self.grad_buffers()
         W = self._wp.planes

@@ -82,10 +82,13 @@ class Classifier(nn.Module):
         ops.head_fwd(g2, P["head.weight"], P["head.bias"], logits, rows=N, D=E)
         if save:
             self._saved = (x0, N, drop)
+            self._in_shape = tuple(text_emb.shape)
         return logits.view(-1, 1)
 
     @torch.no_grad()
-    def engine_backward(self, dlogits):
+    def engine_backward(self, dlogits, input_grads: bool = False):
+        """input_grads: -> d text_emb (a fresh tensor in the forward's shape), for a caller that trains what produced the
+        features; else None."""
         x0, N, drop = self._saved
         ws, P, G = self._ws, self._P(), self.grad_buffers()
         W = self._wp.planes
@@ -93,11 +96,12 @@ class Classifier(nn.Module):
         g2 = ws.mat("g2", N, E)
         dg2 = ws.mat("dg2", N, E)
         ops.head_bwd(g2, P["head.weight"], dlogits.contiguous().view(-1), dg2, G["head.weight"], G["head.bias"], rows=N, D=E)
-        engine.trad_trunk_backward(ws, P, W, G, x0, dg2, N, E, drop=drop)
+        dx0 = engine.trad_trunk_backward(ws, P, W, G, x0, dg2, N, E, drop=drop, want_dx=input_grads)
         self._saved = None
+        return dx0.clone().view(self._in_shape) if input_grads else None
 
     def forward(self, text_emb, img_emb=None, tgts=None):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and (text_emb.requires_grad or any(p.requires_grad for p in self.parameters())):
             logits = _TradFn.apply(self, text_emb, *list(self.parameters()))
         else:
             logits = self.engine_forward(text_emb, save=False)
@@ -115,10 +119,10 @@ class _TradFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         m = ctx.model
-        m.engine_backward(dlogits.contiguous())
+        dx = m.engine_backward(dlogits.contiguous(), input_grads=ctx.needs_input_grad[1])    # the gradient, or a raise: never a silent None
         G = m.grad_buffers()
         unused = tuple(getattr(m, "_unused_prefixes", ()))      # pointwise_2data_trad: the projection this batch did not go through
-        return (None, None) + tuple(G[n].clone() if (p.requires_grad and not n.startswith(unused)) else None
+        return (None, dx) + tuple(G[n].clone() if (p.requires_grad and not n.startswith(unused)) else None
                                     for n, p in m.named_parameters())
 
 

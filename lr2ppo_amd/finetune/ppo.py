@@ -189,6 +189,7 @@ class _Head(nn.Module):
             raise ValueError("mode='cls' supports at most 8 labels (lr2_cls_head_fwd)")
         self.head = nn.Linear(FEAT, self.n_out)
         self._P_cache: Optional[Dict[str, torch.Tensor]] = None
+        self._P_sig = []
         self._ws: Optional[engine.Workspace] = None
         self._wp: Optional[engine.WeightPlanes] = None
         self._G: Optional[Dict[str, torch.Tensor]] = None
@@ -202,12 +203,19 @@ class _Head(nn.Module):
         return self._ws
 
     def _P(self) -> Dict[str, torch.Tensor]:
-        """name -> parameter storage.  Cached: walking named_parameters() costs ~1 ms per call and a PPO step makes seven;
-        nn.Module._apply (.to / .cuda / .float) is the only thing that re-seats parameter storage, and it clears the cache."""
+        """name -> parameter storage.  Cached: walking named_parameters() costs ~1 ms per call and a PPO step makes seven.  The
+        cache is checked against EVERY parameter's current storage address (one data_ptr() per parameter, ~5 us), so anything
+        that re-seats a parameter -- .to() / .cuda(), load_state_dict(assign=True), `p.data = ...` -- rebuilds it."""
         c = self._P_cache
-        if c is None or c["head.weight"].data_ptr() != self.head.weight.data_ptr() \
-                or c["out_layer.fc1.weight"].data_ptr() != self.out_layer.fc1.weight.data_ptr():
-            c = self._P_cache = {n: p.data for n, p in self.named_parameters()}
+        if c is not None:
+            for p, ptr in self._P_sig:
+                if p.data_ptr() != ptr:
+                    c = None
+                    break
+        if c is None:
+            named = list(self.named_parameters())
+            c = self._P_cache = {n: p.data for n, p in named}
+            self._P_sig = [(p, p.data_ptr()) for _, p in named]
         return c
 
     def _apply(self, fn, *a, **kw):
@@ -299,7 +307,7 @@ class Actor(_Head):
     mode 'reg': logits [bs*tags], SmoothL1(beta = 0.3); mode 'cls': logits [bs*tags, labels_num], NLL of log-softmax."""
 
     def forward(self, text_emb, img_emb, tgts=None):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and (_wants_grad(text_emb, img_emb) or any(p.requires_grad for p in self.parameters())):
             logits = _ActorFn.apply(self, text_emb, img_emb, *list(self.parameters()))
         else:
             logits = self.engine_forward(text_emb, img_emb, save=False)
@@ -330,10 +338,13 @@ class Actor(_Head):
             ops.cls_head_fwd(g2, P["head.weight"], P["head.bias"], logits, rows=bs * tags, D=FEAT, C=self.n_out)
         if save:
             self._saved = (text2, img2, bs, tags, n_img, shared, drop)
+            self._in_shapes = (tuple(text_emb.shape), None if img_emb is None else tuple(img_emb.shape))
         return logits
 
-    def engine_backward(self, dlogits: torch.Tensor, dp=None, fc1_update=None):
-        """Gradients of sum(dlogits * logits) into the flat gradient buffer (call after engine_forward(save=True))."""
+    def engine_backward(self, dlogits: torch.Tensor, dp=None, fc1_update=None, input_grads: bool = False):
+        """Gradients of sum(dlogits * logits) into the flat gradient buffer (call after engine_forward(save=True)).
+        input_grads: -> (d text_emb, d img_emb) in the shapes the forward was given (what the reference's autograd passes on
+        to a producer of the features, finetune/ppo.py:214-232); otherwise (None, None)."""
         text2, img2, bs, tags, n_img, shared, drop = self._saved
         P, G = self._P(), self.grad_buffers()
         ws, W = self._workspace(dlogits.device), self._weights(P, refresh=False)
@@ -348,11 +359,16 @@ class Actor(_Head):
         if self.TRAD:
             if fc1_update is not None:
                 raise ValueError("the fused out_layer.fc1 update belongs to the 2-GB matrix of the full heads; pass fuse_fc1_update=False")
-            engine.trad_trunk_backward(ws, P, W, G, text2, dg2, N, FEAT, drop=drop)
+            dx0 = engine.trad_trunk_backward(ws, P, W, G, text2, dg2, N, FEAT, drop=drop, want_dx=input_grads)
+            d_text, d_img = (dx0.clone().view(self._in_shapes[0]) if input_grads else None), None
         else:
-            engine.trunk_backward(ws, P, W, G, text2, img2, dg2, bs, tags, n_img, FEAT, drop=drop, img_shared=shared, dp=dp,
-                                  fc1_update=fc1_update)
+            d_text, d_img = engine.trunk_backward(ws, P, W, G, text2, img2, dg2, bs, tags, n_img, FEAT, drop=drop,
+                                                  img_shared=shared, dp=dp, fc1_update=fc1_update, input_grads=input_grads)
+            if input_grads:
+                d_text = d_text.view(self._in_shapes[0])
+                d_img = _shape_img_grad(d_img, self._in_shapes[1], bs, n_img)
         self._saved = None
+        return d_text, d_img
 
     def action_scores(self, logits: torch.Tensor, bs: int, tags: int, want_probs: bool = False):
         """The per-tag score the PPO loop ranks by: the logit itself ('reg'), or the expected label under softmax(logits)
@@ -369,7 +385,7 @@ class _TailHead(_Head):
     has_tail = True
 
     def forward(self, text_emb, img_emb, tgts, index):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and (_wants_grad(text_emb, img_emb) or any(p.requires_grad for p in self.parameters())):
             return _CriticFn.apply(self, text_emb, img_emb, index, *list(self.parameters()))
         return self.engine_forward(text_emb, img_emb, index, save=False)
 
@@ -451,9 +467,14 @@ class _TailHead(_Head):
         ops.head_fwd(xo, P["head.weight"], P["head.bias"], value, rows=bs, D=FEAT, row_step=t_out, row_off=t_out - 1)
         if save:
             self._saved = (text_p, img_p, bs, t_out, n_img, drop, drop_t)
+            self._in_shapes = (tuple(text_emb.shape), None if img_emb is None else tuple(img_emb.shape), index, tags_in,
+                               None if self.TRAD else engine._img_shared(img_emb))
         return value
 
-    def engine_backward(self, dvalue: torch.Tensor, dp=None, fc1_update=None, fc1_early: bool = False):
+    def engine_backward(self, dvalue: torch.Tensor, dp=None, fc1_update=None, fc1_early: bool = False,
+                        input_grads: bool = False):
+        """input_grads: -> (d text_emb, d img_emb) in the forward's input shapes: the trunk's input gradients scattered back
+        through the `index` gather of finetune/ppo.py:267-271 (a tag picked twice receives the sum); else (None, None)."""
         text_g, img_g, bs, t_out, n_img, drop, drop_t = self._saved
         P, G = self._P(), self.grad_buffers()
         ws, W = self._workspace(dvalue.device), self._weights(P, refresh=False)
@@ -470,11 +491,34 @@ class _TailHead(_Head):
         if self.TRAD:
             if fc1_update is not None:
                 raise ValueError("the fused out_layer.fc1 update belongs to the 2-GB matrix of the full heads; pass fuse_fc1_update=False")
-            engine.trad_trunk_backward(ws, P, W, G, text_g, dxin, M, FEAT, drop=drop)
+            dx0 = engine.trad_trunk_backward(ws, P, W, G, text_g, dxin, M, FEAT, drop=drop, want_dx=input_grads)
+            d_text = d_img = None
+            if input_grads:
+                t_shape, _, index, tags_in, _ = self._in_shapes
+                d_text = torch.empty(t_shape, device=dx0.device)
+                ops.gather_rows_bwd(dx0.view(bs, t_out, FEAT), index, d_text, B=bs, t_in=tags_in, t_out=t_out, row_elems=FEAT)
         else:
-            engine.trunk_backward(ws, P, W, G, text_g, img_g, dxin, bs, t_out, n_img, FEAT, drop=drop, img_shared=False, dp=dp,
-                                  fc1_update=fc1_update, fc1_early=fc1_early)
+            d_text, d_img = engine.trunk_backward(ws, P, W, G, text_g, img_g, dxin, bs, t_out, n_img, FEAT, drop=drop,
+                                                  img_shared=False, dp=dp, fc1_update=fc1_update, fc1_early=fc1_early,
+                                                  input_grads=input_grads)
+            if input_grads:
+                t_shape, i_shape, index, tags_in, shared_in = self._in_shapes
+                dev = d_text.device
+                dt = torch.empty(t_shape, device=dev)
+                ops.gather_rows_bwd(d_text.view(bs, t_out, SEQ_LEN * FEAT), index, dt, B=bs, t_in=tags_in, t_out=t_out,
+                                    row_elems=SEQ_LEN * FEAT)
+                if shared_in:         # every position reads the item's one set of image tokens: sum over positions
+                    di = torch.empty(bs, n_img, FEAT, device=dev)
+                    ops.gather_rows_bwd(d_img.view(bs, t_out, n_img * FEAT), torch.zeros(bs, t_out, dtype=torch.int64, device=dev),
+                                        di, B=bs, t_in=1, t_out=t_out, row_elems=n_img * FEAT)
+                    di = _shape_img_grad(di.view(bs * n_img, FEAT), i_shape, bs, n_img)
+                else:
+                    di = torch.empty(i_shape, device=dev)
+                    ops.gather_rows_bwd(d_img.view(bs, t_out, n_img * FEAT), index, di, B=bs, t_in=tags_in, t_out=t_out,
+                                        row_elems=n_img * FEAT)
+                d_text, d_img = dt, di
         self._saved = None
+        return d_text, d_img
 
 
 class Critic(_TailHead):
@@ -543,8 +587,33 @@ class _NllFn(torch.autograd.Function):
         return (ctx.dl * dloss if ctx.dl is not None else None), None
 
 
+def _wants_grad(*tensors) -> bool:
+    return any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors)
+
+
+def _shape_img_grad(d_img: torch.Tensor, shape, bs: int, n_img: int) -> torch.Tensor:
+    """d_img [bs*n_img or bs*tags*n_img, E] -> the shape of the img_emb the forward was given.  A stride-0 expand over tags
+    ([bs, tags, n_img, E] sharing one set of rows) gets the whole gradient in its tag-0 slice: autograd sums the slices."""
+    rows = 1
+    for d in shape[:-1]:
+        rows *= d
+    if rows == d_img.shape[0]:
+        return d_img.view(shape)
+    full = torch.zeros(shape, dtype=d_img.dtype, device=d_img.device)
+    full[:, 0] = d_img.view(bs, n_img, shape[-1])
+    return full
+
+
+def _param_grads(ctx, mod, first_param_arg: int):
+    """Gradients for the parameter arguments of the coarse autograd nodes: a copy of each flat-buffer slice for parameters that
+    require grad (the buffer is reused by the next backward), None for frozen ones."""
+    G = mod.grad_buffers()
+    return [G[n].clone() if ctx.needs_input_grad[first_param_arg + i] else None for i, (n, _) in enumerate(mod.named_parameters())]
+
+
 class _ActorFn(torch.autograd.Function):
-    """Autograd entry of the drop-in nn.Module path: `loss.backward()` works as with the reference."""
+    """Autograd entry of the drop-in nn.Module path: `loss.backward()` works as with the reference -- parameters AND the two
+    feature inputs receive gradients (the reference's heads are plain autograd, finetune/ppo.py:214-232)."""
 
     @staticmethod
     def forward(ctx, mod, text_emb, img_emb, *params):
@@ -555,9 +624,10 @@ class _ActorFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits):
         mod = ctx.mod
-        mod.engine_backward(dlogits)
-        G = mod.grad_buffers()
-        return (None, None, None, *[G[n].clone() for n, _ in mod.named_parameters()])
+        want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        d_text, d_img = mod.engine_backward(dlogits, input_grads=want)
+        return (None, d_text if ctx.needs_input_grad[1] else None, d_img if ctx.needs_input_grad[2] else None,
+                *_param_grads(ctx, mod, 3))
 
 
 class _CriticFn(torch.autograd.Function):
@@ -570,9 +640,10 @@ class _CriticFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dvalue):
         mod = ctx.mod
-        mod.engine_backward(dvalue)
-        G = mod.grad_buffers()
-        return (None, None, None, None, *[G[n].clone() for n, _ in mod.named_parameters()])
+        want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        d_text, d_img = mod.engine_backward(dvalue, input_grads=want)
+        return (None, d_text if ctx.needs_input_grad[1] else None, d_img if ctx.needs_input_grad[2] else None, None,
+                *_param_grads(ctx, mod, 4))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -635,7 +706,12 @@ class _Side:
     _streams: Dict[int, "torch.cuda.Stream"] = {}
 
     def __init__(self, device):
-        self.on = os.environ.get("LR2_PPO_STREAMS", "1") != "0" and device.type == "cuda"
+        env = os.environ.get("LR2_PPO_STREAMS")
+        # data parallel: the critic's collectives would be issued from the side stream.  Their order on RCCL's stream is the host
+        # issue order on every rank (no cycle), but that schedule has run on no multi-GPU hardware yet: the default
+        # with more than one rank is ONE stream, LR2_PPO_STREAMS=1 opts in.
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.on = (env == "1" if multi else env != "0") and device.type == "cuda"
         if self.on:
             key = device.index if device.index is not None else torch.cuda.current_device()
             if key not in _Side._streams:
@@ -670,6 +746,11 @@ def rollout_step(model, reward_model, text_emb, img_emb, tgts, state=None):
     # dropout seeds in call order).  A third stream for the reward model's trunk, which needs the actor's ordering only at its
     # end, was measured: no further gain (18.35 vs 18.20 ms per step).
     side = _Side(dev)
+    if not model.actor.TRAD:
+        # the input planes all three models share are produced HERE, on the main stream and before the fork: the critic's
+        # first GEMMs on the side stream read them through the cache, and a split launched by the actor after the fork would
+        # be invisible to that stream (a NEW batch tensor every step -- the training loop -- is exactly that case)
+        model.actor._prep_inputs(text_emb, img_emb)
     side.fork_point()
     logits = model.actor.engine_forward(text_emb, img_emb, save=False)
     with side.run():
@@ -698,8 +779,14 @@ class _DataParallel:
     the rest of backward."""
 
     def __init__(self):
-        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self.backend = dist.get_backend() if self.world > 1 else None
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if inited else 1
+        self.backend = dist.get_backend() if inited else None
+        # LR2_DP_FORCE=1: take the exchange path even with ONE rank (factor all-gathers, tail all-reduce, the global RankLoss
+        # statistics, the K = 64 * world fused update with alpha = 1 / world): every collective is the identity there, so the
+        # step must reproduce the plain one bit for bit -- the way RCCL and this path are exercised on a one-GPU box
+        # (tests/test_rccl_world1_gpu.py).  Never set in production.
+        self.active = self.world > 1 or (inited and os.environ.get("LR2_DP_FORCE", "0") == "1")
 
     def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         out, inp = out.view(torch.uint8), inp.view(torch.uint8)   # raw bytes: int16 is not a NCCL/gloo element type
@@ -728,7 +815,7 @@ class _DataParallel:
 
     def reduce_start(self, head: "_Head"):
         """Average every gradient except out_layer.fc1.weight (handled through its factors)."""
-        if self.world == 1:
+        if not self.active:
             return None
         tail = head._flat_grad[head._bucket_split:]
         tail.div_(self.world)
@@ -764,7 +851,7 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
                    margin=0.01, adv_eps=-0.1)
     scores, probs = actor.action_scores(logits, bs, tags, want_probs=True)
     loss_in = (scores, old_scores.contiguous(), rewards.contiguous(), old_value.contiguous(), value, next_state.contiguous())
-    if dp.world > 1 and getattr(args, "global_rank_loss", True):
+    if dp.active and getattr(args, "global_rank_loss", True):
         # RankLoss is one scalar over the whole batch (finetune/ppo.py:43-55): with the batch sharded over ranks its hinge
         # sum / positive count (and mean |A|, which multiplies it) must be global before R is formed, or the rank-averaged
         # gradient is not the gradient of the global-batch loss (SURVEY.md 8e caveat).  Three floats, one all-reduce.
@@ -802,7 +889,7 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
     pm = per.mean(dim=1)
     metrics = torch.stack([scal[0], scal[1], pm[0], old_value.mean(), value.mean(), rewards.mean(), pm[2], pm[3], scal[2],
                            pm[1]])
-    if dp.world > 1:           # the reference's 10 logging all-reduces (ppo.py:589-598), packed into one
+    if dp.active:              # the reference's 10 logging all-reduces (ppo.py:589-598), packed into one
         metrics.div_(dp.world)
         dist.all_reduce(metrics)
     return metrics

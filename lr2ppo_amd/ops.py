@@ -183,18 +183,21 @@ def dropout_apply(src: torch.Tensor, dst: torch.Tensor, drop: Optional[Drop]):
 
 
 def text_embed_bwd(dx, src, seg, dword, dseg, *, rows, D):
-    """dword[src[r]] += dx[r]; dseg[seg[r]] += dx[r] (tables zeroed by the caller).  Deterministic: rows are grouped by
-    token with a stable device sort and summed in row order by one workgroup per distinct token (no float atomics)."""
+    """dword[t] = sum of dx rows whose token is t (rows of tokens PRESENT in src are overwritten, all others left as they are:
+    zero the table first; a caller accumulating into a live table must add the result itself); dseg[s] = sum of dx rows with
+    segment s.  Deterministic: rows are grouped by token with a stable device sort, summed in row order inside pieces of 256
+    sorted positions and the pieces of a long run (the padding id) in piece order (no float atomics)."""
     _chk_f32(dx, dword, dseg)
     if src.dtype != torch.int64 or seg.dtype != torch.int64:
         raise TypeError("src / seg must be int64")
     sorted_ids, order = torch.sort(src.view(-1), stable=True)
-    rpb = 64                                                     # LR2_TEXT_EMBED_BWD_ROWS_PER_BLOCK
+    rpb, wseg = 64, 256                                          # LR2_TEXT_EMBED_BWD_ROWS_PER_BLOCK / _WORD_SEG
     n_seg = dseg.shape[0]
     partials = torch.empty(((rows + rpb - 1) // rpb) * n_seg * D, dtype=torch.float32, device=dx.device)
+    wpart = torch.empty(2 * ((rows + wseg - 1) // wseg) * D, dtype=torch.float32, device=dx.device)
     _nat.check(_nat.lib().lr2_text_embed_bwd(dx.data_ptr(), sorted_ids.data_ptr(), order.data_ptr(), seg.data_ptr(),
-                                             dword.data_ptr(), dseg.data_ptr(), partials.data_ptr(), rows, D, dword.shape[0],
-                                             n_seg, _stream()), "lr2_text_embed_bwd")
+                                             dword.data_ptr(), dseg.data_ptr(), partials.data_ptr(), wpart.data_ptr(), rows, D,
+                                             dword.shape[0], n_seg, _stream()), "lr2_text_embed_bwd")
 
 
 def split_planes_multi(table_dev: torch.Tensor, n_chunks: int):

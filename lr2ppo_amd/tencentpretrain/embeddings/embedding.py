@@ -165,12 +165,30 @@ class Embedding(nn.Module):
             ops.dropout_apply(out, out, saved["drop"])
         return out, saved
 
+    def grad_buffers(self):
+        """{parameter: gradient}: persistent tensors for the explicit training path (see TransformerEncoder.grad_buffers)."""
+        params = list(self.parameters())
+        dev = params[0].device
+        if getattr(self, "_gflat", None) is None or self._gflat.device != dev:
+            self._gflat = torch.zeros(sum(q.numel() for q in params), device=dev)
+            self._gviews, off = {}, 0
+            for q in params:
+                self._gviews[q] = self._gflat[off:off + q.numel()].view_as(q)
+                off += q.numel()
+        return self._gviews
+
     @torch.no_grad()
-    def _backward(self, saved, dout):
-        """-> {parameter: gradient} (inputs are data: token ids / pixels get no gradient)."""
+    def _backward(self, saved, dout, G_out=None):
+        """-> {parameter: gradient} (inputs are data: token ids / pixels get no gradient).  G_out (grad_buffers()): the
+        gradients are written there instead of into fresh tensors."""
         dev = dout.device
         ws = self._ws
         G = {}
+
+        def buf(q, zero=False):
+            if G_out is None:
+                return torch.zeros_like(q) if zero else torch.empty_like(q)
+            return G_out[q].zero_() if zero else G_out[q]
         dy = dout.contiguous()
         if saved["drop"] is not None:
             dy = ops.dropout_apply(dy, torch.empty_like(dy), saved["drop"])
@@ -178,17 +196,17 @@ class Embedding(nn.Module):
             ln = self.layer_norm
             M, E = dy.shape[0] * dy.shape[1], dy.shape[2]
             dx = torch.empty(M, E, device=dev)
-            G[ln.gamma], G[ln.beta] = torch.empty(E, device=dev), torch.empty(E, device=dev)
+            G[ln.gamma], G[ln.beta] = buf(ln.gamma), buf(ln.beta)
             ops.layernorm_bwd(dy.view(M, E), saved["x"].view(M, E), ln.gamma.data, saved["mean"], saved["rstd"], dx,
                               ws.vec("ln_partials", 256 * 2 * E), G[ln.gamma], G[ln.beta], rows=M, D=E, mode=1, eps=ln.eps)
             dy = dx.view_as(dy)
         if saved["kind"] == ("patch", "pos"):
             pe = self.patch
             B, P, E, Kd = saved["dims"]
-            dpos = torch.zeros_like(self.pos.embedding.weight)
+            dpos = buf(self.pos.embedding.weight, zero=True)
             ops.period_rows_grad(dy.view(B * (P + 1), E), dpos, rows=B * (P + 1), D=E, period=P + 1)
             G[self.pos.embedding.weight] = dpos
-            G[pe.cls_emb] = dpos[0].clone().view_as(pe.cls_emb)            # out[b, 0] = cls + pos[0]: same gradient rows
+            G[pe.cls_emb] = buf(pe.cls_emb).copy_(dpos[0].view_as(pe.cls_emb))    # out[b, 0] = cls + pos[0]: same gradient rows
             dproj = torch.empty(B, 1, P * E, device=dev)
             ops.gather_rows(dy.view(B, (P + 1) * E)[:, E:], None, dproj, B=B, t_in=1, t_out=1, row_elems=P * E,
                             src_bstride=(P + 1) * E, src_tstride=0)
@@ -197,11 +215,11 @@ class Embedding(nn.Module):
             Kp = patches_p.cols
             dw = torch.empty(E, Kp, device=dev)
             engine.linear_wgrad(ws, dproj_p, patches_p, dw, None, B * P, Kp, E)
-            G[pe.projection.weight] = (dw if Kp == Kd else dw[:, :Kd].contiguous()).view_as(pe.projection.weight)
+            G[pe.projection.weight] = buf(pe.projection.weight).copy_((dw if Kp == Kd else dw[:, :Kd]).reshape(pe.projection.weight.shape))
         else:
             B, L, E = saved["dims"]
-            dword, dseg = torch.zeros_like(self.word.embedding.weight), torch.zeros_like(self.seg.embedding.weight)
-            dpos = torch.zeros_like(self.pos.embedding.weight)
+            dword, dseg = buf(self.word.embedding.weight, zero=True), buf(self.seg.embedding.weight, zero=True)
+            dpos = buf(self.pos.embedding.weight, zero=True)
             ops.text_embed_bwd(dy.view(B * L, E), saved["ids"], saved["seg"], dword, dseg, rows=B * L, D=E)
             ops.period_rows_grad(dy.view(B * L, E), dpos, rows=B * L, D=E, period=L)
             G[self.word.embedding.weight], G[self.seg.embedding.weight], G[self.pos.embedding.weight] = dword, dseg, dpos

@@ -255,9 +255,24 @@ class TransformerEncoder(nn.Module):
             out = h.view(B, L, E)
         return out, saved
 
+    def grad_buffers(self):
+        """{parameter: gradient} views of ONE persistent flat fp32 buffer (the explicit training path of
+        lr2ppo_amd.finetune.features: no per-step allocation, fixed addresses for the optimizer's chunk table and one
+        contiguous all-reduce under data parallelism)."""
+        params = list(self.parameters())
+        dev = params[0].device
+        if getattr(self, "_gflat", None) is None or self._gflat.device != dev:
+            self._gflat = torch.zeros(sum(q.numel() for q in params), device=dev)
+            self._gviews, off = {}, 0
+            for q in params:
+                self._gviews[q] = self._gflat[off:off + q.numel()].view_as(q)
+                off += q.numel()
+        return self._gviews
+
     @torch.no_grad()
-    def _backward_train(self, saved, dout):
-        """-> (d emb [B, L, E], {parameter: gradient}) for the forward that produced `saved`."""
+    def _backward_train(self, saved, dout, G=None):
+        """-> (d emb [B, L, E], {parameter: gradient}) for the forward that produced `saved`.  G: write the parameter gradients
+        into these tensors (grad_buffers()) instead of a fresh allocation."""
         B, L, E, H, hd, M, F = saved["dims"]
         dev, seg, W = dout.device, saved["seg"], saved["W"]
         ws = self._ws
@@ -267,12 +282,13 @@ class TransformerEncoder(nn.Module):
         # running hidden-state gradient alternates between two of them
         mat = lambda name, r, c: ws.mat("bwd:" + name, r, c)            # noqa: E731
         pl = lambda name, r, c: ws.planes("bwd:" + name, r, c)          # noqa: E731
-        params = list(self.parameters())
-        flat = torch.empty(sum(q.numel() for q in params), device=dev)
-        G, off = {}, 0
-        for q in params:
-            G[q] = flat[off:off + q.numel()].view_as(q)
-            off += q.numel()
+        if G is None:
+            params = list(self.parameters())
+            flat = torch.empty(sum(q.numel() for q in params), device=dev)
+            G, off = {}, 0
+            for q in params:
+                G[q] = flat[off:off + q.numel()].view_as(q)
+                off += q.numel()
         partials = ws.vec("ln_partials", 256 * 2 * E)
         lse_ws, dsum_ws = ws.vec("attn_lse", B * H * L), ws.vec("attn_dsum", B * H * L)
         dwqkv, dbqkv = ws.mat("dwqkv", 3 * E, E), ws.vec("dbqkv", 3 * E)

@@ -1,0 +1,341 @@
+"""Round-3 parity additions on a real MI355X: the heads are differentiable with respect to their inputs (never a silent None),
+the composed path trains end to end -- loss -> head -> ViT / RoBERTa encoder stacks -> embeddings -- against the oracle's
+autograd chain with pinned dropout masks, the explicit (no-autograd) fine-tune schedule equals the autograd route bit for bit,
+the rollout's shared input planes are ordered before the stream fork, long runs in the embedding backward, NDCG range flags."""
+import argparse
+import os
+
+import pytest
+import torch
+
+from oracle import lr2ppo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+REL = 2e-3          # the bar of the encoder-backward tests (test_round2_gpu.py: sum-of-squares within 2e-3, sampled values)
+
+
+def _head_args(dev, **over):
+    d = dict(mode="reg", labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768, is_master=True, kl_div_loss_weight=0.001,
+             entropy_weight=0.001, value_clip=0.5, optimizer="adamw", scheduler="linear", learning_rate=1e-3,
+             critic_learning_rate=1e-3, train_steps=41, warmup=0.1, device=dev)
+    d.update(over)
+    return argparse.Namespace(**d)
+
+
+def _rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    """||a - b|| / ||b|| in fp64 (b: the oracle's tensor)."""
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def _one_layer_extractor(dev):
+    from lr2ppo_amd.finetune.features import TEXT_CONFIG, VIT_CONFIG, FeatureExtractor, encoder_args
+    fx = FeatureExtractor(encoder_args(VIT_CONFIG, layers_num=1), encoder_args(TEXT_CONFIG, layers_num=1))
+    pv = {**{"embedding." + k: v for k, v in O.seeded_params(O.vit_embedding_spec(768, 3, 16, 197), seed=61).items()},
+          **{"encoder." + k: v for k, v in O.seeded_params(O.encoder_param_spec(1, 768, 3072, True), seed=62).items()}}
+    pt = {**{"embedding." + k: v for k, v in O.seeded_params(O.text_embedding_spec(768, 50265, 514), seed=64).items()},
+          **{"encoder." + k: v for k, v in O.seeded_params(O.encoder_param_spec(1, 768, 3072, False), seed=65).items()}}
+    fx.image.load_state_dict(pv, strict=True)
+    fx.text.load_state_dict(pt, strict=True)
+    return fx.to(dev), pv, pt
+
+
+def _oracle_chain(pv, pt, Pa, frames, ids, seg, tgts, seed0, p=0.1):
+    """The reference composition on the CPU with autograd: embedding -> encoder (-> pooling) -> Actor -> SmoothL1
+    (tencentpretrain/models/model.py:32-41 feeding finetune/ppo.py:214-244).  Dropout masks: the HIP path's counter-based
+    stream, one seed per module call in call order (image embedding, image encoder, text embedding, text encoder, head)."""
+    from lr2ppo_amd import ops
+    B, n_img = frames.shape[:2]
+    T, L = ids.shape[1:]
+    leaves = {}
+
+    def req(d, tag):
+        out = {}
+        for k, v in d.items():
+            out[k] = v.clone().requires_grad_(True)
+            leaves[tag + k] = out[k]
+        return out
+
+    pv, pt = req(pv, "image."), req(pt, "text.")
+    sub = lambda d, pre: {k[len(pre):]: v for k, v in d.items() if k.startswith(pre)}      # noqa: E731
+    drop = (lambda k: {"p": p, "seed": seed0 + k, "site_base": 0}) if p > 0 else (lambda k: None)
+    x = frames.float().div(255)
+    x = ((x - torch.tensor(ops.CLIP_MEAN).view(1, 1, 3, 1, 1)) / torch.tensor(ops.CLIP_STD).view(1, 1, 3, 1, 1)).reshape(B * n_img, 3, 224, 224)
+    vseg = torch.ones(B * n_img, 197, dtype=torch.long)
+    e = O.vit_embedding(sub(pv, "embedding."), x, 16, drop=drop(0))
+    h = O.transformer_encoder(sub(pv, "encoder."), e, vseg, 1, 12, True, drop=drop(1))
+    img_emb = O.pooling_first(h, vseg).reshape(B, n_img, 768)
+    s2 = seg.reshape(B * T, L)
+    e = O.text_embedding(sub(pt, "embedding."), ids.reshape(B * T, L), s2, drop=drop(2))
+    text_emb = O.transformer_encoder(sub(pt, "encoder."), e, s2, 1, 12, False, drop=drop(3)).reshape(B, T, L, 768)
+    text_emb.retain_grad(), img_emb.retain_grad()
+    loss, logits = O.actor_forward(Pa, text_emb, img_emb.unsqueeze(1).repeat(1, T, 1, 1), tgts, drop=drop(4))
+    loss.backward()
+    return loss.detach(), logits.detach(), text_emb, img_emb, leaves
+
+
+def test_loss_backward_reaches_both_encoder_stacks_and_matches_the_oracle_chain(dev):
+    """1-layer ViT-B/16 + 1-layer RoBERTa-base + the full-size Actor, B = 2 items x 16 frames x 2 tags, TRAIN mode (dropout
+    0.1 at every reference site, pinned masks): `loss.backward()` through Actor(*fx(frames, ids, seg)) gives text_emb.grad,
+    img_emb.grad and every encoder / embedding parameter gradient within 2e-3 (relative L2) of the oracle's autograd chain;
+    then the explicit schedule (forward_train / engine_backward(input_grads=True) / backward_train) reproduces the autograd
+    route bit for bit on the same seeds."""
+    from lr2ppo_amd import runtime
+    from lr2ppo_amd.finetune import ppo
+    from lr2ppo_amd.finetune.features import synthetic_raw_batch
+    fx, pv, pt = _one_layer_extractor(dev)
+    frames, ids, seg, tgts = synthetic_raw_batch(2, 2, generator=torch.Generator().manual_seed(31))
+    Pa = O.seeded_params(O.head_param_spec("actor"), seed=7)
+    actor = ppo.Actor(_head_args(dev), None)
+    actor.load_state_dict(Pa, strict=True)
+    actor = actor.to(dev).train()
+    fx.train()
+    for p_ in actor.parameters():          # a frozen head in front of trainable encoders: the inputs alone ask for the graph
+        p_.requires_grad_(False)
+    runtime.set_dropout_seed(77)
+    seed0 = runtime.peek_drop_seed()
+    text_emb, img_emb = fx(frames.to(dev), ids.to(dev), seg.to(dev))
+    text_emb.retain_grad(), img_emb.retain_grad()
+    loss, logits = actor(text_emb, img_emb, tgts.to(dev))
+    loss.backward()
+    fx.text.embedding.check_ids()
+    loss_ref, logits_ref, t_ref, i_ref, leaves = _oracle_chain(pv, pt, Pa, frames, ids, seg, tgts, seed0)
+    assert (logits.detach().cpu() - logits_ref).abs().max().item() < 1e-3
+    assert abs(float(loss) - float(loss_ref)) < 1e-3
+    assert text_emb.grad is not None and img_emb.grad is not None
+    assert _rel(text_emb.grad, t_ref.grad) < REL, _rel(text_emb.grad, t_ref.grad)
+    assert _rel(img_emb.grad, i_ref.grad) < REL, _rel(img_emb.grad, i_ref.grad)
+    auto = {}
+    for stack, tag in ((fx.image, "image."), (fx.text, "text.")):
+        for n, q in stack.named_parameters():
+            ref = leaves[tag + n].grad
+            assert q.grad is not None, tag + n
+            if n.endswith("linear_layers.1.bias"):
+                # the key-projection bias gradient is analytically zero (softmax is shift-invariant along the keys): both
+                # sides hold rounding noise there -- bound it instead of comparing it
+                assert float(q.grad.abs().max()) < 1e-5 and float(ref.abs().max()) < 1e-5
+            else:
+                assert _rel(q.grad, ref) < REL, (tag + n, _rel(q.grad, ref))
+            auto[tag + n] = q.grad.detach().clone()
+    assert all(q.grad is None for q in actor.parameters())          # frozen: no gradient materialised for the 519 M head
+    # ---- the explicit schedule on the same seeds: identical bits ----
+    for q in fx.parameters():
+        q.grad = None
+    runtime.set_dropout_seed(77)
+    fx.bind_grads()
+    t2, i2, ctx = fx.forward_train(frames.to(dev), ids.to(dev), seg.to(dev))
+    assert torch.equal(t2, text_emb.detach()) and torch.equal(i2, img_emb.detach())
+    lg = actor.engine_forward(t2, i2, save=True)
+    assert torch.equal(lg, logits.detach())
+    from lr2ppo_amd import ops
+    l2, dl = torch.empty(1, device=dev), torch.empty_like(lg)
+    ops.smooth_l1(lg, tgts.to(dev).float().view(-1), l2, dl, n=lg.numel(), beta=0.3)
+    d_text, d_img = actor.engine_backward(dl, input_grads=True)
+    assert torch.equal(d_text, text_emb.grad) and torch.equal(d_img, img_emb.grad)
+    fx.backward_train(ctx, d_text, d_img)
+    for stack, tag in ((fx.image, "image."), (fx.text, "text.")):
+        for n, q in stack.named_parameters():
+            assert torch.equal(q.grad, auto[tag + n]), tag + n
+
+
+def test_heads_hand_back_input_gradients_or_raise_never_none(dev):
+    """Actor / Critic / Reward with requires_grad inputs (the shapes the heads accept: image tokens per tag, shared per item,
+    a stride-0 expand; the critic's index gather with a repeated tag): the input gradients equal the oracle's autograd."""
+    from lr2ppo_amd.finetune import ppo
+    bs, tags = 2, 2
+    text, img, tgts = O.seeded_head_inputs(13, bs, tags)            # img: [bs, tags, 16, 768] (the reference's repeat)
+    img_shared = img[:, 0].contiguous()
+    Pa, Pc = O.seeded_params(O.head_param_spec("actor"), seed=7), O.seeded_params(O.head_param_spec("critic"), seed=8)
+    args = _head_args(dev)
+    actor, critic = ppo.Actor(args, None), ppo.Critic(args, None)
+    actor.load_state_dict(Pa, strict=True), critic.load_state_dict(Pc, strict=True)
+    actor, critic = actor.to(dev).eval(), critic.to(dev).eval()
+    w = torch.randn(bs * tags, generator=torch.Generator().manual_seed(3))
+
+    # oracle: per-tag image tokens
+    tr, ir = text.clone().requires_grad_(True), img.clone().requires_grad_(True)
+    (O.actor_forward(Pa, tr, ir, None) * w).sum().backward()
+    t1, i1 = text.to(dev).requires_grad_(True), img.to(dev).requires_grad_(True)
+    (actor(t1, i1, None) * w.to(dev)).sum().backward()
+    assert _rel(t1.grad, tr.grad) < REL and _rel(i1.grad, ir.grad) < REL
+    # shared image tokens [bs, 16, 768]: the gradient is the sum over the item's tags
+    isr = img_shared.clone().requires_grad_(True)
+    tr2 = text.clone().requires_grad_(True)
+    (O.actor_forward(Pa, tr2, isr.unsqueeze(1).repeat(1, tags, 1, 1), None) * w).sum().backward()
+    t2, i2 = text.to(dev).requires_grad_(True), img_shared.to(dev).requires_grad_(True)
+    (actor(t2, i2, None) * w.to(dev)).sum().backward()
+    assert i2.grad.shape == (bs, 16, 768) and _rel(i2.grad, isr.grad) < REL and _rel(t2.grad, tr2.grad) < REL
+    # stride-0 expand of the shared tokens: autograd sums the expand's slices back
+    i3 = img_shared.to(dev).requires_grad_(True)
+    (actor(text.to(dev), i3.unsqueeze(1).expand(bs, tags, 16, 768), None) * w.to(dev)).sum().backward()
+    assert _rel(i3.grad, isr.grad) < REL
+    # only ONE input asks: the other stays None by autograd's own rule, the asked one is delivered
+    t4 = text.to(dev).requires_grad_(True)
+    (actor(t4, img_shared.to(dev), None) * w.to(dev)).sum().backward()
+    assert _rel(t4.grad, tr2.grad) < REL
+    # critic, index with a repeated tag (tag 1 twice): the scatter-back sums both positions
+    index = torch.tensor([[1, 1], [0, 1]])
+    wv = torch.tensor([0.7, -1.3])
+    trc, irc = text.clone().requires_grad_(True), img.clone().requires_grad_(True)
+    (O.critic_forward(Pc, trc, irc, index) * wv).sum().backward()
+    tc, ic = text.to(dev).requires_grad_(True), img.to(dev).requires_grad_(True)
+    (critic(tc, ic, None, index.to(dev)) * wv.to(dev)).sum().backward()
+    assert _rel(tc.grad, trc.grad) < REL and _rel(ic.grad, irc.grad) < REL
+    assert float(tc.grad[0, 0].abs().max()) == 0.0                  # item 0 never reads tag 0
+    isc = img_shared.clone().requires_grad_(True)
+    (O.critic_forward(Pc, text, isc.unsqueeze(1).repeat(1, tags, 1, 1), index) * wv).sum().backward()
+    ic2 = img_shared.to(dev).requires_grad_(True)
+    (critic(text.to(dev), ic2, None, index.to(dev)) * wv.to(dev)).sum().backward()
+    assert _rel(ic2.grad, isc.grad) < REL
+
+
+def test_trad_heads_input_gradients(dev):
+    """The sequence-length-1 twins: pointwise_trad's Classifier and ppo_trad's Actor / Critic return d text_emb; the raw-feature
+    classifier (46 / 136 columns are data) raises instead of returning None."""
+    from lr2ppo_amd.finetune import pointwise_2data_trad, pointwise_trad, ppo_trad
+    args = _head_args(dev)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 4, 768, generator=gen)
+    w = torch.randn(12, generator=gen)
+    P = O.seeded_params(O.trad_param_spec(), seed=21)
+    m = pointwise_trad.Classifier(args, None)
+    m.load_state_dict(P, strict=True)
+    m = m.to(dev).eval()
+    xr = x.clone().requires_grad_(True)
+    (O.trad_forward(P, xr).view(-1) * w).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    (m(xd).view(-1) * w.to(dev)).sum().backward()
+    assert xd.grad is not None and _rel(xd.grad, xr.grad) < REL
+    Pa, Pc = O.seeded_params(O.trad_head_param_spec("actor"), seed=22), O.seeded_params(O.trad_head_param_spec("critic"), seed=23)
+    actor, critic = ppo_trad.Actor(args, None), ppo_trad.Critic(args, None)
+    actor.load_state_dict(Pa, strict=True), critic.load_state_dict(Pc, strict=True)
+    actor, critic = actor.to(dev).eval(), critic.to(dev).eval()
+    xr = x.clone().requires_grad_(True)
+    (O.trad_actor_forward(Pa, xr).view(-1) * w).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    (actor(xd, None, None).view(-1) * w.to(dev)).sum().backward()
+    assert _rel(xd.grad, xr.grad) < REL
+    index = torch.tensor([[3, 3, 0], [1, 2, 0], [0, 1, 2]])
+    wv = torch.tensor([0.5, -1.0, 2.0])
+    xr = x.clone().requires_grad_(True)
+    (O.trad_critic_forward(Pc, xr, index) * wv).sum().backward()
+    xd = x.to(dev).requires_grad_(True)
+    (critic(xd, None, None, index.to(dev)) * wv.to(dev)).sum().backward()
+    assert _rel(xd.grad, xr.grad) < REL
+    m2 = pointwise_2data_trad.Classifier(args, None).to(dev).eval()
+    raw = torch.randn(2, 3, 46, device=dev, requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        m2(raw).sum().backward()
+
+
+def test_finetune_pointwise_step_trains_head_and_both_stacks(dev):
+    """finetune_pointwise_step (BASELINE configs[1] with the encoders trained): after two steps past the lr-0 start every
+    parameter group has moved -- head, out_layer.fc1 (fused update), both encoder stacks, both embeddings -- the loss is finite
+    and the first step's loss equals the oracle chain's (1e-3)."""
+    from lr2ppo_amd import runtime
+    from lr2ppo_amd.finetune import pointwise
+    from lr2ppo_amd.finetune.features import build_encoder_optimizer, finetune_pointwise_step, synthetic_raw_batch
+    fx, pv, pt = _one_layer_extractor(dev)
+    args = _head_args(dev, train_steps=20, batch_size=2)
+    Pa = O.seeded_params(O.head_param_spec("actor"), seed=7)
+    model = pointwise.Classifier(args, None)
+    model.load_state_dict(Pa, strict=True)
+    model = model.to(dev).train()
+    fx.train()
+    opt, sch = pointwise.build_optimizer(args, model)
+    eopt, esch = build_encoder_optimizer(args, fx)
+    sch.step(), esch.step()                                                   # leave lambda(0) = 0
+    frames, ids, seg, tgts = synthetic_raw_batch(2, 2, generator=torch.Generator().manual_seed(33))
+    before = {n: q.detach().clone() for n, q in list(fx.named_parameters()) + [("head." + k, v) for k, v in model.named_parameters()]
+              if q.numel() < 5_000_000}
+    runtime.set_dropout_seed(91)
+    seed0 = runtime.peek_drop_seed()
+    loss_ref, *_ = _oracle_chain(pv, pt, Pa, frames, ids, seg, tgts, seed0)
+    losses = [finetune_pointwise_step(args, fx, model, opt, sch, eopt, esch, frames.to(dev), ids.to(dev), seg.to(dev), tgts.to(dev))
+              for _ in range(2)]
+    fx.text.embedding.check_ids()
+    assert abs(float(losses[0]) - float(loss_ref)) < 1e-3
+    assert all(torch.isfinite(l) for l in losses)
+    after = dict(list(fx.named_parameters()) + [("head." + k, v) for k, v in model.named_parameters()])
+    moved = {n: not torch.equal(before[n], after[n].detach()) for n in before}
+    # the key-projection bias has an analytically zero gradient (rounding noise may or may not move it); everything else moves
+    assert all(v for n, v in moved.items() if not n.endswith("linear_layers.1.bias")), [n for n, v in moved.items() if not v]
+
+
+def test_rollout_with_a_new_batch_object_every_step_equals_one_stream(dev):
+    """the planes all three models share are produced before the stream fork.  Every step feeds NEW tensor
+    objects (cache misses, the training loop's case) and the two-stream rollout must reproduce the one-stream bits."""
+    from lr2ppo_amd.finetune import ppo
+    args = _head_args(dev)
+    torch.manual_seed(3)
+    model, reward = ppo.ActorCritic(args, None), ppo.Reward(args, None)
+    for m in (model, reward):
+        ppo._init_normal(m)
+    model, reward = model.to(dev).eval(), reward.to(dev).eval()
+    gen = torch.Generator().manual_seed(17)
+    batches = [(torch.randn(4, 2, 196, 768, generator=gen), torch.randn(4, 16, 768, generator=gen),
+                torch.randint(0, 3, (4, 2), generator=gen)) for _ in range(6)]
+
+    def run(streams):
+        old = os.environ.get("LR2_PPO_STREAMS")
+        os.environ["LR2_PPO_STREAMS"] = streams
+        try:
+            out = []
+            for t, i, g in batches:
+                rec = ppo.rollout_step(model, reward, t.to(dev), i.to(dev), g.to(dev))      # fresh device tensors: cache misses
+                out.append([rec[2].clone(), rec[3].clone(), rec[4].clone(), rec[1].clone()])
+                del rec
+            torch.cuda.synchronize()
+            return out
+        finally:
+            if old is None:
+                os.environ.pop("LR2_PPO_STREAMS", None)
+            else:
+                os.environ["LR2_PPO_STREAMS"] = old
+
+    two, one = run("1"), run("0")
+    for a, b in zip(two, one):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
+def test_embedding_backward_long_runs_are_split_and_deterministic(dev):
+    """a padding id carried by most rows (stage 1: 640 x 196 rows, one id on ~1e5 of them) is summed by many
+    workgroups in fixed piece order: run to run identical, equal to an fp64 index_add, rows of absent tokens untouched, and a
+    run that starts in the middle of a 256-position piece and spans several of them is covered."""
+    from lr2ppo_amd import ops
+    gen = torch.Generator().manual_seed(19)
+    rows, D, vocab = 5000, 768, 40
+    dx = torch.randn(rows, D, generator=gen)
+    ids = torch.randint(2, vocab, (rows,), generator=gen)
+    pad = torch.rand(rows, generator=gen) < 0.7
+    ids[pad] = 1                                              # ~3500 rows of one id, scattered through the batch
+    ids[:300] = 0                                             # a run of 300 at the very start of the sorted order (crosses one cut)
+    seg = torch.randint(0, 3, (rows,), generator=gen)
+    outs = []
+    for _ in range(3):
+        dword, dseg = torch.zeros(vocab + 3, D, device=dev), torch.zeros(3, D, device=dev)
+        ops.text_embed_bwd(dx.to(dev), ids.to(dev), seg.to(dev), dword, dseg, rows=rows, D=D)
+        outs.append(dword.cpu())
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    want = torch.zeros(vocab + 3, D, dtype=torch.float64).index_add_(0, ids, dx.double())
+    assert (outs[0].double() - want).abs().max() < 5e-4
+    assert outs[0][vocab:].abs().max() == 0
+
+
+def test_ndcg_flags_items_it_cannot_rank(dev):
+    """lr2_ndcg never returns a truncated or wrapped value -- an item with more than 64 elements or a label outside
+    [0, 62] gets a row of NaN through the C ABI; its neighbours are unaffected."""
+    from lr2ppo_amd import ops
+    gen = torch.Generator().manual_seed(2)
+    sizes = [20, 70, 5, 8]
+    scores = torch.randn(sum(sizes), generator=gen)
+    gold = torch.randint(0, 3, (sum(sizes),), generator=gen)
+    gold[20 + 70 + 5 + 3] = 63                                # item 3: label out of range
+    offsets = torch.tensor([0] + sizes).cumsum(0)
+    out = ops.ndcg(scores.to(dev), gold.to(dev), offsets.to(dev)).cpu()
+    assert torch.isnan(out[1]).all() and torch.isnan(out[3]).all()
+    for i in (0, 2):
+        s, g = scores[offsets[i]:offsets[i + 1]], gold[offsets[i]:offsets[i + 1]]
+        assert torch.allclose(out[i], O.ndcg_vector(s, g), atol=1e-6)
