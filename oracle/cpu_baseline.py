@@ -78,6 +78,56 @@ def time_ppo_steps(bs: int = 32, tags: int = 2, steps: int = 1, warmup_bs: int =
     return dict(med, steps=len(runs), warmup_bs=warmup_bs, threads=torch.get_num_threads())
 
 
+class FeaturesCpu:
+    """The oracle's dual-encoder forward (ViT-B/16 + RoBERTa-base, 12 layers each, random N(0, 0.02) weights, inference) on the
+    host cores: uint8 frames -> /255 -> CLIP mean / std -> vit_embedding -> transformer_encoder -> pooling_first, token ids ->
+    text_embedding -> transformer_encoder (tencentpretrain/models/model.py:32-41 with the shipped configs)."""
+
+    MEAN = (0.48145466, 0.4578275, 0.40821073)       # tencentpretrain/utils/dataloader.py:561
+    STD = (0.26862954, 0.26130258, 0.27577711)
+
+    def __init__(self, seed: int = 60):
+        self.pve = O.seeded_params(O.vit_embedding_spec(768, 3, 16, 197), seed=seed + 1)
+        self.pvn = O.seeded_params(O.encoder_param_spec(12, 768, 3072, True), seed=seed + 2)
+        self.pte = O.seeded_params(O.text_embedding_spec(768, 50265, 514), seed=seed + 4)
+        self.ptn = O.seeded_params(O.encoder_param_spec(12, 768, 3072, False), seed=seed + 5)
+
+    @torch.no_grad()
+    def extract(self, frames, ids, seg, chunk: int = 64):
+        B, n_img = frames.shape[:2]
+        T, L = ids.shape[1:]
+        mean, std = torch.tensor(self.MEAN).view(1, 3, 1, 1), torch.tensor(self.STD).view(1, 3, 1, 1)
+        flat = frames.reshape(B * n_img, 3, 224, 224)
+        out = []
+        for i in range(0, flat.shape[0], chunk):              # frames in chunks: the [b, 12, 197, 197] score tensors stay small
+            x = (flat[i:i + chunk].float().div(255) - mean) / std
+            vseg = torch.ones(x.shape[0], 197, dtype=torch.long)
+            h = O.transformer_encoder(self.pvn, O.vit_embedding(self.pve, x, 16), vseg, 12, 12, True)
+            out.append(O.pooling_first(h, vseg))
+        img_emb = torch.cat(out).reshape(B, n_img, 768)
+        s2 = seg.reshape(B * T, L)
+        text_emb = O.transformer_encoder(self.ptn, O.text_embedding(self.pte, ids.reshape(B * T, L), s2), s2, 12, 12, False)
+        return text_emb.reshape(B, T, L, 768), img_emb
+
+
+def time_feature_extraction(bs: int = 32, tags: int = 2, n_img: int = 16, seed: int = 7):
+    """-> seconds of ONE dual-encoder forward at the PPO step's shapes (bs x n_img frames, bs x tags sequences) after a small
+    untimed warm-up call."""
+    fx = FeaturesCpu()
+    g = torch.Generator().manual_seed(seed)
+
+    def raw(b):
+        frames = torch.randint(0, 256, (b, n_img, 3, 224, 224), dtype=torch.uint8, generator=g)
+        ids = torch.randint(5, 50265, (b, tags, 196), generator=g)
+        lens = torch.randint(4, 197, (b, tags, 1), generator=g)
+        return frames, ids, (torch.arange(196).view(1, 1, -1) < lens).to(torch.int64)
+    fx.extract(*raw(1))
+    batch = raw(bs)
+    t0 = time.time()
+    fx.extract(*batch)
+    return time.time() - t0
+
+
 def time_ppo_step(bs: int, tags: int = 2, seed: int = 7, lr: float = 1e-4):
     """One cold step (kept for callers of the round-1 interface)."""
     r = PpoCpu(tags, seed, lr).step(bs)
