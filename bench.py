@@ -463,7 +463,7 @@ def main():
                   f"update fwd/bwd {r['fwd_bwd_s']:.1f}s + AdamW(1.045B) {r['adamw_s']:.1f}s = {r['total_s']:.1f}s per head-only step")
         total = r["total_s"]
         if online is not None:
-            fb = max(1, a.batch // 4)
+            fb = max(1, a.batch // 16)         # ~10 s of host time for 2 of 32 items; the encoders are per-frame / per-sequence
             fe = cpu_baseline.time_feature_extraction(fb, a.tags) * (a.batch / fb)
             total += fe
             sample += (f"; + dual-encoder forward (oracle ViT-B/16 + RoBERTa-base, 12 layers each) timed on {fb} of the {a.batch} items "

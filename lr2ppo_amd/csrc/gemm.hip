@@ -469,11 +469,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #define LR2_GEMM_INST_W8(BK, TA, TB) \
   template __global__ void gemm_kernel<128, 128, BK, 64, 32, TA, TB, 3, true, true, 8>(GemmParams);
 LR2_GEMM_INST_W8(64, false, false)
-LR2_GEMM_INST_W8(64, false, true)
-LR2_GEMM_INST_W8(64, true, true)
 LR2_GEMM_INST_W8(32, false, false)
 LR2_GEMM_INST_W8(32, false, true)
-LR2_GEMM_INST_W8(32, true, true)
 LR2_GEMM_INST_FORM(128, 64, 1)
 LR2_GEMM_INST_FORM(128, 64, 3)
 LR2_GEMM_INST_FORM(64, 32, 1)
@@ -493,7 +490,9 @@ int launch(const GemmParams& p_in, int splits, hipStream_t stream) {
   constexpr size_t epi_lds = (size_t)4 * 32 * (WN + 4) * 4;
   const size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
   constexpr size_t max_lds = (size_t)2 * NIMG * BM * BK * 2 + (size_t)2 * NIMG * BN * BK * 2;
-  if constexpr (APL && BPL && BM == 128 && PASSES == 3) {
+  // 8-wave workgroups: NT at either K depth, NN at 32-deep tiles (lr2_gemm never asks for them with a transposed A, and the
+  // 64-deep NN variant does not fit 128 VGPRs without scratch: it is not built)
+  if constexpr (APL && BPL && BM == 128 && PASSES == 3 && !TA && !(TB && BK == 64)) {
     if (p.waves8) {   // 8 waves per workgroup, wave tile 64 x 32
       auto k8 = gemm_kernel<128, 128, BK, 64, 32, TA, TB, 3, true, true, 8>;
       constexpr size_t epi8 = (size_t)8 * 32 * (32 + 4) * 4;

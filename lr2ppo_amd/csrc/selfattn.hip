@@ -1131,7 +1131,8 @@ static int fwd_blocked_dispatch(const AttnArgs& a, float* o, bf16_t* oh, size_t 
              : launch_fwd_blocked<NT, 4>(a, o, oh, o_lo_off, ld_o, lse, (a.L + 16 * NT - 1) / (16 * NT));
   if (tiles <= 10) { BLK(10) }
   if (tiles <= 12) { BLK(12) }
-  BLK(14)
+  // 14 key tiles: 3 query sub-tiles per wave always (the 4-slot variant needs 11 VGPRs more than the 256 of two waves per SIMD)
+  return launch_fwd_blocked<14, 3>(a, o, oh, o_lo_off, ld_o, lse, (a.L + 16 * 14 - 1) / (16 * 14));
 #undef BLK
 }
 
@@ -1176,10 +1177,14 @@ int launch_bwd_blocked(const AttnArgs& a, const bf16_t* go, size_t do_lo_off, in
   return lr2_launch_status("lr2_self_attn_bwd(dkv, blocked)");
 }
 
-#define LR2_SA_INST(NT)                                                                                                        \
+#define LR2_SA_INST_FWD(NT)                                                                                                    \
   template __global__ void self_attn_mfma_kernel<NT, (NT <= 14 ? 8 : 4)>(const bf16_t*, const bf16_t*, const bf16_t*, size_t,  \
                                                                          int, const int64_t*, float*, bf16_t*, size_t, int,   \
-                                                                         int, int, float, float*, DropP);                      \
+                                                                         int, int, float, float*, DropP);
+LR2_SA_INST_FWD(4)
+LR2_SA_INST_FWD(8)
+LR2_SA_INST_FWD(14)
+#define LR2_SA_INST(NT)                                                                                                        \
   template __global__ void self_attn_bwd_dq_kernel<NT, (NT <= 14 ? 8 : 4)>(const bf16_t*, const bf16_t*, const bf16_t*, size_t, int, const bf16_t*, \
                                                        size_t, int, const int64_t*, bf16_t*, size_t, int, float*, float*, int,  \
                                                        int, float, DropP);                                                     \
@@ -1279,10 +1284,12 @@ extern "C" int lr2_self_attn_fwd(const void* q_hi, const void* k_hi, const void*
   if (drop_p < 0.f || drop_p >= 1.f) return LR2_ERR_ARG;
   const AttnArgs a{(const bf16_t*)q_hi, (const bf16_t*)k_hi, (const bf16_t*)v_hi, (size_t)lo_off, ld, seg, batch, heads, L,
                    scale, make_drop(drop_p, drop_seed, drop_site), (hipStream_t)stream};
-  if (L > 256) return fwd_blocked_dispatch(a, (float*)o, (bf16_t*)o_hi, (size_t)o_lo_off, ld_o, (float*)lse);
-#define CALL(NT) launch_fwd<NT>(a, (float*)o, (bf16_t*)o_hi, (size_t)o_lo_off, ld_o, (float*)lse)
-  LR2_SA_DISPATCH(L, CALL)
-#undef CALL
+  // L > 224: key blocks with a running max / sum.  (A one-block kernel for 225 <= L <= 256 -- 16 key tiles, 4 waves -- needs
+  // 512 VGPRs + 710 spilled: the two-block walk of the blocked kernel is the forward for those lengths.)
+  if (L > 224) return fwd_blocked_dispatch(a, (float*)o, (bf16_t*)o_hi, (size_t)o_lo_off, ld_o, (float*)lse);
+  if (L <= 64) return launch_fwd<4>(a, (float*)o, (bf16_t*)o_hi, (size_t)o_lo_off, ld_o, (float*)lse);
+  if (L <= 128) return launch_fwd<8>(a, (float*)o, (bf16_t*)o_hi, (size_t)o_lo_off, ld_o, (float*)lse);
+  return launch_fwd<14>(a, (float*)o, (bf16_t*)o_hi, (size_t)o_lo_off, ld_o, (float*)lse);
 }
 
 extern "C" int lr2_self_attn_bwd(const void* q_hi, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld,

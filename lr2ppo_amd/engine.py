@@ -428,7 +428,7 @@ def trunk_backward(ws: Workspace, P, W, G, text, img, dg2, bs, tags, n_img, E, *
     linear_wgrad(ws, dg2p, g1, G["out_layer.fc2.weight"], G["out_layer.fc2.bias"], N, F, E)
     dzo = ws.planes("dzo", N, F)
     linear_dgrad(ws, dg2p, W["out_layer.fc2.weight"], None, N, F, E, act=2, aux_z=zo, out_planes=dzo)
-    if dp is not None and dp.active:
+    if dp is not None and getattr(dp, "active", dp.world > 1):
         # Data parallel: dW_fc1 = sum over ranks of dzo_r^T flat_r is a rank-(N*world) product of two thin factors.
         # All-gather the factors (42 MB per rank) instead of all-reducing the 2 GB product; the gathers run on the
         # communication stream while the rest of backward proceeds, the K = N*world wgrad GEMM is issued last.

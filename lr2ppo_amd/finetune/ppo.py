@@ -786,7 +786,12 @@ class _DataParallel:
         # statistics, the K = 64 * world fused update with alpha = 1 / world): every collective is the identity there, so the
         # step must reproduce the plain one bit for bit -- the way RCCL and this path are exercised on a one-GPU box
         # (tests/test_rccl_world1_gpu.py).  Never set in production.
-        self.active = self.world > 1 or (inited and os.environ.get("LR2_DP_FORCE", "0") == "1")
+        self._forced = inited and os.environ.get("LR2_DP_FORCE", "0") == "1"
+
+    @property
+    def active(self) -> bool:
+        """True when the gradient-exchange path runs: more than one rank (or forced, see __init__)."""
+        return self.world > 1 or self._forced
 
     def _all_gather(self, out: torch.Tensor, inp: torch.Tensor):
         out, inp = out.view(torch.uint8), inp.view(torch.uint8)   # raw bytes: int16 is not a NCCL/gloo element type

@@ -6,6 +6,7 @@ import json
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -309,3 +310,19 @@ def test_integration_doc_quotes_the_current_abi_version(native):
     doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
     m = re.search(r"lr2_abi_version\(\) == (\d+)", doc)
     assert m and int(m.group(1)) == native.ABI_VERSION
+
+
+def test_no_kernel_in_the_library_spills_registers(native):
+    """every kernel of the shipped library keeps its working set in registers -- no spilled VGPRs and no
+    private (scratch) memory -- read from the gfx950 code objects' metadata notes (tools/kernel_resources.py; needs the ROCm
+    llvm tools, no GPU).  The one allowed exception is listed with its reason."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import kernel_resources as kr
+    if not os.path.exists(os.path.join(kr.LLVM, "llvm-readelf")):
+        pytest.skip("ROCm llvm tools not installed")
+    ks = kr.kernels(native.LIB_PATH)
+    assert len(ks) > 60                                        # every .hip file's kernels are in the bundle
+    bad = [(k["name"], k["vgpr_spill"], k["scratch"]) for k in ks
+           if (k["vgpr_spill"] > 0 or k["scratch"] > 0) and not any(k["name"].startswith(a) for a in kr.ALLOWED_SCRATCH)]
+    assert not bad, bad
+    assert all(k["vgpr"] <= 512 and k["vgpr"] + k["agpr"] <= 512 for k in ks)
