@@ -325,4 +325,4 @@ def test_no_kernel_in_the_library_spills_registers(native):
     bad = [(k["name"], k["vgpr_spill"], k["scratch"]) for k in ks
            if (k["vgpr_spill"] > 0 or k["scratch"] > 0) and not any(k["name"].startswith(a) for a in kr.ALLOWED_SCRATCH)]
     assert not bad, bad
-    assert all(k["vgpr"] <= 512 and k["vgpr"] + k["agpr"] <= 512 for k in ks)
+    assert all(k["vgpr"] <= 512 for k in ks)                   # .vgpr_count = architectural + accumulation registers
