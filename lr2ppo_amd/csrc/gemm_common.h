@@ -115,10 +115,7 @@ __device__ __forceinline__ void epilogue_apply4(const Epilogue& e, float4 v, flo
   }
   if (e.drop_scale != 0.0f) {
     const uint64_t idx = (uint64_t)m * (uint64_t)N + (uint64_t)n;
-    v.x = dropout_keep(e.drop_key, idx + 0, e.drop_thr) ? v.x * e.drop_scale : 0.0f;
-    v.y = dropout_keep(e.drop_key, idx + 1, e.drop_thr) ? v.y * e.drop_scale : 0.0f;
-    v.z = dropout_keep(e.drop_key, idx + 2, e.drop_thr) ? v.z * e.drop_scale : 0.0f;
-    v.w = dropout_keep(e.drop_key, idx + 3, e.drop_thr) ? v.w * e.drop_scale : 0.0f;
+    v = dropout_apply4(e.drop_key, idx, e.drop_thr, e.drop_scale, v);     // idx = m * N + n: N and n are multiples of 4
   }
   if (e.act == 2) {
     const float4 z = L.s[0];

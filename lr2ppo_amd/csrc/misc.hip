@@ -68,10 +68,7 @@ __global__ __launch_bounds__(256) void dropout_planes_kernel(const float* __rest
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 v = reinterpret_cast<const float4*>(src)[i];
     const uint64_t e = (uint64_t)i * 4;
-    v.x = dropout_keep(key, e + 0, thr) ? v.x * scale : 0.f;
-    v.y = dropout_keep(key, e + 1, thr) ? v.y * scale : 0.f;
-    v.z = dropout_keep(key, e + 2, thr) ? v.z * scale : 0.f;
-    v.w = dropout_keep(key, e + 3, thr) ? v.w * scale : 0.f;
+    v = dropout_apply4(key, e, thr, scale, v);
     store_planes4(dst + i * 4, lo_off, v);
   }
 }
@@ -82,10 +79,7 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     float4 v = reinterpret_cast<const float4*>(src)[i];
     const uint64_t e = (uint64_t)i * 4;
-    v.x = dropout_keep(key, e + 0, thr) ? v.x * scale : 0.f;
-    v.y = dropout_keep(key, e + 1, thr) ? v.y * scale : 0.f;
-    v.z = dropout_keep(key, e + 2, thr) ? v.z * scale : 0.f;
-    v.w = dropout_keep(key, e + 3, thr) ? v.w * scale : 0.f;
+    v = dropout_apply4(key, e, thr, scale, v);
     reinterpret_cast<float4*>(dst)[i] = v;
   }
 }

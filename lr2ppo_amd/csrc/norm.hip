@@ -129,10 +129,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         if (dxm_hi) {
           float4 m = d;
           if (drop_scale != 0.f) {
-            m.x = dropout_keep(drop_key, o + 0, drop_thr) ? d.x * drop_scale : 0.f;
-            m.y = dropout_keep(drop_key, o + 1, drop_thr) ? d.y * drop_scale : 0.f;
-            m.z = dropout_keep(drop_key, o + 2, drop_thr) ? d.z * drop_scale : 0.f;
-            m.w = dropout_keep(drop_key, o + 3, drop_thr) ? d.w * drop_scale : 0.f;
+            m = dropout_apply4(drop_key, o, drop_thr, drop_scale, d);
           }
           store_planes4(dxm_hi + o, dxm_lo_off, m);
         }

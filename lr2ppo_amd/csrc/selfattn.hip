@@ -32,6 +32,24 @@ struct DropP {
 __device__ __forceinline__ float drop_mul(const DropP& d, uint64_t idx) {
   return dropout_keep(d.key, idx, d.thr) ? d.inv_keep : 0.0f;
 }
+// The mask of probability (b, h, q, key) is element ((b * heads + h) * L + q) * mask_pitch(L) + key of the mask stream: rows are
+// pitched to a multiple of 4 so that a lane's 4 consecutive keys 4j .. 4j + 3 are one aligned group = two hashes (dropout_keep4).
+__device__ __forceinline__ uint64_t mask_pitch(int L) { return (uint64_t)((L + 3) & ~3); }
+__device__ __forceinline__ f32x4_t drop_mul4v(const DropP& d, uint64_t idx4, f32x4_t x) {
+  bool k[4];
+  dropout_keep4(d.key, idx4, d.thr, k);
+  return f32x4_t{k[0] ? x[0] * d.inv_keep : 0.0f, k[1] ? x[1] * d.inv_keep : 0.0f, k[2] ? x[2] * d.inv_keep : 0.0f,
+                 k[3] ? x[3] * d.inv_keep : 0.0f};
+}
+// x[0..3] *= mask / keep of the aligned group starting at idx4
+__device__ __forceinline__ void drop_mul4(const DropP& d, uint64_t idx4, float& x0, float& x1, float& x2, float& x3) {
+  bool k[4];
+  dropout_keep4(d.key, idx4, d.thr, k);
+  x0 = k[0] ? x0 * d.inv_keep : 0.0f;
+  x1 = k[1] ? x1 * d.inv_keep : 0.0f;
+  x2 = k[2] ? x2 * d.inv_keep : 0.0f;
+  x3 = k[3] ? x3 * d.inv_keep : 0.0f;
+}
 
 // K plane: 16-B unit u of row r at u ^ ((r >> 1) & 7): conflict-free ds_read_b128 fragment reads (as in gemm.hip).
 __device__ __forceinline__ int k_off(int r, int u) { return r * ROW_B + ((u ^ ((r >> 1) & 7)) << 4); }
@@ -102,7 +120,7 @@ __device__ __forceinline__ void attn_subtile_fwd(const char* sK, const char* sV,
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
   if (lse && g == 0 && q_row < L) lse[((size_t)b * heads + h) * L + q_row] = mx * LN2 + logf(sum);
-  const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_row < L ? q_row : 0)) * (uint64_t)L;
+  const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_row < L ? q_row : 0)) * mask_pitch(L);
 
   // ---- O = (P~ V) / sum over 32-key blocks, P~ = the un-normalised exponentials in (0, 1]: fragments straight from the
   // accumulators (permuted contraction index); the 1 / sum goes onto the 16 output values instead of the NT * 4 probabilities
@@ -119,11 +137,8 @@ __device__ __forceinline__ void attn_subtile_fwd(const char* sK, const char* sV,
       p[4 + r] = s[2 * u + 1][r];
     }
     if (dr.thr) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        p[r] *= drop_mul(dr, drow + 32 * u + 4 * g + r);
-        p[4 + r] *= drop_mul(dr, drow + 32 * u + 16 + 4 * g + r);
-      }
+      drop_mul4(dr, drow + 32 * u + 4 * g, p[0], p[1], p[2], p[3]);
+      drop_mul4(dr, drow + 32 * u + 16 + 4 * g, p[4], p[5], p[6], p[7]);
     }
     const uint32_t h01 = cvt_pk_bf16(p[0], p[1]), h23 = cvt_pk_bf16(p[2], p[3]);
     const uint32_t h45 = cvt_pk_bf16(p[4], p[5]), h67 = cvt_pk_bf16(p[6], p[7]);
@@ -347,7 +362,7 @@ __device__ __forceinline__ void blocked_subtiles(AttnState<SLOTS>& st, const bf1
 #pragma unroll
       for (int n = 0; n < 4; ++n) st.o[J][n][r] *= a_r;
     }
-    const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_row < L ? q_row : 0)) * (uint64_t)L + (uint64_t)k0;
+    const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_row < L ? q_row : 0)) * mask_pitch(L) + (uint64_t)k0;
     const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
 #pragma unroll
     for (int u = 0; u < NT / 2; ++u) {
@@ -358,11 +373,8 @@ __device__ __forceinline__ void blocked_subtiles(AttnState<SLOTS>& st, const bf1
         p[4 + r] = s[2 * u + 1][r];
       }
       if (dr.thr) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          p[r] *= drop_mul(dr, drow + 32 * u + 4 * g + r);
-          p[4 + r] *= drop_mul(dr, drow + 32 * u + 16 + 4 * g + r);
-        }
+        drop_mul4(dr, drow + 32 * u + 4 * g, p[0], p[1], p[2], p[3]);
+        drop_mul4(dr, drow + 32 * u + 16 + 4 * g, p[4], p[5], p[6], p[7]);
       }
       const uint32_t h01 = cvt_pk_bf16(p[0], p[1]), h23 = cvt_pk_bf16(p[2], p[3]);
       const uint32_t h45 = cvt_pk_bf16(p[4], p[5]), h67 = cvt_pk_bf16(p[6], p[7]);
@@ -642,16 +654,17 @@ __global__ __launch_bounds__(64 * NW) void self_attn_bwd_dq_kernel(const bf16_t*
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
-  const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_ok ? q_row : 0)) * (uint64_t)L;
+  const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_ok ? q_row : 0)) * mask_pitch(L);
   float dd = 0.f;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
+    if (dr.thr) dp[t] = drop_mul4v(dr, drow + 16 * t + 4 * g, dp[t]);    // dP = dPd o M
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       s[t][r] *= inv;                                                     // P
-      if (dr.thr) dp[t][r] *= drop_mul(dr, drow + 16 * t + 4 * g + r);    // dP = dPd o M
       dd += dp[t][r] * s[t][r];
     }
+  }
   dd += __shfl_xor(dd, 16, 64);
   dd += __shfl_xor(dd, 32, 64);
   if (g == 0 && q_ok) {
@@ -773,7 +786,7 @@ __global__ __launch_bounds__(64 * NW) void self_attn_bwd_dkv_kernel(const bf16_t
         float m = 1.0f;
         if (dr.thr) {
           const int q = 16 * t + 4 * g + r;
-          m = drop_mul(dr, (dbase + (uint64_t)(q < L ? q : 0)) * (uint64_t)L + (uint64_t)(k_ok ? key : 0));
+          m = drop_mul(dr, (dbase + (uint64_t)(q < L ? q : 0)) * mask_pitch(L) + (uint64_t)(k_ok ? key : 0));
         }
         pd[4 * half + r] = p * m;
         ds[4 * half + r] = p * (d[r] * m - ddv[r]) * scale;
@@ -824,7 +837,7 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dq_blocked_kernel(
   bf16x8_t qh[2], ql[2], gh[2], gl[2];
   load_frags(Qh, lo_off, (row0 + (q_ok ? q_row : 0)) * (size_t)ld + col0 + 8 * g, q_ok, qh, ql);
   load_frags(dOh, do_lo_off, (row0 + (q_ok ? q_row : 0)) * (size_t)ld_do + col0 + 8 * g, q_ok, gh, gl);
-  const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_ok ? q_row : 0)) * (uint64_t)L;
+  const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_ok ? q_row : 0)) * mask_pitch(L);
 
   float m = -INFINITY, l = 0.f, a = 0.f, lse_q = 0.f, dd = 0.f;
   f32x4_t o[4];
@@ -874,13 +887,8 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dq_blocked_kernel(
         sa[1] = sa[1] * scale + mk.y;
         sa[2] = sa[2] * scale + mk.z;
         sa[3] = sa[3] * scale + mk.w;
-        if (dr.thr) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = k0 + 16 * t + 4 * g + r;
-            d[r] *= drop_mul(dr, drow + (uint64_t)(key < L ? key : 0));         // dP = dPd o M
-          }
-        }
+        // dP = dPd o M (keys past L: P is 0 there, whatever the mask says)
+        if (dr.thr) d = drop_mul4v(dr, drow + (uint64_t)(k0 + 16 * t + 4 * g), d);
         s[t] = sa;
         dp[t] = d;
       }
@@ -1025,7 +1033,7 @@ __global__ __launch_bounds__(256) void self_attn_bwd_dkv_blocked_kernel(
           float mm = 1.0f;
           if (dr.thr) {
             const int q = q0 + 16 * t + 4 * g + r;
-            mm = drop_mul(dr, (dbase + (uint64_t)(q < L ? q : 0)) * (uint64_t)L + (uint64_t)(k_ok ? key : 0));
+            mm = drop_mul(dr, (dbase + (uint64_t)(q < L ? q : 0)) * mask_pitch(L) + (uint64_t)(k_ok ? key : 0));
           }
           pd[4 * half + r] = p * mm;
           ds[4 * half + r] = p * (d[r] * mm - ddv[r]) * scale;

@@ -208,7 +208,7 @@ def linear_wgrad(ws, dy, x, dw, db, M, N_in, N_out):
 
 
 def _ln_bwd(ws, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, **kw):
-    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, ws.vec("ln_partials", 256 * 2 * D), dgamma, dbeta, rows=rows, D=D, **kw)
+    ops.layernorm_bwd(dy, x, gamma, mean, rstd, dx, ws.vec("ln_partials", ops.LN_BWD_BLOCKS * 2 * D), dgamma, dbeta, rows=rows, D=D, **kw)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -356,8 +356,13 @@ def layernorm_fwd(x, gamma, beta, out, mean=None, rstd=None, *, rows, D, eps=1e-
     return out if out is not None else out_planes
 
 
+# workgroups of the LayerNorm backward (each leaves one partial row of d gamma / d beta): 4 per CU.  With one per CU (round 2) the
+# kernel kept 24 KB of loads in flight per CU and ran at 3.4 TB/s on the encoders' [100864, 768] rows (rocprofv3, profiles/r03_*).
+LN_BWD_BLOCKS = 1024
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partials, dgamma, dbeta, *, rows, D, group=0, group_stride=0,
-                  resid_grad=None, dx_planes: Optional[Planes] = None, drop: Optional[Drop] = None, nblocks=256, mode=0,
+                  resid_grad=None, dx_planes: Optional[Planes] = None, drop: Optional[Drop] = None, nblocks=LN_BWD_BLOCKS, mode=0,
                   eps=1e-5):
     """dx (fp32) = LN'(dy) + resid_grad; dx_planes = planes of dropout_mask(dx)/(1-p) (p = 0: of dx).
     mode / eps: the forward's (0 = nn.LayerNorm, 1 = TencentPretrain LayerNorm)."""

@@ -198,7 +198,7 @@ class Embedding(nn.Module):
             dx = torch.empty(M, E, device=dev)
             G[ln.gamma], G[ln.beta] = buf(ln.gamma), buf(ln.beta)
             ops.layernorm_bwd(dy.view(M, E), saved["x"].view(M, E), ln.gamma.data, saved["mean"], saved["rstd"], dx,
-                              ws.vec("ln_partials", 256 * 2 * E), G[ln.gamma], G[ln.beta], rows=M, D=E, mode=1, eps=ln.eps)
+                              ws.vec("ln_partials", ops.LN_BWD_BLOCKS * 2 * E), G[ln.gamma], G[ln.beta], rows=M, D=E, mode=1, eps=ln.eps)
             dy = dx.view_as(dy)
         if saved["kind"] == ("patch", "pos"):
             pe = self.patch

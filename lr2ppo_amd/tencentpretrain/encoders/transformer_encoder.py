@@ -289,7 +289,7 @@ class TransformerEncoder(nn.Module):
             for q in params:
                 G[q] = flat[off:off + q.numel()].view_as(q)
                 off += q.numel()
-        partials = ws.vec("ln_partials", 256 * 2 * E)
+        partials = ws.vec("ln_partials", ops.LN_BWD_BLOCKS * 2 * E)
         lse_ws, dsum_ws = ws.vec("attn_lse", B * H * L), ws.vec("attn_dsum", B * H * L)
         dwqkv, dbqkv = ws.mat("dwqkv", 3 * E, E), ws.vec("dbqkv", 3 * E)
         pre = self.layernorm_positioning == "pre"

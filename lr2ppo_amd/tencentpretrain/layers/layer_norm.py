@@ -31,7 +31,7 @@ class _LayerNormFn(torch.autograd.Function):
         dy = dout.contiguous().view(M, D)
         dx = torch.empty_like(x2)
         dgamma, dbeta = torch.empty(D, device=dy.device), torch.empty(D, device=dy.device)
-        partials = torch.empty(256 * 2 * D, device=dy.device)
+        partials = torch.empty(ops.LN_BWD_BLOCKS * 2 * D, device=dy.device)
         ops.layernorm_bwd(dy, x2, gamma, mean, rstd, dx, partials, dgamma, dbeta, rows=M, D=D, mode=1, eps=ctx.eps)
         return dx.view(ctx.shape), dgamma, dbeta, None
 

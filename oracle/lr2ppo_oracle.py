@@ -125,27 +125,46 @@ def layernorm_tp(x, gamma, beta, eps: float = 1e-6):
 # the reference uses torch's Philox stream which no other backend can reproduce)
 # --------------------------------------------------------------------------------------------
 def dropout_keep_mask(seed: int, site: int, numel: int, p: float) -> np.ndarray:
-    """keep[i] for flat element index i; mirrors lr2ppo_amd/csrc/common.h::dropout_keep."""
-    idx = np.arange(numel, dtype=np.uint64)
+    """keep[i] for flat element index i; mirrors lr2ppo_amd/csrc/common.h::dropout_keep (round 3: one 32-bit hash -- the
+    'lowbias32' finaliser on (i >> 1) ^ k32 -- serves two consecutive elements, 16 bits each, against floor(p * 65536))."""
+    M32 = np.uint64(0xFFFFFFFF)
     key = ((int(site) << 40) ^ ((int(seed) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
-    x = idx ^ np.uint64(key)
-    # splitmix64 finaliser
-    x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
-    x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
-    x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & np.uint64(0xFFFFFFFFFFFFFFFF)
-    x = x ^ (x >> np.uint64(31))
-    u = (x >> np.uint64(32)).astype(np.uint32)
-    # the C ABI carries p as a float: the threshold is formed from float32(p) (0.1f = 0.100000001490116: 7 counts above 0.1 * 2^32)
-    thr = np.uint32(min(int(float(np.float32(p)) * 4294967296.0), 4294967295))
-    return u >= thr
+    k32 = np.uint64((key ^ (key >> 32)) & 0xFFFFFFFF)
+    idx = np.arange(numel, dtype=np.uint64)
+    x = ((idx >> np.uint64(1)) & M32) ^ k32                     # 32-bit arithmetic carried in uint64 lanes
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & M32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & M32
+    x ^= x >> np.uint64(16)
+    field = np.where((idx & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))
+    # the C ABI carries p as a float: the threshold is formed from float32(p)
+    thr = np.uint64(min(int(float(np.float32(p)) * 65536.0), 65535))
+    return field >= thr
 
 
-def _apply_dropout(x, drop: Optional[dict], site: int):
+def attention_keep_mask(seed: int, site: int, batch: int, heads: int, L: int, p: float) -> np.ndarray:
+    """keep[b, h, q, key] of the encoders' probability dropout (lr2_self_attn_fwd / bwd): the mask stream is laid out with the key
+    dimension pitched to a multiple of 4 (csrc/selfattn.hip::mask_pitch)."""
+    pitch = (L + 3) // 4 * 4
+    return np.ascontiguousarray(dropout_keep_mask(seed, site, batch * heads * L * pitch, p).reshape(batch, heads, L, pitch)[..., :L])
+
+
+def _apply_dropout(x, drop: Optional[dict], site: int, pitch4: bool = False):
+    """pitch4: the mask stream pitches the LAST dimension to a multiple of 4 (the encoders' attention probabilities [b, heads, L, L]:
+    element (b, h, q, key) is index ((b * heads + h) * L + q) * pitch + key, csrc/selfattn.hip::mask_pitch)."""
     if drop is None or drop.get("p", 0.0) <= 0.0:
         return x
     p = float(drop["p"])
-    keep = dropout_keep_mask(int(drop["seed"]), int(drop.get("site_base", 0)) + site, x.numel(), p)
-    m = torch.from_numpy(keep.astype(np.float32)).view_as(x) / (1.0 - p)
+    site_id = int(drop.get("site_base", 0)) + site
+    if pitch4:
+        L = x.shape[-1]
+        pitch = (L + 3) // 4 * 4
+        rows = x.numel() // L
+        keep = dropout_keep_mask(int(drop["seed"]), site_id, rows * pitch, p).reshape(rows, pitch)[:, :L]
+    else:
+        keep = dropout_keep_mask(int(drop["seed"]), site_id, x.numel(), p)
+    m = torch.from_numpy(np.ascontiguousarray(keep).astype(np.float32)).view_as(x) / (1.0 - p)
     return x * m
 
 
@@ -415,7 +434,7 @@ def tp_attention(P: Params, prefix: str, h: torch.Tensor, mask: torch.Tensor, he
     k = linear(P, prefix + ".linear_layers.1", h).view(b, L, heads, d).transpose(1, 2)
     v = linear(P, prefix + ".linear_layers.2", h).view(b, L, heads, d).transpose(1, 2)
     s = (q @ k.transpose(-2, -1)) / math.sqrt(float(d)) + mask
-    p = _apply_dropout(torch.softmax(s, dim=-1), drop, site)
+    p = _apply_dropout(torch.softmax(s, dim=-1), drop, site, pitch4=True)
     o = (p @ v).transpose(1, 2).contiguous().view(b, L, e)
     return linear(P, prefix + ".final_linear", o)
 

@@ -172,7 +172,7 @@ def test_layernorm_bwd(ops, dev, rows, D, drop_p):
     ops.layernorm_fwd(xd, gam.to(dev), bet.to(dev), out, mean, rstd, rows=rows, D=D)
     dx, dxm = torch.empty(rows, D, device=dev), ops.Planes.empty(rows, D, dev)
     dgam, dbet = torch.empty(D, device=dev), torch.empty(D, device=dev)
-    partials = torch.empty(256 * 2 * D, device=dev)
+    partials = torch.empty(ops.LN_BWD_BLOCKS * 2 * D, device=dev)
     drop = ops.Drop(drop_p, 99, 4) if drop_p > 0 else None
     ops.layernorm_bwd(dy.to(dev), xd, gam.to(dev), mean, rstd, dx, partials, dgam, dbet, rows=rows, D=D,
                       resid_grad=rg.to(dev), dx_planes=dxm, drop=drop)
@@ -266,7 +266,7 @@ def test_self_attn_bwd_matches_autograd(ops, dev, batch, heads, L, drop_p):
     seed, site = 99, 5
     mult = torch.ones(batch, heads, L, L, dtype=torch.float64)
     if drop_p > 0:
-        keep = O.dropout_keep_mask(seed, site, batch * heads * L * L, drop_p)
+        keep = O.attention_keep_mask(seed, site, batch, heads, L, drop_p)
         mult = torch.from_numpy(np.asarray(keep, dtype=np.float64)).view(batch, heads, L, L) / (1.0 - drop_p)
     x = qkv.double().requires_grad_(True)
     qh, kh, vh = (t.reshape(batch, L, heads, 64).transpose(1, 2) for t in x.split(E, dim=1))

@@ -121,6 +121,18 @@ def test_dropout_mask_statistics_and_determinism():
     k3 = O.dropout_keep_mask(seed=6, site=2, numel=200000, p=0.1)
     assert np.array_equal(k1, k2) and not np.array_equal(k1, k3)
     assert abs(k1.mean() - 0.9) < 5e-3
+    # the two 16-bit fields of one hash (elements 2j, 2j + 1) and neighbouring hashes are uncorrelated; sites differ
+    a = k1.astype(np.float64) - k1.mean()
+    for lag in (1, 2, 3, 196, 197):
+        assert abs((a[:-lag] * a[lag:]).mean() / a.var()) < 0.01, lag
+    k4 = O.dropout_keep_mask(seed=5, site=3, numel=200000, p=0.1)
+    assert abs(((k4.astype(np.float64) - k4.mean()) * a).mean() / a.var()) < 0.01
+    for p in (0.05, 0.3, 0.5):
+        assert abs(O.dropout_keep_mask(seed=11, site=0, numel=400000, p=p).mean() - (1 - p)) < 3e-3
+    # attention masks: key dimension pitched to a multiple of 4
+    m = O.attention_keep_mask(3, 1, 2, 3, 5, 0.1)
+    flat = O.dropout_keep_mask(3, 1, 2 * 3 * 5 * 8, 0.1).reshape(2, 3, 5, 8)
+    assert m.shape == (2, 3, 5, 5) and np.array_equal(m, flat[..., :5])
 
 
 @pytest.mark.slow

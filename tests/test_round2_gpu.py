@@ -379,7 +379,7 @@ def test_self_attn_forward_blocked_keys(dev, batch, heads, L, drop_p):
     mult = torch.ones(batch, heads, L, L, dtype=torch.float64)
     seed, site = 42, 7
     if drop_p > 0:
-        keep = O.dropout_keep_mask(seed, site, batch * heads * L * L, drop_p)
+        keep = O.attention_keep_mask(seed, site, batch, heads, L, drop_p)
         mult = torch.from_numpy(np.asarray(keep, dtype=np.float64)).view(batch, heads, L, L) / (1.0 - drop_p)
     qh, kh, vh = (t.double().reshape(batch, L, heads, 64).transpose(1, 2) for t in qkv.split(E, dim=1))
     sc = qh @ kh.transpose(-2, -1) / 8.0 + mask

@@ -104,7 +104,7 @@ for it in range(max(10, a.n // 5)):
     seed, site = 1234 + it, 3
     mult = torch.ones(batch, heads, L, L, dtype=torch.float64)
     if drop_p > 0:
-        keep = O.dropout_keep_mask(seed, site, batch * heads * L * L, drop_p)
+        keep = O.attention_keep_mask(seed, site, batch, heads, L, drop_p)
         mult = torch.from_numpy(np.asarray(keep, dtype=np.float64)).view(batch, heads, L, L) / (1.0 - drop_p)
     x = qkv.double().requires_grad_(True)
     qh, kh, vh = (t.reshape(batch, L, heads, 64).transpose(1, 2) for t in x.split(E, dim=1))
@@ -154,7 +154,7 @@ for it in range(max(10, a.n // 5)):
     dx, dxm = torch.empty(rows, D, device=dev), ops.Planes.empty(rows, D, dev)
     dgam, dbet = torch.empty(D, device=dev), torch.empty(D, device=dev)
     drop = ops.Drop(drop_p, 99 + it, 4) if drop_p > 0 else None
-    ops.layernorm_bwd(dy.to(dev), x.to(dev), gam.to(dev), mean, rstd, dx, torch.empty(256 * 2 * D, device=dev), dgam, dbet, rows=rows,
+    ops.layernorm_bwd(dy.to(dev), x.to(dev), gam.to(dev), mean, rstd, dx, torch.empty(ops.LN_BWD_BLOCKS * 2 * D, device=dev), dgam, dbet, rows=rows,
                       D=D, resid_grad=rg.to(dev), dx_planes=dxm, drop=drop, mode=mode, eps=eps)
     ref_dx = xt.grad + rg.double()
     keep = torch.ones(rows, D, dtype=torch.float64)
