@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 13
+#define LR2_ABI_VERSION 14
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -58,6 +58,13 @@ typedef struct lr2_epilogue {
   void* adam_m;
   void* adam_v;
   double adam_lr, adam_beta1, adam_beta2, adam_eps, adam_weight_decay;
+  /* (1,1) form only -- the weight gradient dW = dY^T X of an nn.Linear: when colsum is set, colsum[m] = sum over k of A[k, m]
+   * (the gradient of the layer's BIAS, db = sum of dY rows) is produced by the same call.  On the 256 x 256 kernel (block_m =
+   * 256) the sums are accumulated from the A fragments the product stages anyway -- dY is not read a second time; otherwise a
+   * column-sum pass runs behind the product.  colsum_ws: fp32 scratch, max(128, splits * ceil(N / 256)) * M floats.
+   * replaces: autograd of the bias of nn.Linear (tencentpretrain/layers/position_ffn.py:12-15, multi_headed_attn.py:55-76). */
+  void* colsum;
+  void* colsum_ws;
 } lr2_epilogue;
 
 /* C[M,N] = op(A).op(B), fp32 in / fp32 out, computed on bf16 MFMA with fp32 accumulation.

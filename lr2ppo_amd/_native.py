@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(CSRC, "liblr2ppo_hip.so")
 SOURCES = ["gemm.hip", "gemm256.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
 
-ABI_VERSION = 13     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
+ABI_VERSION = 14     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
 
 _lock = threading.Lock()
 _lib = None
@@ -66,7 +66,7 @@ class Epilogue(C.Structure):
                 ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("_pad", C.c_uint32), ("drop_seed", C.c_uint64),
                 ("adam_p", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_lr", C.c_double),
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
-                ("adam_weight_decay", C.c_double)]
+                ("adam_weight_decay", C.c_double), ("colsum", C.c_void_p), ("colsum_ws", C.c_void_p)]
 
 
 class SplitChunk(C.Structure):

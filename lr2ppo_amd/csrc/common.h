@@ -158,6 +158,7 @@ struct Epilogue {
   float* adam_v;
   float adam_lr, adam_b1, adam_b2, adam_ob1, adam_ob2, adam_eps, adam_wd;
   int stream_nt;         // optimizer state p / m / v: non-temporal loads and stores (each byte is touched once per launch)
+  float* colsum_partial; // gemm256 TN: [splits * tiles_n][M] partial column sums of A (bias gradient), or NULL
 };
 
 // One AdamW element update, TencentPretrain semantics (correct_bias=False; eps outside the sqrt; decay after the

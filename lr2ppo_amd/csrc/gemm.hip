@@ -572,6 +572,7 @@ Epilogue to_device_epilogue(const lr2_epilogue* e) {
 }
 
 int launch_gemm256_nt(const GemmParams& p, hipStream_t stream);   // gemm256.hip
+int launch_gemm256_tn(const GemmParams& p, int splits, hipStream_t stream);
 
 }  // namespace lr2gemm
 using namespace lr2gemm;
@@ -583,6 +584,7 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   if (!A || !B || M <= 0 || N <= 0 || K <= 0 || !epi || (!epi->out && !epi->out_hi && !epi->adam_p)) return LR2_ERR_ARG;
   if (epi->adam_p && (!epi->adam_m || !epi->adam_v || epi->out || epi->out_hi || epi->ld_out % 4)) return LR2_ERR_ARG;
   if (passes != 1 && passes != 3) return LR2_ERR_ARG;
+  if (epi->colsum && (!trans_a || !trans_b || !epi->colsum_ws || (M % 4))) return LR2_ERR_ARG;   // weight-gradient form only
   const bool want256 = block_m == 256;
   if (block_m != 64) block_m = 128;
   // K-contiguous operands need whole K tiles (a ragged K would read into the next row, not zeros); ragged M / N are
@@ -610,7 +612,12 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   const bool use256 = want256 && g256_env && a_planes && b_planes && !trans_a && !trans_b && passes == 3 && splits <= 1 &&
                       (K % 32) == 0 && a_bytes <= 0xFFFFFD00ull && b_bytes <= 0xFFFFFD00ull && !epi->adam_p &&
                       ((epi->act == 2) + (epi->resid != nullptr) + (epi->accumulate != 0)) <= 1;   // one request slot per element
-  const int BK = use256 ? 32 : (a_planes && b_planes) ? (bk_env ? bk_env : (trans_b ? 32 : 64)) : 64;
+  // Long-contraction TN products of planes (weight gradients at >= 4096 token rows): the TN form of that kernel, tiles x K-splits
+  // in one round of the chip, raw slabs + the reducer below.
+  const bool use256tn = want256 && g256_env && a_planes && b_planes && trans_a && trans_b && passes == 3 &&
+                        a_bytes <= 0xFFFFFD00ull && b_bytes <= 0xFFFFFD00ull && !epi->adam_p &&
+                        ((epi->act == 2) + (epi->resid != nullptr) + (epi->accumulate != 0)) <= 1;
+  const int BK = (use256 || use256tn) ? 32 : (a_planes && b_planes) ? (bk_env ? bk_env : (trans_b ? 32 : 64)) : 64;
   if ((!trans_a || !trans_b) && (K % BK != 0)) return LR2_ERR_SHAPE;
   const int a_align = a_planes ? 8 : 4, b_align = b_planes ? 8 : 4;  // 16-byte rows
   if ((lda % a_align) || (ldb % b_align) || (N % 4)) return LR2_ERR_SHAPE;
@@ -651,7 +658,10 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (use256) return launch_gemm256_nt(p, s);
-  if (a_planes && b_planes && BK == 32) rc = dispatch_form<32, true, true>(p, splits, block_m, passes, trans_a, trans_b, s);
+  const bool fused_colsum = use256tn && epi->colsum;
+  if (fused_colsum) p.epi.colsum_partial = (float*)epi->colsum_ws;
+  if (use256tn) rc = launch_gemm256_tn(p, splits, s);
+  else if (a_planes && b_planes && BK == 32) rc = dispatch_form<32, true, true>(p, splits, block_m, passes, trans_a, trans_b, s);
   else if (a_planes && b_planes) rc = dispatch_form<64, true, true>(p, splits, block_m, passes, trans_a, trans_b, s);
   else if (a_planes) rc = dispatch_form<64, true, false>(p, splits, block_m, passes, trans_a, trans_b, s);
   else rc = dispatch_form<64, false, false>(p, splits, block_m, passes, trans_a, trans_b, s);
@@ -662,6 +672,13 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
     if (blocks > 2048) blocks = 2048;
     LR2_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)splitk_ws, splits, M, N, p.epi);
     if (lr2_launch_status(__func__)) return LR2_ERR_LAUNCH;
+  }
+  if (epi->colsum) {
+    // bias gradient of the layer this weight gradient belongs to: the 256 x 256 kernel left splits * tiles_n partial rows; any
+    // other path sums the columns of A in a pass of its own
+    if (fused_colsum)
+      return lr2_colsum_partials_finish(epi->colsum_ws, splits * ((N + 255) / 256), M, M, epi->colsum, 0, stream);
+    return lr2_colsum(A, a_planes, a_planes ? a_lo_off / 2 : 0, K, M, lda, epi->colsum_ws, K < 128 ? K : 128, epi->colsum, stream);
   }
   return 0;
 }

@@ -260,6 +260,262 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
 
 }  // namespace g256
 
+// ---------------------------------------------------------------------------------------------------------------------
+// TN form of the same kernel:  C[M,N] = A^T . B  with A [K][lda] (M contiguous) and B [K][ldb] (N contiguous), both bf16 hi/lo
+// planes -- the weight gradient dW = dY^T X of an nn.Linear at M_tokens = K >= 1e4 (encoder training, the stage-1 head at 20
+// tags): the output is small (768 x 3072: 36 tiles), the contraction is long, so the grid is tiles x K-splits (one round of the
+// chip) and the epilogue is a raw fp32 slab per split + the fixed-order reducer of gemm.hip.
+//   replaces: autograd of nn.Linear's weight in tencentpretrain/layers/position_ffn.py:12-15, multi_headed_attn.py:55-76,
+//   finetune/ppo.py:164-170 (cuBLAS sgemm with a transposed operand upstream).
+// Same ring, same four-phase / two-group ping-pong, same counted waits as the NT kernel above.  What differs:
+//   * a part's LDS image is [32 k-rows][16 units of 8 consecutive m (or n)]: the operands keep their HBM orientation, a DMA
+//     piece of a wave is 4 k-rows x 256 B; unit u of k-row k sits at u ^ swz_tr(k) (XOR on 32-byte chunks, as gemm.hip's
+//     contraction-strided image: conflict-free transposed reads);
+//   * fragments are read with ds_read_b64_tr_b16 (two per fragment: k-rows 8g + q and 8g + q + 4): twice the LDS instructions
+//     of the NT form for the same bytes;
+//   * the ring is laid out [A half][stage][plane] / [B half][stage][plane] so that every fragment address is one of six per-lane
+//     bases (the XOR swizzle does not commute with the tile offset) plus an immediate < 64 KiB.
+namespace g256t {
+
+using g256::BK;
+using g256::BM;
+using g256::BN;
+using g256::OOB;
+constexpr int PLANE = 32 * 256;        // one plane of one part: 32 k-rows x 128 m x 2 B = 8 KiB
+constexpr int STAGE_STRIDE = 2 * PLANE;   // hi + lo of one stage of one part
+constexpr int HALF_STRIDE = 2 * STAGE_STRIDE;
+constexpr int REGION = 2 * HALF_STRIDE;   // A region, then B region: 64 KiB each
+constexpr int LDS_BYTES = 2 * REGION;
+
+__device__ __forceinline__ int swz_tr16(int k) { return ((((k & 3) | (((k >> 3) & 1) << 2))) << 1) & 15; }
+
+template <int IMM>
+__device__ __forceinline__ bf16x8_t lds_read_tr(uint32_t addr) {
+  u32x2_t lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "i"(IMM));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "i"(IMM + 4 * 256));
+  u32x4_t v = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+struct Ctx {
+  __amdgpu_buffer_rsrc_t a_hi, a_lo, b_hi, b_lo;
+  uint32_t voff_a[2], voff_b[2];   // per-lane source byte offsets of this wave's piece of part A(h) / B(h) at this split's K step 0
+  uint32_t kstep_a, kstep_b;       // bytes per 32-row K step
+  uint32_t rd_a[4], rd_b[2];       // per-lane LDS read bases of the wave's A tiles i = 0..3 / B tiles j = 0..1 (stage 0, half 0, hi)
+  char* smem;
+  int wave, nt;
+};
+
+template <bool IS_A, int HALF>
+__device__ __forceinline__ void issue_part(const Ctx& c, int tile, int stage) {
+  const uint32_t base = IS_A ? c.voff_a[HALF] : c.voff_b[HALF];
+  const uint32_t step = IS_A ? c.kstep_a : c.kstep_b;
+  const uint64_t o = (uint64_t)base + (uint64_t)(uint32_t)tile * (uint64_t)step;
+  const uint32_t v = (tile < c.nt && base != OOB && o < (uint64_t)OOB) ? (uint32_t)o : OOB;
+  char* dst = c.smem + (IS_A ? 0 : REGION) + HALF * HALF_STRIDE + stage * STAGE_STRIDE + c.wave * 1024;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_A ? c.a_hi : c.b_hi, LDS_PTR(dst), 16, v, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_A ? c.a_lo : c.b_lo, LDS_PTR(dst + PLANE), 16, v, 0, 0, 0);
+}
+
+template <int HALF, int S>
+__device__ __forceinline__ void read_a_half(const Ctx& c, bf16x8_t (&hi)[4], bf16x8_t (&lo)[4]) {
+  constexpr int O = HALF * HALF_STRIDE + S * STAGE_STRIDE;
+  hi[0] = lds_read_tr<O>(c.rd_a[0]);
+  hi[1] = lds_read_tr<O>(c.rd_a[1]);
+  hi[2] = lds_read_tr<O>(c.rd_a[2]);
+  hi[3] = lds_read_tr<O>(c.rd_a[3]);
+  lo[0] = lds_read_tr<O + PLANE>(c.rd_a[0]);
+  lo[1] = lds_read_tr<O + PLANE>(c.rd_a[1]);
+  lo[2] = lds_read_tr<O + PLANE>(c.rd_a[2]);
+  lo[3] = lds_read_tr<O + PLANE>(c.rd_a[3]);
+}
+template <int HALF, int S>
+__device__ __forceinline__ void read_b_half(const Ctx& c, bf16x8_t (&hi)[2], bf16x8_t (&lo)[2]) {
+  constexpr int O = HALF * HALF_STRIDE + S * STAGE_STRIDE;
+  hi[0] = lds_read_tr<O>(c.rd_b[0]);
+  hi[1] = lds_read_tr<O>(c.rd_b[1]);
+  lo[0] = lds_read_tr<O + PLANE>(c.rd_b[0]);
+  lo[1] = lds_read_tr<O + PLANE>(c.rd_b[1]);
+}
+
+// Column sums of A (the bias gradient that belongs to this weight gradient) from the fragments a wave holds anyway: lane l of a
+// fragment carries A[k = 8 * (l >> 4) + j][m = tile row (l & 15)], j = 0..7, as packed bf16 pairs; hi and lo plane are added in
+// fp32.  cs[i] = this lane's share for m-tile i; the four lane groups are combined once, after the main loop.
+__device__ __forceinline__ float frag_sum(const bf16x8_t& f) {
+  const u32x4_t w = __builtin_bit_cast(u32x4_t, f);
+  float s = 0.f;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) s += __uint_as_float(w[d] << 16) + __uint_as_float(w[d] & 0xffff0000u);
+  return s;
+}
+template <int AH>
+__device__ __forceinline__ void colsum_frags(float (&cs)[8], const bf16x8_t (&ahi)[4], const bf16x8_t (&alo)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cs[AH * 4 + i] += frag_sum(ahi[i]) + frag_sum(alo[i]);
+}
+
+// One K step; the section / refill / counted-wait schedule of g256::k_step<S, 0>.  do_cs (wave-uniform): this wave adds the K
+// step's A fragments to its column sums (after the MFMAs of the phase were issued: the vector work runs under the matrix pipe).
+template <int S>
+__device__ __forceinline__ void k_step(const Ctx& c, int t, f32x4_t (&acc)[8][4], float (&cs)[8], bool do_cs) {
+  using g256::end_load_section;
+  using g256::mfma_section;
+  bf16x8_t ahi[4], alo[4], bhi[2], blo[2];
+  issue_part<false, 0>(c, t + 1, S ^ 1);          // phase 0: quadrant (A0, B0)
+  read_a_half<0, S>(c, ahi, alo);
+  read_b_half<0, S>(c, bhi, blo);
+  end_load_section<12>();
+  mfma_section<0, 0>(acc, ahi, alo, bhi, blo);
+  issue_part<true, 0>(c, t + 2, S);               // phase 1: (A0, B1)
+  read_b_half<1, S>(c, bhi, blo);
+  if (do_cs) colsum_frags<0>(cs, ahi, alo);
+  end_load_section<12>();
+  mfma_section<0, 1>(acc, ahi, alo, bhi, blo);
+  issue_part<false, 1>(c, t + 2, S);              // phase 2: (A1, B1)
+  read_a_half<1, S>(c, ahi, alo);
+  end_load_section<12>();
+  mfma_section<1, 1>(acc, ahi, alo, bhi, blo);
+  issue_part<true, 1>(c, t + 2, S);               // phase 3: (A1, B0)
+  read_b_half<0, S>(c, bhi, blo);
+  if (do_cs) colsum_frags<1>(cs, ahi, alo);
+  end_load_section<6>();
+  mfma_section<1, 0>(acc, ahi, alo, bhi, blo);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmParams g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // work units in split-major order, cut into 8 contiguous chunks (one per XCD): the tiles of one K range -- which share its A
+  // and B panels -- run on one XCD's L2
+  const int tiles = g.tiles_m * g.tiles_n;
+  const int unit = xcd_chunk_index(tiles * g.splits, blockIdx.x);
+  const int split = unit / tiles, tile = unit - split * tiles;
+  const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int total_steps = (g.K + BK - 1) / BK;
+  const int t0 = split * g.k_tiles_per_split;
+
+  Ctx c;
+  c.smem = smem;
+  c.wave = wave;
+  c.nt = min(g.k_tiles_per_split, total_steps - t0);
+  c.a_hi = uniform_rsrc(g.A, g.a_bytes);
+  c.a_lo = uniform_rsrc((const char*)g.A + g.a_lo_off, g.a_bytes);
+  c.b_hi = uniform_rsrc(g.B, g.b_bytes);
+  c.b_lo = uniform_rsrc((const char*)g.B + g.b_lo_off, g.b_bytes);
+  c.kstep_a = (uint32_t)g.lda * 2u * BK;
+  c.kstep_b = (uint32_t)g.ldb * 2u * BK;
+  {
+    // this wave's 1-KiB piece of a part = k-rows wave*4 .. +4; lane l fills unit slot (l & 15) of k-row (l >> 4), which holds
+    // source unit (l & 15) ^ swz_tr16(k-row) = 8 consecutive m (n) of the part
+    const int kl = wave * 4 + (lane >> 4);
+    const int pu = ((lane & 15) ^ swz_tr16(kl)) * 8;          // part-local index of the unit's first element
+    const uint64_t krow = (uint64_t)t0 * BK + (uint64_t)kl;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int am = m0 + (pu >> 6) * 128 + h * 64 + (pu & 63);   // part A(h): rows wr*128 + h*64 + [0, 64) of both wr
+      const int bn = n0 + (pu >> 5) * 64 + h * 32 + (pu & 31);    // part B(h): cols wc*64 + h*32 + [0, 32) of all wc
+      const uint64_t oa = (krow * (uint64_t)g.lda + (uint64_t)am) * 2u;
+      const uint64_t ob = (krow * (uint64_t)g.ldb + (uint64_t)bn) * 2u;
+      // units past the row's end would read the next k-row's first columns: they only feed output rows / columns >= M / N, which
+      // the epilogue masks -- but a unit that STRADDLES lda cannot exist (lda % 8 == 0)
+      c.voff_a[h] = (am < g.lda && oa < (uint64_t)OOB) ? (uint32_t)oa : OOB;
+      c.voff_b[h] = (bn < g.ldb && ob < (uint64_t)OOB) ? (uint32_t)ob : OOB;
+    }
+    // fragment bases (gemm.hip::read_frag, TR form): lane (g4, q, p) reads 8 B at k-row 8*g4 + q, unit (rbase >> 3) + (p >> 1)
+    const int i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, g4 = lane >> 4;
+    const int ka = 8 * g4 + q;
+    const int sx = swz_tr16(ka);                               // == swz_tr16(ka + 4)
+    const uint32_t sm = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const uint32_t rowb = (uint32_t)(ka * 256 + 8 * (pp & 1));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.rd_a[i] = sm + rowb + (uint32_t)((((wr * 8 + 2 * i + (pp >> 1)) ^ sx)) * 16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) c.rd_b[j] = sm + REGION + rowb + (uint32_t)((((wc * 4 + 2 * j + (pp >> 1)) ^ sx)) * 16);
+  }
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: everything of K steps 0 and 1 except B0(1), in the steady-state issue order
+  issue_part<true, 0>(c, 0, 0);
+  issue_part<false, 1>(c, 0, 0);
+  issue_part<true, 1>(c, 0, 0);
+  issue_part<false, 0>(c, 0, 0);
+  issue_part<true, 0>(c, 1, 1);
+  issue_part<false, 1>(c, 1, 1);
+  issue_part<true, 1>(c, 1, 1);
+  g256::end_load_section<6>();
+  if (wr == 1) {                                // waves 4-7 run one section behind waves 0-3
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // Column sums of A (g.epi.colsum_partial): every K step of an A row panel is seen by the tiles_n workgroups of that panel's tile
+  // row; global step tau is summed by the one with tn == tau % tiles_n, in its wc == 0 waves (waves of one wr hold the same A
+  // fragments).  Every workgroup writes its [256] slice of partial row (split * tiles_n + tn): nothing to zero beforehand.
+  float cs[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) cs[i] = 0.f;
+  const bool cs_wave = g.epi.colsum_partial != nullptr && wc == 0;
+  int cs_phase = (t0 + g.tiles_n - tn) % g.tiles_n;      // (global step - tn) mod tiles_n of local step 0
+  for (int t = 0; t < c.nt; t += 2) {
+    k_step<0>(c, t, acc, cs, cs_wave && cs_phase == 0);
+    cs_phase = cs_phase + 1 == g.tiles_n ? 0 : cs_phase + 1;
+    if (t + 1 < c.nt) k_step<1>(c, t + 1, acc, cs, cs_wave && cs_phase == 0);
+    cs_phase = cs_phase + 1 == g.tiles_n ? 0 : cs_phase + 1;
+  }
+  if (wr == 0) {                                // same number of barriers for every wave
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range tail refills have landed: LDS is reusable
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  if (cs_wave) {
+    float* dst = g.epi.colsum_partial + (size_t)(split * g.tiles_n + tn) * (size_t)g.M;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = cs[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + (lane & 15);
+      if (lane < 16 && m < g.M) dst[m] = v;
+    }
+  }
+  float* slab = reinterpret_cast<float*>(smem) + wave * (32 * (64 + 4));
+  float* partial = g.partial ? g.partial + (size_t)split * (size_t)g.M * (size_t)g.N : nullptr;
+  epilogue_wave<128, 64, 8, 4, 1>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, partial);
+}
+
+}  // namespace g256t
+
+// Host entry: planes x planes, TN, passes == 3, plain epilogue (alpha / accumulate-free store or split-K slabs); the caller runs the
+// split-K reducer.  p.k_tiles_per_split is in units of 32 rows.
+int launch_gemm256_tn(const GemmParams& p_in, int splits, hipStream_t stream) {
+  using namespace g256t;
+  GemmParams p = p_in;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.splits = splits;
+  if (splits <= 1) p.partial = nullptr;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (lr2_allow_dynamic_lds(gemm256_tn_kernel, LDS_BYTES, "gemm256_tn")) return LR2_ERR_LAUNCH;
+    attr_set = true;
+  }
+  LR2_LAUNCH(gemm256_tn_kernel, dim3(p.tiles_m * p.tiles_n * splits), dim3(512), LDS_BYTES, stream, p);
+  return lr2_launch_status(__func__);
+}
+
 // Host entry for gemm.hip's dispatcher.  Requirements (checked by the caller): planes x planes, NT, passes == 3,
 // K % 32 == 0, no split-K, operand extents < 4 GiB - 512 B.
 int launch_gemm256_nt(const GemmParams& p_in, hipStream_t stream) {

@@ -198,11 +198,15 @@ def linear_dgrad(ws, dy, w, out, M, N_in, N_out, *, w_f32: Optional[torch.Tensor
 
 
 def linear_wgrad(ws, dy, x, dw, db, M, N_in, N_out):
-    """dw[N_out,N_in] = dy[M,N_out]^T @ x[M,N_in];  db[N_out] = colsum(dy)."""
+    """dw[N_out,N_in] = dy[M,N_out]^T @ x[M,N_in];  db[N_out] = colsum(dy).  At thousands of token rows the product runs on the TN
+    form of the 256 x 256 kernel (ops.choose_tiling) and the bias gradient comes out of the same launch -- the column sums of
+    the dy fragments it stages anyway -- instead of a second pass over dy."""
     skw, sp, bm = _splitk_ws(ws, N_out, N_in, M, trans_a=True, trans_b=True)
+    fused = db is not None and bm == 256 and isinstance(dy, Planes) and isinstance(x, Planes) and N_out % 4 == 0
+    cs_ws = ws.vec("colsum_gemm", max(128, sp * ((N_in + 255) // 256)) * N_out) if fused else None
     ops.gemm(dy, x, dw, N_out, N_in, M, trans_a=True, trans_b=True, lda=N_out, ldb=N_in, splitk_ws=skw, splits=sp,
-             block_m=bm)
-    if db is not None:
+             block_m=bm, colsum=db if fused else None, colsum_ws=cs_ws)
+    if db is not None and not fused:
         nb = min(512 if N_out <= 1024 else 256, M)     # row chunks: enough workgroups to fill 256 CUs at 1024 columns each
         ops.colsum(dy, db, ws.vec("colsum_partials", nb * N_out), rows=M, cols=N_out, nblocks=nb)
 

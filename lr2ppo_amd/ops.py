@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import os
 from typing import Optional
 
 import torch
@@ -235,12 +236,30 @@ def _use_gemm256(M: int, N: int, K: int, passes: int) -> bool:
 
 
 @functools.lru_cache(maxsize=4096)
+def _gemm256_tn_splits(M: int, N: int, K: int, passes: int) -> int:
+    """K-split count when the TN product C[M, N] = A[K, M]^T B[K, N] of planes should run on the TN form of the 256 x 256 kernel
+    (csrc/gemm256.hip::gemm256_tn_kernel), else 0.  Weight gradients at thousands of token rows: few output tiles (768 x 3072 =
+    36), a long contraction; tiles x splits fill ONE round of the 256 CUs, each workgroup runs >= 16 K steps of 32 rows."""
+    if passes != 3 or K < 4096 or os.environ.get("LR2_GEMM_256_TN", "1") == "0":
+        return 0
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if tiles > 128 or M * N < 0.85 * tiles * 65536:
+        return 0
+    steps = (K + 31) // 32
+    return max(1, min(256 // tiles, steps // 16))
+
+
+@functools.lru_cache(maxsize=4096)
 def choose_tiling(M: int, N: int, K: int, trans_a: bool, trans_b: bool = False):
     """(block_m, splits).  256 CUs hold 2 (BM=128) or 3 (BM=64) workgroups each; pick the split-K factor that minimises
     rounds x (K-tiles per workgroup + fixed prologue/epilogue cost) + the cost of writing/reading the partial slabs, so
     that skinny GEMMs fill the chip without wave-quantisation tails (576 workgroups on 512 slots = 2 rounds)."""
     if not trans_a and not trans_b and use_gemm256(M, N, K):
         return 256, 1        # honoured for planes x planes operands only (lr2_gemm falls back to 128-row tiles otherwise)
+    if trans_a and trans_b:
+        sp256 = _gemm256_tn_splits(M, N, K, _PASSES)
+        if sp256:
+            return 256, sp256    # planes x planes only, as above
     bm = 64 if (M <= 64 and not trans_a) else 128
     tiles = ((M + bm - 1) // bm) * ((N + 127) // 128)
     if bm == 128 and not trans_a and not trans_b and tiles < 1536:
@@ -284,7 +303,8 @@ def gemm(a, b, out: Optional[torch.Tensor], M: int, N: int, K: int, *, trans_a=F
          aux_z: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, drop: Optional[Drop] = None,
          accumulate: bool = False, alpha: float = 1.0, out_planes: Optional[Planes] = None,
          splitk_ws: Optional[torch.Tensor] = None, splits: Optional[int] = None, block_m: Optional[int] = None,
-         passes: Optional[int] = None, adam: Optional[AdamArgs] = None):
+         passes: Optional[int] = None, adam: Optional[AdamArgs] = None, colsum: Optional[torch.Tensor] = None,
+         colsum_ws: Optional[torch.Tensor] = None):
     """out[M,N] = op(a) @ op(b) with the fused epilogue; a / b are fp32 tensors or Planes; the result goes to `out`
     (fp32) and/or `out_planes`, or -- with `adam` -- straight into the AdamW update of adam.p[M,N].
     See lr2_gemm in include/lr2ppo_hip.h."""
@@ -320,6 +340,13 @@ def gemm(a, b, out: Optional[torch.Tensor], M: int, N: int, K: int, *, trans_a=F
         e.adam_p, e.adam_m, e.adam_v = adam.p.data_ptr(), adam.m.data_ptr(), adam.v.data_ptr()
         e.adam_lr, e.adam_beta1, e.adam_beta2 = adam.lr, adam.beta1, adam.beta2
         e.adam_eps, e.adam_weight_decay = adam.eps, adam.weight_decay
+    if colsum is not None:
+        # weight-gradient form: colsum[m] = sum_k A[k, m] (the bias gradient) from the same launch (lr2_epilogue.colsum)
+        _chk_f32(colsum, colsum_ws)
+        if not (trans_a and trans_b) or colsum.numel() != M or colsum_ws is None \
+                or colsum_ws.numel() < max(128, sp * ((N + 255) // 256)) * M:
+            raise ValueError("gemm(colsum=...): TN form only; colsum [M], colsum_ws >= max(128, splits * ceil(N / 256)) * M floats")
+        e.colsum, e.colsum_ws = colsum.data_ptr(), colsum_ws.data_ptr()
     a_bytes = a.plane_bytes() if a_pl else a.numel() * 4
     b_bytes = b.plane_bytes() if b_pl else b.numel() * 4
     args = (a.data_ptr(), b.data_ptr(), M, N, K, lda, ldb, 1 if trans_a else 0, 1 if trans_b else 0, a_bytes, b_bytes,

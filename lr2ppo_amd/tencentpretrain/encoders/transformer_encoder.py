@@ -52,7 +52,7 @@ class TransformerEncoder(nn.Module):
             att, ffn = layer.self_attn, layer.feed_forward
             wqkv = torch.cat([att.linear_layers[i].weight.data for i in range(3)], dim=0).contiguous()
             bqkv = torch.cat([att.linear_layers[i].bias.data for i in range(3)], dim=0).contiguous()
-            ent = {"bqkv": bqkv}
+            ent = {"bqkv": bqkv, "wqkv_f32": wqkv}      # the fp32 concatenation: large-M input gradients transpose it (engine.linear_dgrad)
             for name, w in (("wqkv", wqkv), ("wo", att.final_linear.weight.data), ("w1", ffn.linear_1.weight.data),
                             ("w2", ffn.linear_2.weight.data)):
                 pl = ops.Planes.empty(w.shape[0], w.shape[1], dev)
@@ -344,11 +344,11 @@ class TransformerEncoder(nn.Module):
             flip ^= 1
             if pre:
                 d_x1 = mat("d_x1", M, E)
-                engine.linear_dgrad(ws, dqkv_p, w["wqkv"], d_x1, M, E, 3 * E)
+                engine.linear_dgrad(ws, dqkv_p, w["wqkv"], d_x1, M, E, 3 * E, w_f32=w["wqkv_f32"])
                 ops.layernorm_bwd(d_x1, S["h_in"], ln1.gamma.data, S["m1"], S["r1"], dprev, partials, G[ln1.gamma], G[ln1.beta],
                                   rows=M, D=E, resid_grad=d_t1, mode=1, eps=ln1.eps)
             else:
-                engine.linear_dgrad(ws, dqkv_p, w["wqkv"], dprev, M, E, 3 * E, resid=d_t1)
+                engine.linear_dgrad(ws, dqkv_p, w["wqkv"], dprev, M, E, 3 * E, resid=d_t1, w_f32=w["wqkv_f32"])
             dh = dprev
             saved["layers"][i] = None                                   # release this layer's activations
         return dh.view(B, L, E), G

@@ -326,3 +326,14 @@ def test_no_kernel_in_the_library_spills_registers(native):
            if (k["vgpr_spill"] > 0 or k["scratch"] > 0) and not any(k["name"].startswith(a) for a in kr.ALLOWED_SCRATCH)]
     assert not bad, bad
     assert all(k["vgpr"] <= 512 for k in ks)                   # .vgpr_count = architectural + accumulation registers
+
+
+def test_wgrad_tiling_picks_the_tn256_kernel_for_long_contractions():
+    """Host logic (no launch): weight gradients of the encoders / heads at >= 4096 token rows go to the TN 256 kernel with
+    tiles x splits in one round of the chip; short contractions and the 2 GB out_layer.fc1 matrix do not."""
+    from lr2ppo_amd import ops
+    for (M, N, K), want in (((768, 3072, 100864), (256, 7)), ((3072, 768, 100864), (256, 7)), ((2304, 768, 100864), (256, 9)),
+                            ((768, 768, 100352), (256, 28)), ((768, 3072, 12544), (256, 7))):
+        assert ops.choose_tiling(M, N, K, True, True) == want, (M, N, K)
+    assert ops.choose_tiling(3072, 162816, 64, True, True)[0] != 256
+    assert ops.choose_tiling(768, 3072, 2048, True, True)[0] != 256

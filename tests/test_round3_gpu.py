@@ -339,3 +339,97 @@ def test_ndcg_flags_items_it_cannot_rank(dev):
     for i in (0, 2):
         s, g = scores[offsets[i]:offsets[i + 1]], gold[offsets[i]:offsets[i + 1]]
         assert torch.allclose(out[i], O.ndcg_vector(s, g), atol=1e-6)
+
+
+# ---- TN form of the 256 x 256 kernel (csrc/gemm256.hip::gemm256_tn_kernel): weight gradients at thousands of token rows ----------
+def _planes(ops, x, dev):
+    return ops.split_planes(x.to(dev).contiguous(), ops.Planes.empty(x.shape[0], x.shape[1], dev))
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(256, 256, 32, 1), (256, 256, 64, 1), (256, 512, 100, 1), (768, 768, 4100, 3),
+                                          (296, 520, 4128, 2), (768, 3072, 12544, 7), (2304, 768, 6304, 9), (512, 256, 8200, 32)])
+def test_gemm256_tn_matches_fp64(dev, M, N, K, splits):
+    """C = A^T B with A [K, M], B [K, N] planes: one and two K steps, a ragged last K step (K % 32 != 0: rows past K are zero-filled
+    by the descriptor's range check), ragged M / N tiles, split counts that do and do not divide the K steps, the production
+    shapes (RoBERTa-base FFN / QKV weight gradients at 64 x 196 and 32 x 197 token rows) -- against fp64 and against the general
+    TN kernel (same split-bf16 arithmetic, different summation order)."""
+    import math
+    from lr2ppo_amd import ops
+    from test_kernels_gpu import _close
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    a, b = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g)
+    ref = a.double().t() @ b.double()
+    ap, bp = _planes(ops, a, dev), _planes(ops, b, dev)
+    out = torch.full((M, N), float("nan"), device=dev)
+    ws = torch.empty(splits * M * N, device=dev) if splits > 1 else None
+    ops.gemm(ap, bp, out, M, N, K, trans_a=True, trans_b=True, lda=M, ldb=N, block_m=256, splits=splits, splitk_ws=ws)
+    _close(out, ref, atol=6e-5 * math.sqrt(K), rtol=5e-5, what="gemm256 TN")
+    out128 = torch.empty((M, N), device=dev)
+    ws1 = torch.empty(4 * M * N, device=dev)
+    ops.gemm(ap, bp, out128, M, N, K, trans_a=True, trans_b=True, lda=M, ldb=N, block_m=128, splits=4 if K >= 1024 else 1, splitk_ws=ws1)
+    _close(out, out128.double().cpu(), atol=2e-5 * math.sqrt(K), rtol=2e-5, what="gemm256 TN vs general kernel")
+
+
+def test_gemm256_tn_exact_on_integers_and_epilogues(dev):
+    """Small-integer operands: every product and sum is exact, so the part / wave / quadrant / transposed-fragment index maps are
+    checked bit for bit with asymmetric operands; then alpha + accumulate through the kernel's own epilogue (one split) and
+    through the reducer (several splits)."""
+    from lr2ppo_amd import ops
+    M, N, K = 512, 768, 160
+    g = torch.Generator().manual_seed(4)
+    a = torch.randint(-3, 4, (K, M), generator=g).float() + torch.arange(M).float().view(1, -1) % 5
+    b = torch.randint(-3, 4, (K, N), generator=g).float() + (torch.arange(N).float().view(1, -1) % 7) * 2
+    ref = (a.double().t() @ b.double()).float()
+    ap, bp = _planes(ops, a, dev), _planes(ops, b, dev)
+    for splits in (1, 2, 5):
+        out = torch.empty(M, N, device=dev)
+        ws = torch.empty(splits * M * N, device=dev)
+        ops.gemm(ap, bp, out, M, N, K, trans_a=True, trans_b=True, lda=M, ldb=N, block_m=256, splits=splits, splitk_ws=ws)
+        assert torch.equal(out.cpu(), ref), splits
+        base = torch.randint(-5, 6, (M, N), generator=g).float()
+        acc = base.to(dev).clone()
+        ops.gemm(ap, bp, acc, M, N, K, trans_a=True, trans_b=True, lda=M, ldb=N, block_m=256, splits=splits, splitk_ws=ws,
+                 accumulate=True, alpha=0.5)
+        assert torch.equal(acc.cpu(), base + 0.5 * ref), splits
+
+
+@pytest.mark.parametrize("M,N,K,splits,bm", [(768, 3072, 12544, 7, 256), (296, 520, 4128, 2, 256), (256, 256, 64, 1, 256),
+                                             (2304, 768, 6304, 9, 256), (768, 768, 4100, 3, 128)])
+def test_wgrad_gemm_returns_the_bias_gradient_too(dev, M, N, K, splits, bm):
+    """lr2_epilogue.colsum: the column sums of A (db = sum of dY rows) from the weight-gradient launch -- accumulated from the staged
+    fragments on the TN 256 kernel (every K step counted exactly once across the workgroups of a tile row and across splits, ragged
+    M, ragged K), by a column-sum pass behind the product on the general kernel."""
+    import math
+    from lr2ppo_amd import ops
+    from test_kernels_gpu import _close
+    g = torch.Generator().manual_seed(5 * M + N + K)
+    a, b = torch.randn(K, M, generator=g) + 0.3, torch.randn(K, N, generator=g)
+    ap, bp = _planes(ops, a, dev), _planes(ops, b, dev)
+    out, db = torch.empty(M, N, device=dev), torch.full((M,), float("nan"), device=dev)
+    ws = torch.empty(max(splits, 4) * M * N, device=dev)
+    cs_ws = torch.empty(max(128, splits * ((N + 255) // 256)) * M, device=dev)
+    ops.gemm(ap, bp, out, M, N, K, trans_a=True, trans_b=True, lda=M, ldb=N, block_m=bm, splits=splits, splitk_ws=ws, colsum=db,
+             colsum_ws=cs_ws)
+    _close(out, a.double().t() @ b.double(), atol=6e-5 * math.sqrt(K), rtol=5e-5, what="dW")
+    _close(db, ap.to_float().double().sum(0).cpu(), atol=2e-5 * math.sqrt(K), rtol=2e-5, what="db")
+
+
+def test_linear_wgrad_fused_bias_gradient_equals_the_separate_pass(dev):
+    """engine.linear_wgrad at 12 544 token rows (TN 256 kernel + fused column sums) against the same call forced onto the general
+    kernel + colsum pass (LR2_GEMM_256_TN=0 changes the host's tiling choice; the cache is keyed by it through a fresh call)."""
+    from lr2ppo_amd import engine, ops
+    from test_kernels_gpu import _close
+    g = torch.Generator().manual_seed(12)
+    Mtok, Nin, Nout = 12544, 768, 3072
+    dy, x = torch.randn(Mtok, Nout, generator=g) * 0.1 + 0.01, torch.randn(Mtok, Nin, generator=g)
+    dyp, xp = _planes(ops, dy, dev), _planes(ops, x, dev)
+    ws = engine.Workspace(dev)
+    assert ops.choose_tiling(Nout, Nin, Mtok, True, True)[0] == 256
+    dw, db = torch.empty(Nout, Nin, device=dev), torch.empty(Nout, device=dev)
+    engine.linear_wgrad(ws, dyp, xp, dw, db, Mtok, Nin, Nout)
+    dw0, db0 = torch.empty(Nout, Nin, device=dev), torch.empty(Nout, device=dev)
+    skw = ws.vec("splitk_ref", 4 * Nout * Nin)
+    ops.gemm(dyp, xp, dw0, Nout, Nin, Mtok, trans_a=True, trans_b=True, lda=Nout, ldb=Nin, splitk_ws=skw, splits=4, block_m=128)
+    ops.colsum(dyp, db0, ws.vec("cs_ref", 256 * Nout), rows=Mtok, cols=Nout, nblocks=256)
+    _close(dw, dw0.double().cpu(), atol=3e-3, rtol=2e-5, what="dW")
+    _close(db, db0.double().cpu(), atol=3e-3, rtol=2e-5, what="db")
