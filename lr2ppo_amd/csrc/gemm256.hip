@@ -349,16 +349,20 @@ __device__ __forceinline__ float frag_sum(const bf16x8_t& f) {
   for (int d = 0; d < 4; ++d) s += __uint_as_float(w[d] << 16) + __uint_as_float(w[d] & 0xffff0000u);
   return s;
 }
+// The four waves of one wr hold the same A fragments: wave wc sums tile wc of each half (a quarter of the vector work each, in
+// parallel on the four SIMDs).  wc is wave-uniform: a branch per case keeps the fragment index a compile-time constant.
 template <int AH>
-__device__ __forceinline__ void colsum_frags(float (&cs)[8], const bf16x8_t (&ahi)[4], const bf16x8_t (&alo)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) cs[AH * 4 + i] += frag_sum(ahi[i]) + frag_sum(alo[i]);
+__device__ __forceinline__ void colsum_frags(float (&cs)[2], int wc, const bf16x8_t (&ahi)[4], const bf16x8_t (&alo)[4]) {
+  if (wc == 0) cs[AH] += frag_sum(ahi[0]) + frag_sum(alo[0]);
+  else if (wc == 1) cs[AH] += frag_sum(ahi[1]) + frag_sum(alo[1]);
+  else if (wc == 2) cs[AH] += frag_sum(ahi[2]) + frag_sum(alo[2]);
+  else cs[AH] += frag_sum(ahi[3]) + frag_sum(alo[3]);
 }
 
 // One K step; the section / refill / counted-wait schedule of g256::k_step<S, 0>.  do_cs (wave-uniform): this wave adds the K
 // step's A fragments to its column sums (after the MFMAs of the phase were issued: the vector work runs under the matrix pipe).
 template <int S>
-__device__ __forceinline__ void k_step(const Ctx& c, int t, f32x4_t (&acc)[8][4], float (&cs)[8], bool do_cs) {
+__device__ __forceinline__ void k_step(const Ctx& c, int t, f32x4_t (&acc)[8][4], float (&cs)[2], int wc, bool do_cs) {
   using g256::end_load_section;
   using g256::mfma_section;
   bf16x8_t ahi[4], alo[4], bhi[2], blo[2];
@@ -369,7 +373,7 @@ __device__ __forceinline__ void k_step(const Ctx& c, int t, f32x4_t (&acc)[8][4]
   mfma_section<0, 0>(acc, ahi, alo, bhi, blo);
   issue_part<true, 0>(c, t + 2, S);               // phase 1: (A0, B1)
   read_b_half<1, S>(c, bhi, blo);
-  if (do_cs) colsum_frags<0>(cs, ahi, alo);
+  if (do_cs) colsum_frags<0>(cs, wc, ahi, alo);
   end_load_section<12>();
   mfma_section<0, 1>(acc, ahi, alo, bhi, blo);
   issue_part<false, 1>(c, t + 2, S);              // phase 2: (A1, B1)
@@ -378,7 +382,7 @@ __device__ __forceinline__ void k_step(const Ctx& c, int t, f32x4_t (&acc)[8][4]
   mfma_section<1, 1>(acc, ahi, alo, bhi, blo);
   issue_part<true, 1>(c, t + 2, S);               // phase 3: (A1, B0)
   read_b_half<0, S>(c, bhi, blo);
-  if (do_cs) colsum_frags<1>(cs, ahi, alo);
+  if (do_cs) colsum_frags<1>(cs, wc, ahi, alo);
   end_load_section<6>();
   mfma_section<1, 0>(acc, ahi, alo, bhi, blo);
 }
@@ -459,17 +463,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmParams g) {
     __builtin_amdgcn_sched_barrier(0);
   }
   // Column sums of A (g.epi.colsum_partial): every K step of an A row panel is seen by the tiles_n workgroups of that panel's tile
-  // row; global step tau is summed by the one with tn == tau % tiles_n, in its wc == 0 waves (waves of one wr hold the same A
-  // fragments).  Every workgroup writes its [256] slice of partial row (split * tiles_n + tn): nothing to zero beforehand.
-  float cs[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) cs[i] = 0.f;
-  const bool cs_wave = g.epi.colsum_partial != nullptr && wc == 0;
+  // row; global step tau is summed by the one with tn == tau % tiles_n, wave (wr, wc) taking m-tile wc of each half of its wr
+  // rows.  Every workgroup writes its [256] slice of partial row (split * tiles_n + tn): nothing to zero beforehand.
+  float cs[2] = {0.f, 0.f};
+  const bool cs_on = g.epi.colsum_partial != nullptr;
   int cs_phase = (t0 + g.tiles_n - tn) % g.tiles_n;      // (global step - tn) mod tiles_n of local step 0
   for (int t = 0; t < c.nt; t += 2) {
-    k_step<0>(c, t, acc, cs, cs_wave && cs_phase == 0);
+    k_step<0>(c, t, acc, cs, wc, cs_on && cs_phase == 0);
     cs_phase = cs_phase + 1 == g.tiles_n ? 0 : cs_phase + 1;
-    if (t + 1 < c.nt) k_step<1>(c, t + 1, acc, cs, cs_wave && cs_phase == 0);
+    if (t + 1 < c.nt) k_step<1>(c, t + 1, acc, cs, wc, cs_on && cs_phase == 0);
     cs_phase = cs_phase + 1 == g.tiles_n ? 0 : cs_phase + 1;
   }
   if (wr == 0) {                                // same number of barriers for every wave
@@ -480,14 +482,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmParams g) {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
-  if (cs_wave) {
+  if (cs_on) {
     float* dst = g.epi.colsum_partial + (size_t)(split * g.tiles_n + tn) * (size_t)g.M;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float v = cs[i];
+    for (int h = 0; h < 2; ++h) {
+      float v = cs[h];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
-      const int m = m0 + wr * 128 + (i >> 2) * 64 + (i & 3) * 16 + (lane & 15);
+      const int m = m0 + wr * 128 + h * 64 + wc * 16 + (lane & 15);
       if (lane < 16 && m < g.M) dst[m] = v;
     }
   }
