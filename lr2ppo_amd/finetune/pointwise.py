@@ -200,7 +200,7 @@ def evaluate(args, model, dataloader, step, split="test", num_tasks=None):
 def get_dataloader(args, dataset, num_tasks, global_rank, is_train=False):
     """finetune/pointwise.py:415-430: train batches of args.batch_size, validation one item at a time."""
     sampler = DistributedSampler(dataset, num_replicas=num_tasks, rank=global_rank, shuffle=is_train)
-    workers = getattr(args, "num_workers", 32 if not isinstance(dataset, SyntheticMovieNet) else 2)
+    workers = getattr(args, "num_workers", 32 if isinstance(dataset, MovieNet) else 2)        # synthetic sets: 2 workers
     return DataLoader(dataset=dataset, batch_size=args.batch_size if is_train else 1, sampler=sampler,
                       num_workers=workers, drop_last=False)
 
@@ -226,7 +226,97 @@ def build_parser():
     parser.add_argument("--synthetic_items", type=int, default=0, help="use SyntheticMovieNet with this many train items")
     parser.add_argument("--synthetic_val_items", type=int, default=16)
     parser.add_argument("--max_steps", type=int, default=0, help="stop after this many training steps (0 = run all epochs)")
+    # the composed model (encoder(embedding(src, seg), seg) -> head: tencentpretrain/models/model.py:32-41 upstream).  The reference's
+    # launcher already carries --pretrained_model_path / --vit_pretrained_model_path for the RoBERTa and ViT checkpoints but loads them
+    # into a module that holds only the head (pointwise.py:239-271); with --raw_inputs they load into the two encoder stacks that run
+    # in front of it, and --finetune_encoders trains those stacks from the head's loss.
+    parser.add_argument("--raw_inputs", action="store_true",
+                        help="items are raw (uint8 frames, tag token ids, seg): features come from ViT-B/16 + RoBERTa-base in line")
+    parser.add_argument("--finetune_encoders", action="store_true",
+                        help="with --raw_inputs: train both encoder stacks end to end (AdamW, the head's schedule) instead of freezing them")
+    parser.add_argument("--encoder_layers", type=int, default=0, help="override layers_num of both encoder configs (0 = the shipped 12)")
     return parser
+
+
+class SyntheticRawMovieNet(Dataset):
+    """Seeded raw stand-in for an LRMovieNet item: uint8 frames [max_imgs, 3, 224, 224], tag token ids [tags, 196]
+    uniform in [5, vocab), seg = 1 on the first len ~ U{4..196} tokens, targets in {0, 1, 2}."""
+
+    def __init__(self, n_items, tags, max_imgs=16, seed=7):
+        self.n, self.tags, self.max_imgs, self.seed = n_items, tags, max_imgs, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        from .features import synthetic_raw_batch
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        frames, ids, seg, tgts = synthetic_raw_batch(1, self.tags, n_img=self.max_imgs, generator=g)
+        return frames[0], ids[0], seg[0], tgts[0]
+
+
+def _run_raw(args, model, num_tasks, global_rank):
+    """The training loop of main() on raw items: FeatureExtractor in front of the head, frozen (features extracted in line, then
+    train_model) or fine-tuned (features.finetune_pointwise_step); validation extracts in line and calls evaluate()."""
+    from .features import (TEXT_CONFIG, VIT_CONFIG, FeatureExtractor, build_encoder_optimizer, encoder_args,
+                           finetune_pointwise_step)
+    over = {"layers_num": args.encoder_layers} if args.encoder_layers else {}
+    fx = FeatureExtractor(encoder_args(VIT_CONFIG, **over), encoder_args(TEXT_CONFIG, **over))
+    if args.pretrained_model_path or args.vit_pretrained_model_path:
+        if not (args.pretrained_model_path and args.vit_pretrained_model_path):
+            raise ValueError("--raw_inputs: give both --pretrained_model_path (RoBERTa) and --vit_pretrained_model_path, or neither")
+        fx.load_pretrained(args.vit_pretrained_model_path, args.pretrained_model_path)
+    else:
+        fx.init_normal()
+    fx = fx.to(args.device)
+    if num_tasks > 1:
+        for p in fx.parameters():
+            dist.broadcast(p.data, src=0)
+    if args.synthetic_items <= 0:
+        raise RuntimeError("--raw_inputs: the repository holds no raw LRMovieNet reader (the reference reads pre-extracted features, "
+                           "finetune/pointwise.py:77-167); use --synthetic_items N")
+    trainset = SyntheticRawMovieNet(args.synthetic_items, args.max_tags, args.max_imgs, args.seed)
+    valset = SyntheticRawMovieNet(args.synthetic_val_items, 20, args.max_imgs, args.seed + 1)
+    train_loader = get_dataloader(args, trainset, num_tasks, global_rank, is_train=True)
+    val_loader = get_dataloader(args, valset, num_tasks, global_rank, is_train=False)
+    args.train_steps = int(len(trainset) * args.epochs_num / args.batch_size) + 1
+    optimizer, scheduler = build_optimizer(args, model)
+    enc_opt, enc_sch = build_encoder_optimizer(args, fx) if args.finetune_encoders else (None, None)
+    args.model = model
+
+    class _Features:                       # validation loader of (text_emb, img_emb, tgts) from the raw one
+        def __iter__(self_):
+            for frames, ids, seg, tgts in val_loader:
+                t, i = fx.extract(frames.to(args.device), ids.to(args.device), seg.to(args.device))
+                yield t, i, tgts
+
+    best, step, total_loss = 0.0, 0, 0.0
+    for epoch in range(1, args.epochs_num + 1):
+        train_loader.sampler.set_epoch(epoch)
+        for i, (frames, ids, seg, tgts) in enumerate(train_loader):
+            frames, ids, seg, tgts = (t.to(args.device) for t in (frames, ids, seg, tgts))
+            model.train()
+            if args.finetune_encoders:
+                fx.train()
+                loss = finetune_pointwise_step(args, fx, model, optimizer, scheduler, enc_opt, enc_sch, frames, ids, seg, tgts)
+            else:
+                text_emb, img_emb = fx.extract(frames, ids, seg)
+                loss = train_model(args, model, optimizer, scheduler, text_emb, img_emb, tgts)
+            if num_tasks > 1:
+                dist.all_reduce(loss.div_(num_tasks))
+            total_loss += loss.item()
+            step += 1
+            if (i + 1) % args.report_steps == 0 or (args.max_steps and step >= args.max_steps):
+                if args.is_master:
+                    args.logger.info("Epoch id: {}, Training steps: {}, Avg loss: {:.3f}".format(epoch, i + 1, total_loss / args.report_steps))
+                total_loss = 0.0
+                result, _ = evaluate(args, model, _Features(), step, split="val", num_tasks=num_tasks)
+                if args.is_master and result.item() > best:
+                    best = result.item()
+                    save_model(model, args.output_model_path)
+            if args.max_steps and step >= args.max_steps:
+                return best
+    return best
 
 
 def main(argv=None):
@@ -252,6 +342,8 @@ def main(argv=None):
     if num_tasks > 1:
         for p in model.parameters():
             dist.broadcast(p.data, src=0)
+    if args.raw_inputs:
+        return _run_raw(args, model, num_tasks, global_rank)
     if args.synthetic_items > 0:
         trainset = SyntheticMovieNet(args.synthetic_items, args.max_tags, args.max_imgs, args.seed)
         valset = SyntheticMovieNet(args.synthetic_val_items, 20, args.max_imgs, args.seed + 1)

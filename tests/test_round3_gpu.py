@@ -433,3 +433,25 @@ def test_linear_wgrad_fused_bias_gradient_equals_the_separate_pass(dev):
     ops.colsum(dyp, db0, ws.vec("cs_ref", 256 * Nout), rows=Mtok, cols=Nout, nblocks=256)
     _close(dw, dw0.double().cpu(), atol=3e-3, rtol=2e-5, what="dW")
     _close(db, db0.double().cpu(), atol=3e-3, rtol=2e-5, what="db")
+
+
+def test_stage1_launcher_trains_the_composed_model_from_raw_inputs(dev, tmp_path):
+    """`python -m lr2ppo_amd.finetune.pointwise --raw_inputs --finetune_encoders`: the stage-1 entry point with ViT + RoBERTa stacks
+    (1 layer each here) in front of the head, trained end to end for two steps on synthetic raw items, validation through
+    evaluate(), best model saved -- the composed path is reachable from a main(), not only from library calls."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    cfg = tmp_path / "cfg.json"
+    cfg.write_text(json.dumps({"emb_size": 768, "hidden_size": 768}))
+    out = tmp_path / "stage1.bin"
+    cmd = [sys.executable, "-m", "lr2ppo_amd.finetune.pointwise", "--config_path", str(cfg), "--output_model_path", str(out),
+           "--raw_inputs", "--finetune_encoders", "--encoder_layers", "1", "--synthetic_items", "4", "--synthetic_val_items", "2",
+           "--batch_size", "2", "--max_tags", "2", "--max_imgs", "16", "--seq_length", "196", "--visual_feat_dim", "768",
+           "--epochs_num", "1", "--report_steps", "2", "--max_steps", "2", "--learning_rate", "1e-4", "--mode", "reg"]
+    r = subprocess.run(cmd, cwd=REPO, capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=REPO))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    log = r.stdout + r.stderr
+    assert "Avg loss" in log and "NDCG" in log, log[-3000:]
+    assert out.exists()
