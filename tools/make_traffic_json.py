@@ -31,10 +31,27 @@ for r in f:
     if r["bench_signature"]:
         by_label[r["bench_signature"]] = rec
     by_sig[f"{r['kernel']} [{r['workgroups']} x {r['workgroup_size']}]"] = rec
+# MFMA-busy of the value loop's GEMM signatures from the encoder PMC pass of the same call (SQ_VALU_MFMA_BUSY_CYCLES over
+# GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs; tools/mfma_busy_table.py prints the same numbers as a table)
+_mf = os.path.join(d, f"{tag}_encoder_pmc_mfma.json")
+if os.path.exists(_mf):
+    for r in json.load(open(_mf)):
+        if not r.get("bench_signature"):
+            continue
+        c = r["counters_sum"]
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if gui <= 0:
+            continue
+        rec = by_label.setdefault(r["bench_signature"], {})
+        rec["mfma_busy"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0), 4)
+        rec["effective_clock_ghz"] = round(gui / (r["total_ms"] * 1e-3) / 1e9, 3)
+        rec["pmc_launches"] = r["launches"]
 print(json.dumps({
     "_method": "tools/profile_round.sh " + tag + ": rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) on "
-               "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile`, summarised per dispatch signature by "
+               "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile` (head-only PPO steps), summarised per dispatch signature by "
                "tools/rocprof_summary.py; counters are KiB; read bytes = 2 x FETCH_SIZE (gfx950, 16-B/lane streaming reads), WRITE_SIZE as "
                "is.  kernel_trace_* come from the `--serial-streams` kernel-trace pass of the SAME gpurun call (same box, 13 PPO steps on one "
-               "HIP stream: exclusive per-launch durations).",
+               "HIP stream: exclusive per-launch durations).  mfma_busy / effective_clock_ghz: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 "
+               "x 1024 SIMDs) and (GRBM_GUI_ACTIVE / 8) / kernel time from the encoder PMC pass of the same call "
+               "(`tools/encoder_bench.py --ppo-shapes --iters 1` under --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES).",
     "by_bench_label": by_label, "by_dispatch_signature": by_sig}, indent=1))

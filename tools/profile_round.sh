@@ -4,7 +4,7 @@
 # counters.  Raw CSVs (kernel names run to kilobytes per row) are summarised per dispatch signature by tools/rocprof_summary.py
 # and removed; only the summaries are kept under gpurun_out/ (copy the ones to be judged into profiles/).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
@@ -19,11 +19,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- python3 $R/ben
 $S kernel-trace $O/kts --steps 13 --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online --serial-streams ($TAG; 13 PPO steps, one HIP stream)" --md $O/${TAG}_bench_kernel_trace_serial.md --json $O/${TAG}_bench_kernel_trace_serial.json || exit 1
 rm -rf $O/kts
 echo "== plain bench on the same box, right after the exclusive trace"
-python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_same_box.json 2> $O/bench.err
+python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/${TAG}_bench_same_box.json 2> $O/bench.err
 echo "== kernel trace of the bench, default two-stream schedule (overlapped durations: roofline.in_timed_region)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online > $O/bench_under_kernel_trace.json 2> $O/kt.err || exit 1
 $S kernel-trace $O/kt --steps 18 --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online ($TAG; 18 PPO steps: 13 on two streams, 5 on one)" --md $O/${TAG}_bench_kernel_trace.md --json $O/${TAG}_bench_kernel_trace.json || exit 1
 rm -rf $O/kt
+echo "== kernel trace of the VALUE loop (frames + ids -> ViT-B/16 + RoBERTa-base -> PPO step), one stream: head-only loop (2 + 3 + 8 steps) then the composed loop (2 + 8 steps)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktv -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --serial-streams > $O/${TAG}_bench_value_under_kernel_trace_serial.json 2> $O/ktv.err || exit 1
+$S kernel-trace $O/ktv --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --serial-streams ($TAG; 13 head-only PPO steps + 10 composed steps = 10 dual-encoder forwards + 10 PPO steps, one HIP stream)" --md $O/${TAG}_bench_value_kernel_trace_serial.md --json $O/${TAG}_bench_value_kernel_trace_serial.json || exit 1
+rm -rf $O/ktv
 echo "== FETCH_SIZE pass"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile > /dev/null 2> $O/fetch.err || exit 1
 $S pmc $O/fetch --title "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile ($TAG)" --md $O/${TAG}_bench_pmc_fetch.md --json $O/${TAG}_bench_pmc_fetch.json || exit 1
@@ -40,4 +44,9 @@ echo "== encoder forward: MFMA counters"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/enc_pmc -- python3 $R/tools/encoder_bench.py --ppo-shapes --iters 1 > /dev/null 2> $O/enc_pmc.err || exit 1
 $S pmc $O/enc_pmc --title "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python3 tools/encoder_bench.py --ppo-shapes --iters 1 ($TAG)" --md $O/${TAG}_encoder_pmc_mfma.md --json $O/${TAG}_encoder_pmc_mfma.json || exit 1
 rm -rf $O/enc_pmc
+ls -la $O
+echo "== encoder forward + backward: kernel trace"
+bash $R/tools/prof_enc_train.sh $TAG > $O/enc_train.log 2>&1 || exit 1
+python3 $R/tools/mfma_busy_table.py $O/${TAG}_encoder_pmc_mfma.json > $O/${TAG}_encoder_mfma_busy_table.md
+python3 $R/tools/make_traffic_json.py $O $TAG > $O/pmc_traffic.json
 ls -la $O

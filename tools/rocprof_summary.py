@@ -44,6 +44,13 @@ def gemm_label(short: str, grid_wg: int):
         return "gemm_NT_pf_M64_N3072_K162816"             # out_layer.fc1 forward: 24 column tiles x 32 K splits
     if short.startswith("gemm_kernel<64, 128, 64, 64, 32, false, true, 3, true, false") and grid_wg == 1272:
         return "gemm_NN_pf_M64_N162816_K3072"             # out_layer.fc1 input gradient
+    # the 256 x 256 NT kernel at M = 100 864 (ViT-B/16 over 512 frames): 394 tile rows x N / 256 tile columns
+    if short.startswith("gemm256_nt_kernel") and grid_wg == 394 * 12:
+        return "gemm_NT_pp_M100864_N3072_K768"            # FFN-1 (+ GELU): the value loop's dominant signature
+    if short.startswith("gemm256_nt_kernel") and grid_wg == 394 * 9:
+        return "gemm_NT_pp_M100864_N2304_K768"            # fused QKV projection
+    if short.startswith("gemm256_nt_kernel") and grid_wg == 394 * 3:
+        return "gemm_NT_pp_M100864_N768_K{768,3072}"      # output projection / FFN-2 (same grid)
     return None
 
 
