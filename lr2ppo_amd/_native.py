@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "liblr2ppo_hip.so")
+_AB_LIB = os.environ.get("LR2_AB_LIB")     # tools/dbg only: load another build of the same ABI for an A/B timing (never in a test or bench run)
 SOURCES = ["gemm.hip", "gemm256.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
 
@@ -142,7 +143,7 @@ def lib() -> C.CDLL:
         # process would hold two HIP/HSA runtimes and the second one finds "no ROCm-capable device".
         import torch  # noqa: F401
         try:
-            handle = C.CDLL(LIB_PATH)
+            handle = C.CDLL(_AB_LIB or LIB_PATH)
         except OSError as e:  # e.g. libamdhip64 not loadable
             raise RuntimeError(f"lr2ppo_amd: cannot load {LIB_PATH}: {e}") from e
         for name, argtypes in SIGNATURES.items():
