@@ -258,6 +258,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
   epilogue_wave<128, 64, 8, 4, 1>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, nullptr);
 }
 
+
 }  // namespace g256
 
 // ---------------------------------------------------------------------------------------------------------------------
