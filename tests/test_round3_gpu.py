@@ -455,3 +455,42 @@ def test_stage1_launcher_trains_the_composed_model_from_raw_inputs(dev, tmp_path
     log = r.stdout + r.stderr
     assert "Avg loss" in log and "NDCG" in log, log[-3000:]
     assert out.exists()
+
+
+def test_vit_l14_full_depth_forward_and_gradients_match_oracle(dev):
+    """BASELINE config 5's encoder swap at FULL depth (round-2 review: 'ViT-L/14 parity only on a 2-layer stack'): all 24 layers of
+    lr2ppo_amd/configs/vit_large_14_224.json (hidden 1024, 16 heads, patch 14 -> 257 tokens, blocked attention kernels) on one
+    frame pair -- the hidden states and the pooled [CLS] row of the inference schedule (last layer for row 0 only) within 1e-3 of the
+    oracle, then the training path's parameter gradients at both ends and the middle of the stack against the oracle's autograd."""
+    import os
+    from lr2ppo_amd.finetune.features import EncoderStack, encoder_args
+    from test_encoder_gpu import _cmp
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lr2ppo_amd", "configs", "vit_large_14_224.json")
+    a = encoder_args(cfg)
+    assert a.layers_num == 24
+    stack = EncoderStack(a, 10)
+    pe = O.seeded_params(O.vit_embedding_spec(1024, 3, 14, 257), seed=191)
+    pn = O.seeded_params(O.encoder_param_spec(24, 1024, 4096, True), seed=192)
+    stack.embedding.load_state_dict(pe, strict=True)
+    stack.encoder.load_state_dict(pn, strict=True)
+    stack = stack.to(dev).eval()
+    gen = torch.Generator().manual_seed(193)
+    img = torch.randn(2, 3, 224, 224, generator=gen)
+    seg = torch.ones(2, 257, dtype=torch.long)
+    w = torch.randn(2, 257, 1024, generator=gen)
+    with torch.no_grad():
+        got = stack(img.to(dev), seg.to(dev))
+        cls = stack.forward_first_token(img.to(dev), seg.to(dev))
+    pg = {k: v.clone().requires_grad_(True) for k, v in pn.items()}
+    want = O.transformer_encoder(pg, O.vit_embedding(pe, img, 14), seg, 24, 16, True)
+    (want * w).sum().backward()
+    _cmp(got, want.detach(), "ViT-L/14, 24 layers")
+    _cmp(cls, want.detach()[:, 0, :], "ViT-L/14 pooled [CLS] row (pruned last layer)")
+    (stack(img.to(dev), seg.to(dev)) * w.to(dev)).sum().backward()
+    named = dict(stack.encoder.named_parameters())
+    for name in ("transformer.0.self_attn.linear_layers.0.weight", "transformer.0.feed_forward.linear_1.weight",
+                 "transformer.11.self_attn.linear_layers.2.weight", "transformer.12.feed_forward.linear_2.weight",
+                 "transformer.23.self_attn.final_linear.weight", "transformer.23.layer_norm_2.gamma", "layer_norm.gamma"):
+        ref_g = pg[name].grad
+        rel = float((named[name].grad.cpu().double() - ref_g.double()).norm() / ref_g.double().norm())
+        assert rel < REL, (name, rel)
