@@ -488,15 +488,8 @@ int launch(const GemmParams& p_in, int splits, hipStream_t stream) {
   const size_t main_lds = (size_t)((APL && p.dma_stages == 2) ? 2 : 1) * NIMG * BM * BK * 2 +
                           (size_t)((BPL && p.dma_stages == 2) ? 2 : 1) * NIMG * BN * BK * 2;
   constexpr size_t epi_lds = (size_t)4 * 32 * (WN + 4) * 4;
-  size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
+  const size_t lds = main_lds > epi_lds ? main_lds : epi_lds;
   constexpr size_t max_lds = (size_t)2 * NIMG * BM * BK * 2 + (size_t)2 * NIMG * BN * BK * 2;
-  // Experiment knob (LR2_ADAM_LDS_PAD bytes, read per call; never set in a timed run): inflate the LDS request of the fused-AdamW
-  // launch so that fewer of its workgroups fit a CU and the other stream's GEMMs keep an LDS slot beside them.
-  if (p.epi.adam_p) {
-    const char* pad = getenv("LR2_ADAM_LDS_PAD");
-    if (pad) lds += (size_t)atoi(pad);
-    if (lds > 160 * 1024) lds = 160 * 1024;
-  }
   // 8-wave workgroups: NT at either K depth, NN at 32-deep tiles (lr2_gemm never asks for them with a transposed A, and the
   // 64-deep NN variant does not fit 128 VGPRs without scratch: it is not built)
   if constexpr (APL && BPL && BM == 128 && PASSES == 3 && !TA && !(TB && BK == 64)) {
@@ -516,8 +509,7 @@ int launch(const GemmParams& p_in, int splits, hipStream_t stream) {
   auto kern = gemm_kernel<BM, BN, BK, WM, WN, TA, TB, PASSES, APL, BPL>;
   static bool attr_set = false;
   if (!attr_set) {
-    if (lr2_allow_dynamic_lds(kern, getenv("LR2_ADAM_LDS_PAD") ? (size_t)160 * 1024 : (max_lds > epi_lds ? max_lds : epi_lds), "gemm"))
-      return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(kern, max_lds > epi_lds ? max_lds : epi_lds, "gemm")) return LR2_ERR_LAUNCH;
     attr_set = true;
   }
   LR2_LAUNCH(kern, grid, dim3(NTHREADS), lds, stream, p);
