@@ -88,6 +88,40 @@ for it in range(a.n):
         print("GEMM MISMATCH", form, M, N, K, "bm", bm, "splits", splits, "planes", use_planes, "epi", epi, "err", err, "tol", tol, flush=True)
 print("gemm cases done", a.n, "bad", bad, flush=True)
 
+# ---- TN form of the 256 x 256 kernel (long contractions, K-splits, ragged everything) with the fused column sums of A ----
+for it in range(max(8, a.n // 6)):
+    M = int(rng.integers(1, 140)) * 8
+    N = int(rng.integers(1, 140)) * 8
+    K = int(rng.integers(33, 9000))
+    steps = (K + 31) // 32
+    splits = int(rng.integers(1, max(2, min(40, steps))))
+    with_cs = bool(rng.integers(0, 2)) and M % 4 == 0
+    A = torch.randn(K, M, generator=g) + 0.2
+    B = torch.randn(K, N, generator=g) * 0.1
+    Ad, Bd = planes(A), planes(B)
+    out = torch.full((M, N), float("nan"), device=dev)
+    ws = torch.empty(splits * M * N, device=dev)
+    db = torch.full((M,), float("nan"), device=dev) if with_cs else None
+    cs_ws = torch.empty(max(128, splits * ((N + 255) // 256)) * M, device=dev) if with_cs else None
+    try:
+        ops.gemm(Ad, Bd, out, M, N, K, trans_a=True, trans_b=True, lda=M, ldb=N, block_m=256, splits=splits, splitk_ws=ws, colsum=db,
+                 colsum_ws=cs_ws)
+    except Exception as e:                                    # noqa: BLE001
+        print("gemm256 TN raised", M, N, K, splits, repr(e)[:120], flush=True)
+        bad += 1
+        continue
+    want = A.double().t() @ B.double()
+    err = (out.double().cpu() - want).abs().max().item()
+    tol = 8e-5 * math.sqrt(K) * max(1.0, float(want.abs().max()) / 10)
+    ok = err < tol
+    if with_cs:
+        ref_cs = Ad.to_float().double().sum(0).cpu()
+        ok = ok and (db.double().cpu() - ref_cs).abs().max().item() < 3e-5 * math.sqrt(K) * max(1.0, float(ref_cs.abs().max()) / 10)
+    if not ok:
+        bad += 1
+        print("GEMM256 TN MISMATCH", M, N, K, "splits", splits, "colsum", with_cs, "err", err, "tol", tol, flush=True)
+print("gemm256 TN cases done, bad", bad, flush=True)
+
 # ---- self-attention forward + backward, first-token attention ----
 for it in range(max(10, a.n // 5)):
     batch, heads = int(rng.integers(1, 4)), int(rng.integers(1, 4))
