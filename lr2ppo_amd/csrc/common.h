@@ -159,6 +159,7 @@ struct Epilogue {
   float adam_lr, adam_b1, adam_b2, adam_ob1, adam_ob2, adam_eps, adam_wd;
   int stream_nt;         // optimizer state p / m / v: non-temporal loads and stores (each byte is touched once per launch)
   float* colsum_partial; // gemm256 TN: [splits * tiles_n][M] partial column sums of A (bias gradient), or NULL
+  int store_nt;          // result stores (out / out_z / planes) non-temporal: large outputs that the next kernel streams from HBM anyway
 };
 
 // One AdamW element update, TencentPretrain semantics (correct_bias=False; eps outside the sqrt; decay after the

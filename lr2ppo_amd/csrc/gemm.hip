@@ -650,6 +650,10 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   p.epi = to_device_epilogue(epi);
   p.epi.stream_nt = (ablate & 64) ? 0 : 1;   // fused AdamW: +2-3 % on the 12-GB p / m / v stream (A/B with LR2_GEMM_ABLATE=64)
   p.ablate = ablate;
+  // Results of 256 MiB and more (the encoders' token GEMMs at M >= 1e5 rows: larger than L2 + the 256-MiB MALL, streamed from HBM by
+  // the next kernel whatever we do) are stored non-temporally: +1..4 % on the K = 768 shapes of the 256 x 256 kernel, A/B with
+  // LR2_GEMM_ABLATE=128 (= off).  Smaller results keep the default policy: their consumer may still find them on chip.
+  p.epi.store_nt = (!(ablate & 128) && (uint64_t)M * (uint64_t)N * 4ull >= (256ull << 20)) ? 1 : 0;
   // 128 x 128 planes tiles, NT / NN: 8-wave workgroups (two workgroups per CU = 4 waves per SIMD) overlap the MFMA issue,
   // the LDS-DMA issue and the fragment waits of different waves: +5..21 % over 4 waves (tools/gemm_bench.py); TN: equal.
   p.waves8 = (w8_env && !trans_a) ? 1 : 0;

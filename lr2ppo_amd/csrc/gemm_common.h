@@ -110,7 +110,7 @@ __device__ __forceinline__ void epilogue_apply4(const Epilogue& e, float4 v, flo
   v.x *= e.alpha; v.y *= e.alpha; v.z *= e.alpha; v.w *= e.alpha;
   if (e.bias) { v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
   if (e.act == 1) {
-    if (e.out_z) st4(e.out_z + (size_t)m * e.ld_z + n, v);
+    if (e.out_z) { if (e.store_nt) st4_nt(e.out_z + (size_t)m * e.ld_z + n, v); else st4(e.out_z + (size_t)m * e.ld_z + n, v); }
     v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
   }
   if (e.drop_scale != 0.0f) {
@@ -135,14 +135,19 @@ __device__ __forceinline__ void epilogue_apply4(const Epilogue& e, float4 v, flo
   }
   if (e.out) {
     if (e.accumulate) { v.x += L.s[SO].x; v.y += L.s[SO].y; v.z += L.s[SO].z; v.w += L.s[SO].w; }
-    st4(e.out + (size_t)m * e.ld_out + n, v);
+    if (e.store_nt) st4_nt(e.out + (size_t)m * e.ld_out + n, v); else st4(e.out + (size_t)m * e.ld_out + n, v);
   }
   if (e.out_hi) {  // bf16 hi/lo planes for the next GEMM (same bytes as the fp32 tensor they replace)
     u32x2_t hv, lv;
     split4(v, hv, lv);
     bf16_t* ph = e.out_hi + (size_t)m * e.ld_planes + n;
-    *reinterpret_cast<u32x2_t*>(ph) = hv;
-    *reinterpret_cast<u32x2_t*>(ph + e.lo_off) = lv;
+    if (e.store_nt) {
+      __builtin_nontemporal_store(hv, reinterpret_cast<u32x2_t*>(ph));
+      __builtin_nontemporal_store(lv, reinterpret_cast<u32x2_t*>(ph + e.lo_off));
+    } else {
+      *reinterpret_cast<u32x2_t*>(ph) = hv;
+      *reinterpret_cast<u32x2_t*>(ph + e.lo_off) = lv;
+    }
   }
 }
 // one element group, loads and stores together (the split-K reducer: a grid-stride loop with one group in flight per thread)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--tags", type=int, default=2)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--detail", action="store_true")
+    ap.add_argument("--each", action="store_true", help="print every iteration's duration (first process on a fresh box: how long until the chip is warm)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(8)
@@ -37,6 +38,15 @@ def main():
         t, i, ctx = fx.forward_train(frames, ids, seg)
         fx.backward_train(ctx, d_text, d_img)
 
+    if a.each:
+        import time
+        t00 = time.perf_counter()
+        for k in range(a.iters):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            it()
+            torch.cuda.synchronize()
+            print(f"  iteration {k}: {(time.perf_counter() - t0) * 1e3:7.1f} ms   (t = {time.perf_counter() - t00:5.1f} s)", flush=True)
     it()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
