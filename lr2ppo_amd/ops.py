@@ -33,14 +33,17 @@ def get_gemm_passes() -> int:
 _PROF = None
 _PROF_ONLY = None
 
-# Bumped whenever a kernel of this package writes parameters through raw pointers (the optimizer): caches of derived
-# data (weight planes) compare it next to torch's own tensor version counters, which such writes do not advance.
-PARAM_EPOCH = 0
+# Kernels of this package write parameters through raw pointers (the optimizer), which torch's tensor version counters do not see:
+# every parameter such a kernel updates gets its own write counter bumped (mark_params_written), and caches of derived data (weight
+# planes) compare it next to p._version.  Per parameter, not global: the PPO heads' optimizer steps must not invalidate the frozen
+# encoders' weight planes (round 2's single global epoch re-split both stacks' weights on every step of the composed loop).
+def mark_params_written(params):
+    for p in params:
+        p._lr2_writes = getattr(p, "_lr2_writes", 0) + 1
 
 
-def bump_param_epoch():
-    global PARAM_EPOCH
-    PARAM_EPOCH += 1
+def param_write_count(p) -> int:
+    return getattr(p, "_lr2_writes", 0)
 
 
 def profile_start(only=None):

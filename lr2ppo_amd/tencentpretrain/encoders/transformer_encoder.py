@@ -42,9 +42,9 @@ class TransformerEncoder(nn.Module):
 
     def _weight_planes(self, dev, cache=True):
         """Per layer: (Wqkv planes [3E, E], bqkv [3E], Wo, W1, W2 planes); rebuilt when any parameter was written
-        (torch's version counters + ops.PARAM_EPOCH, which the HIP optimizer bumps: its kernels write through raw
+        (torch's version counters + the per-parameter write counters the HIP optimizer bumps: its kernels write through raw
         pointers).  cache=False (training): always re-split."""
-        sig = tuple(p._version for p in self.parameters()) + (str(dev), ops.PARAM_EPOCH)
+        sig = tuple((p._version, ops.param_write_count(p)) for p in self.parameters()) + (str(dev),)
         if cache and self._wplanes is not None and self._wplanes[0] == sig:
             return self._wplanes[1]
         out = []

@@ -122,8 +122,10 @@ class AdamW(Optimizer):
                     # decay must use the raw lr (optimizers.py:399-400): run the decay-free update, then decay
                     raise NotImplementedError("correct_bias=True with weight decay is not used by LR2PPO")
             ops.adamw_multi(table, n, step_size, beta1, beta2, group["eps"], n_params=n_params)
+            ops.mark_params_written(ps)
+        if self._external:          # parameters a fused kernel updated since the last step (external_update)
+            ops.mark_params_written([p for g_ in self.param_groups for p in g_["params"] if id(p) in self._external])
         self._external.clear()
-        ops.bump_param_epoch()
         return loss
 
 
