@@ -81,7 +81,9 @@ typedef struct lr2_epilogue {
  *   Supported: (fp32, fp32), (planes, planes), (planes A, fp32 B).  Planes are produced by the epilogue's out_hi,
  *   by lr2_split_planes(_multi) and by the LayerNorm / attention kernels' planes outputs.
  * a_bytes/b_bytes: bytes addressable from A/B, per plane (rows past the end read as zero: ragged M, ragged K in (1,1)).
- * splits>1 uses split-K through splitk_ws (fp32 [splits][M][N]).  block_m: 128 or 64.
+ * splits>1 uses split-K through splitk_ws (fp32 [splits][M][N]).  block_m: 128 or 64, or 256 = the 256 x 256 ping-pong kernel for
+ *   planes x planes operands with passes = 3: the (0,0) form (whole 32-deep K steps, splits = 1) and the (1,1) form (any K, any
+ *   splits: tiles x splits workgroups, the weight-gradient kernel of round 3); other combinations fall back to the 128-row family.
  * replaces: nn.Linear / F.linear + bias + nn.GELU + nn.Dropout + residual add in
  *   finetune/ppo.py:164-170 (Mlp), finetune/xit.py:103-110,118-122,147,
  *   tencentpretrain/layers/{multi_headed_attn.py:55-58,75, position_ffn.py:12-15} and their autograd backward. */
