@@ -451,6 +451,77 @@ def main():
                                    "39.7 M parameters)" if tag == "stage1_finetune" else "")}
             fx.text.embedding.check_ids()
             del pmodel, popt, psch, eopt, esch, praw
+            torch.cuda.empty_cache()
+            # BASELINE configs[4], the parts that exist at fp32-grade numerics: (i) one stage-2 reward-pair step (finetune/
+            # reward_pair_dataloader.py:347-365, the launcher's batch 64 x 20 tags, chosen / reject orderings of 4 positions each:
+            # the Reward architecture's trunk over 2 x 64 x 4 = 512 pairs, M = 100 352 token rows) on pre-extracted features as
+            # upstream; (ii) the ViT-L/14 encoder swap (lr2ppo_amd/configs/vit_large_14_224.json) forward over the step's 512 frames.
+            from lr2ppo_amd.finetune import reward_pair_dataloader as rp
+            torch.manual_seed(10)
+            rmodel = rp.Classifier(pargs, None).to(dev)
+            with torch.no_grad():
+                for p in rmodel.parameters():
+                    p.normal_(0, 0.02)
+            ropt, rsch = rp.build_optimizer(pargs, rmodel)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for _ in range(20):
+                    rsch.step()
+            rmodel.train()
+            gs = torch.Generator(device=dev).manual_seed(4000)
+            rb, rt = 64, 20
+            rtext = torch.randn(rb, rt, 196, 768, device=dev, generator=gs)
+            rimg = torch.randn(rb, 16, 768, device=dev, generator=gs)
+            rtg = torch.randint(0, 3, (rb, rt), device=dev, generator=gs)
+            chosen = torch.stack([torch.randperm(rt, device=dev, generator=gs)[:4] for _ in range(rb)])
+            reject = chosen.flip(1)
+            for _ in range(2):
+                l2, acc = rp.train_model(pargs, rmodel, ropt, rsch, rtext, rimg, rtg, chosen, reject)
+            fence()
+            n2 = 4
+            t0 = time.perf_counter()
+            for _ in range(n2):
+                l2, acc = rp.train_model(pargs, rmodel, ropt, rsch, rtext, rimg, rtg, chosen, reject)
+            fence()
+            dt2 = time.perf_counter() - t0
+            if not torch.isfinite(l2):
+                raise SystemExit("bench: non-finite stage-2 loss")
+            out["stage2_reward_pair_steps_per_sec"] = round(n2 / dt2, 3)
+            out["config"]["stage2_reward_pair_step"] = {
+                "ms_per_step": round(dt2 / n2 * 1e3, 3), "steps": n2, "measured": True,
+                "workload": "finetune/reward_pair_dataloader.py train step on pre-extracted features: 64 items x 20 tags, chosen / reject "
+                            "orderings of 4 tags -> Reward-architecture trunk over 512 pairs (M = 100352 token rows), pair hinge, "
+                            "fused out_layer.fc1 update"}
+            del rmodel, ropt, rsch, rtext, rimg
+            torch.cuda.empty_cache()
+        if not a.no_stage1:
+            from lr2ppo_amd.finetune.features import EncoderStack, encoder_args
+            cfg_l = os.path.join(REPO, "lr2ppo_amd", "configs", "vit_large_14_224.json")
+            vl = EncoderStack(encoder_args(cfg_l), 10)
+            with torch.no_grad():
+                for n_, p in vl.named_parameters():
+                    if "gamma" not in n_ and "beta" not in n_:
+                        p.normal_(0, 0.02)
+            vl = vl.to(dev).eval()
+            nfr = a.batch * 16
+            limg = torch.randn(nfr, 3, 224, 224, device=dev)
+            lseg = torch.ones(nfr, 257, dtype=torch.long, device=dev)
+            with torch.no_grad():
+                vl(limg, lseg)
+                torch.cuda.synchronize()
+                ev0.record()
+                for _ in range(2):
+                    vl(limg, lseg)
+                ev1.record()
+                torch.cuda.synchronize()
+            l_ms = ev0.elapsed_time(ev1) / 2
+            l_fl = 24 * (2.0 * nfr * 257 * 1024 * (4 * 1024 + 2 * 4096) + 4.0 * nfr * 16 * 257 * 257 * 64) + 2.0 * nfr * 256 * 640 * 1024
+            out["vit_l14_forward_ms"] = round(l_ms, 3)
+            out["vit_l14_forward_mfma_frac"] = round(a.passes * l_fl / l_ms / 1e9 / MFMA_BF16_PEAK_TF, 4)
+            out["config"]["vit_l14_forward"] = {"ms": round(l_ms, 3), "algorithmic_tflop": round(l_fl / 1e12, 1), "frames": nfr,
+                                                "workload": "ViT-L/14 (hidden 1024, 24 layers, 16 heads, 257 tokens: key-block attention) "
+                                                            "full forward, random weights"}
+            del vl, limg, lseg
         del fx, raw
     # ================= [D] CPU baseline: the oracle on this box's host cores, bounded sample =================
     if world == 1 and not a.no_cpu_baseline:
