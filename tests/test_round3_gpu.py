@@ -251,9 +251,24 @@ def test_finetune_pointwise_step_trains_head_and_both_stacks(dev):
               if q.numel() < 5_000_000}
     runtime.set_dropout_seed(91)
     seed0 = runtime.peek_drop_seed()
-    loss_ref, *_ = _oracle_chain(pv, pt, Pa, frames, ids, seg, tgts, seed0)
-    losses = [finetune_pointwise_step(args, fx, model, opt, sch, eopt, esch, frames.to(dev), ids.to(dev), seg.to(dev), tgts.to(dev))
-              for _ in range(2)]
+    loss_ref, _, _, _, leaves = _oracle_chain(pv, pt, Pa, frames, ids, seg, tgts, seed0)
+    lr = eopt.param_groups[0]["lr"]
+    assert lr > 0
+    l0 = finetune_pointwise_step(args, fx, model, opt, sch, eopt, esch, frames.to(dev), ids.to(dev), seg.to(dev), tgts.to(dev))
+    # the first step's encoder update against the oracle's AdamW on the oracle's gradients (zero moments: the update is
+    # lr * 0.1 g / (sqrt(0.001 g^2) + 1e-6), nearly a sign step, so only elements with a near-zero gradient may differ), with the
+    # reference's decay rule: 0.01 except names containing bias / gamma / beta
+    named = {**{"image." + n: q for n, q in fx.image.named_parameters()}, **{"text." + n: q for n, q in fx.text.named_parameters()}}
+    for name in ("text.encoder.transformer.0.feed_forward.linear_1.weight", "text.encoder.transformer.0.layer_norm_1.gamma",
+                 "image.encoder.transformer.0.self_attn.linear_layers.0.weight", "image.embedding.patch.projection.weight",
+                 "text.embedding.pos.embedding.weight", "image.encoder.transformer.0.feed_forward.linear_2.bias"):
+        w0 = (pv if name.startswith("image.") else pt)[name.split(".", 1)[1]]
+        g = leaves[name].grad
+        want, _, _ = O.adamw_step(w0, g, torch.zeros_like(w0), torch.zeros_like(w0), lr, 0.0 if O.no_decay(name) else 0.01)
+        got = named[name].detach().cpu()
+        close = ((got - want).abs() < 2e-7 + 1e-6 * want.abs()).float().mean().item()
+        assert close > 0.99, (name, close)
+    losses = [l0, finetune_pointwise_step(args, fx, model, opt, sch, eopt, esch, frames.to(dev), ids.to(dev), seg.to(dev), tgts.to(dev))]
     fx.text.embedding.check_ids()
     assert abs(float(losses[0]) - float(loss_ref)) < 1e-3
     assert all(torch.isfinite(l) for l in losses)
