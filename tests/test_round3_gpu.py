@@ -266,8 +266,11 @@ def test_finetune_pointwise_step_trains_head_and_both_stacks(dev):
         g = leaves[name].grad
         want, _, _ = O.adamw_step(w0, g, torch.zeros_like(w0), torch.zeros_like(w0), lr, 0.0 if O.no_decay(name) else 0.01)
         got = named[name].detach().cpu()
-        close = ((got - want).abs() < 2e-7 + 1e-6 * want.abs()).float().mean().item()
-        assert close > 0.99, (name, close)
+        # compare the UPDATE: where |g| is far above eps / sqrt(1 - beta2) it is a sign step (insensitive to the 2e-3 gradient
+        # tolerance), below it is linear in g -- so the update as a whole agrees to about the gradient tolerance
+        du_got, du_want = (got - w0).double(), (want - w0).double()
+        rel = float((du_got - du_want).norm() / du_want.norm())
+        assert rel < 2e-2, (name, rel)
     losses = [l0, finetune_pointwise_step(args, fx, model, opt, sch, eopt, esch, frames.to(dev), ids.to(dev), seg.to(dev), tgts.to(dev))]
     fx.text.embedding.check_ids()
     assert abs(float(losses[0]) - float(loss_ref)) < 1e-3
