@@ -298,9 +298,14 @@ class TransformerEncoder(nn.Module):
         if self.final_layernorm:
             ln = self.layer_norm
             dnew = mat("dh0", M, E)
+            # pre-LN: the top layer's first consumer of this gradient is dropout_2's mask + the planes split (FFN-2's dY): the LayerNorm
+            # backward writes them on the way out instead of a separate pass over [M, E]
+            top = self.layers_num - 1
             ops.layernorm_bwd(dh, saved["h_final"], ln.gamma.data, saved["mf"], saved["rf"], dnew, partials, G[ln.gamma],
-                              G[ln.beta], rows=M, D=E, mode=1, eps=ln.eps)
+                              G[ln.beta], rows=M, D=E, mode=1, eps=ln.eps, dx_planes=pl("dff_p", M, E) if pre else None,
+                              drop=drop(4 * top + 2) if pre else None)
             dh = dnew
+        dff_ready = pre and self.final_layernorm
         flip = 1
         for i in reversed(range(self.layers_num)):
             layer, w, S = self.transformer[i], W[i], saved["layers"][i]
@@ -309,7 +314,8 @@ class TransformerEncoder(nn.Module):
             s0 = 4 * i
             dff_p, dz_p = pl("dff_p", M, E), pl("dz_p", M, F)
             if pre:
-                ops.dropout_planes(dh, dff_p, drop(s0 + 2))
+                if not dff_ready:
+                    ops.dropout_planes(dh, dff_p, drop(s0 + 2))
                 ffn_in_p = S["x2_p"]
             else:
                 d_t2 = mat("d_t2", M, E)
@@ -345,8 +351,13 @@ class TransformerEncoder(nn.Module):
             if pre:
                 d_x1 = mat("d_x1", M, E)
                 engine.linear_dgrad(ws, dqkv_p, w["wqkv"], d_x1, M, E, 3 * E, w_f32=w["wqkv_f32"])
+                # ... and the layer below gets its dropout_2-masked planes from this LayerNorm backward (dff_p is free again: its
+                # readers of this layer ran earlier on the stream)
+                nxt = i > 0
                 ops.layernorm_bwd(d_x1, S["h_in"], ln1.gamma.data, S["m1"], S["r1"], dprev, partials, G[ln1.gamma], G[ln1.beta],
-                                  rows=M, D=E, resid_grad=d_t1, mode=1, eps=ln1.eps)
+                                  rows=M, D=E, resid_grad=d_t1, mode=1, eps=ln1.eps, dx_planes=dff_p if nxt else None,
+                                  drop=drop(s0 - 4 + 2) if nxt else None)
+                dff_ready = nxt
             else:
                 engine.linear_dgrad(ws, dqkv_p, w["wqkv"], dprev, M, E, 3 * E, resid=d_t1, w_f32=w["wqkv_f32"])
             dh = dprev
