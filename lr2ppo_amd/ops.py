@@ -235,7 +235,11 @@ def _use_gemm256(M: int, N: int, K: int, passes: int) -> bool:
         return False
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
     rounds = -(-tiles // 256)
-    return tiles >= 256 and tiles >= 0.88 * rounds * 256
+    if tiles >= 256 and tiles >= 0.88 * rounds * 256:
+        return True
+    # one partial round, long contraction (M = 12544, N = 768, K = 3072: 147 tiles): each CU runs one tile at the 256 x 256 kernel's
+    # main-loop rate and the epilogue is amortised over 96 K steps -- 182 us against 197 (64-row tiles) / 212 (128-row), round 3
+    return 128 <= tiles <= 256 and K >= 2304
 
 
 @functools.lru_cache(maxsize=4096)
