@@ -375,12 +375,13 @@ def main():
             t_, i_, ctx = fx.forward_train(frames, ids, seg)
             fx.backward_train(ctx, d_text, d_img)
 
-        enc_train(0)
+        for i in range(2):            # two untimed passes: the first process on a fresh box needs more than one to settle (arenas, clocks)
+            enc_train(i)
         torch.cuda.synchronize()
         n_tr = 3
         ev0.record()
         for i in range(n_tr):
-            enc_train(1 + i)
+            enc_train(2 + i)
         ev1.record()
         torch.cuda.synchronize()
         tr_ms = ev0.elapsed_time(ev1) / n_tr
