@@ -22,6 +22,94 @@ from ..layers.layer_norm import LayerNorm
 from ..layers.transformer import TransformerLayer
 
 
+class _LayerPlanes(dict):
+    """One layer's GEMM operands; `wqkv_f32`, `wqkv_t`, `w1_t` are produced on first access after a refresh."""
+
+    def __missing__(self, key):
+        if key == "wqkv_f32":
+            v = torch.cat([lin.weight.data for lin in self._qkv], dim=0, out=self._f32)
+        elif key == "wqkv_t":
+            v = ops.split_planes_t(self["wqkv_f32"], self._t_qkv)
+        elif key == "w1_t":
+            v = ops.split_planes_t(self._w1.data.contiguous(), self._t_w1)
+        else:
+            raise KeyError(key)
+        self[key] = v
+        return v
+
+
+class _StackPlanes:
+    """bf16 hi / lo planes of every GEMM weight of an encoder stack in one buffer + the device table that re-splits them from the
+    fp32 parameters in one launch (lr2_split_planes_multi).  Wq, Wk, Wv are split straight into the row blocks of one [3E, E] planes
+    matrix (hi plane of all three, then lo plane): no fp32 concatenation on the forward path."""
+    CHUNK = 1 << 16
+    LAZY = ("wqkv_f32", "wqkv_t", "w1_t")
+
+    def __init__(self, enc, dev):
+        layers = list(enc.transformer)
+        E = layers[0].self_attn.final_linear.out_features
+        F = layers[0].feed_forward.linear_1.out_features
+        per = 3 * E * E + E * E + 2 * E * F
+        self.dev = dev
+        self.buf = torch.empty(2 * per * len(layers), dtype=torch.int16, device=dev)
+        self.ptrs = tuple(p.data_ptr() for p in enc.parameters())
+        self.layers, rows, cur = [], [], 0
+        base = self.buf.data_ptr()
+
+        def add(sources, nrows, ncols):
+            nonlocal cur
+            n = nrows * ncols
+            pl = ops.Planes(self.buf[cur:cur + 2 * n], nrows, ncols)
+            r0 = 0
+            for w in sources:
+                if w.dim() != 2 or w.shape[1] != ncols or not w.is_contiguous() or w.numel() % 4:
+                    raise ValueError("encoder GEMM weights must be contiguous 2-D fp32 tensors")
+                k, o = w.numel(), 0
+                while o < k:
+                    c = min(self.CHUNK, k - o)
+                    rows.append((w.data_ptr() + 4 * o, base + 2 * (cur + r0 * ncols + o), n, c))
+                    o += c
+                r0 += w.shape[0]
+            cur += 2 * n
+            return pl
+
+        for layer in layers:
+            att, ffn = layer.self_attn, layer.feed_forward
+            ent = _LayerPlanes()
+            ent["wqkv"] = add([att.linear_layers[i].weight.data for i in range(3)], 3 * E, E)
+            ent["wo"] = add([att.final_linear.weight.data], E, E)
+            ent["w1"] = add([ffn.linear_1.weight.data], F, E)
+            ent["w2"] = add([ffn.linear_2.weight.data], E, F)
+            ent["bqkv"] = torch.empty(3 * E, device=dev)
+            ent._qkv, ent._w1 = [att.linear_layers[i] for i in range(3)], ffn.linear_1.weight
+            ent._f32 = torch.empty(3 * E, E, device=dev)
+            ent._t_qkv, ent._t_w1 = ops.Planes.empty(E, 3 * E, dev), ops.Planes.empty(E, F, dev)
+            self.layers.append(ent)
+        import ctypes as C  # noqa: F401
+        from ... import _native
+        arr = (_native.SplitChunk * len(rows))()
+        for i, (src, dst, lo, cnt) in enumerate(rows):
+            arr[i].src, arr[i].dst_hi, arr[i].lo_off, arr[i].count = src, dst, lo, cnt
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.n_chunks = len(rows)
+        self.sig = None
+
+    @staticmethod
+    def signature(enc):
+        return tuple((p._version, ops.param_write_count(p)) for p in enc.parameters())
+
+    def matches(self, enc, dev) -> bool:
+        return self.dev == dev and self.ptrs == tuple(p.data_ptr() for p in enc.parameters())
+
+    def refresh(self, enc):
+        ops.split_planes_multi(self.table, self.n_chunks)
+        for ent in self.layers:
+            for k in self.LAZY:
+                ent.pop(k, None)
+            torch.cat([lin.bias.data for lin in ent._qkv], dim=0, out=ent["bqkv"])
+        self.sig = self.signature(enc)
+
+
 class TransformerEncoder(nn.Module):
     def __init__(self, args):
         super().__init__()
@@ -41,29 +129,21 @@ class TransformerEncoder(nn.Module):
         self._wplanes = None
 
     def _weight_planes(self, dev, cache=True):
-        """Per layer: (Wqkv planes [3E, E], bqkv [3E], Wo, W1, W2 planes); rebuilt when any parameter was written
-        (torch's version counters + the per-parameter write counters the HIP optimizer bumps: its kernels write through raw
-        pointers).  cache=False (training): always re-split."""
-        sig = tuple((p._version, ops.param_write_count(p)) for p in self.parameters()) + (str(dev),)
-        if cache and self._wplanes is not None and self._wplanes[0] == sig:
-            return self._wplanes[1]
-        out = []
-        for layer in self.transformer:
-            att, ffn = layer.self_attn, layer.feed_forward
-            wqkv = torch.cat([att.linear_layers[i].weight.data for i in range(3)], dim=0).contiguous()
-            bqkv = torch.cat([att.linear_layers[i].bias.data for i in range(3)], dim=0).contiguous()
-            ent = {"bqkv": bqkv, "wqkv_f32": wqkv}      # the fp32 concatenation: large-M input gradients transpose it (engine.linear_dgrad)
-            for name, w in (("wqkv", wqkv), ("wo", att.final_linear.weight.data), ("w1", ffn.linear_1.weight.data),
-                            ("w2", ffn.linear_2.weight.data)):
-                pl = ops.Planes.empty(w.shape[0], w.shape[1], dev)
-                ops.split_planes(w.contiguous(), pl)
-                ent[name] = pl
-            # wide outputs (QKV, FFN1): the forward runs the NN form on W^T planes (~10 % faster than NT there)
-            for name, w in (("wqkv_t", wqkv), ("w1_t", ffn.linear_1.weight.data)):
-                ent[name] = ops.split_planes_t(w.contiguous(), ops.Planes.empty(w.shape[1], w.shape[0], dev))
-            out.append(ent)
-        self._wplanes = (sig, out)
-        return out
+        """Per layer a dict: Wqkv planes [3E, E] (rows Q | K | V), bqkv [3E], Wo, W1, W2 planes -- and, computed on first use after
+        a refresh, the fp32 concatenation `wqkv_f32` (large-M input gradients transpose it) and the transposed planes `wqkv_t` /
+        `w1_t` (the NN form of the forward on small batches).  All planes of the stack live in ONE buffer and are re-split from the
+        fp32 parameters by ONE multi-tensor launch (round 3; rounds 1-2: 2 concatenations + 6 allocations + 6 split launches per layer
+        and forward); re-split when any parameter was written (torch's version counters + the per-parameter write counters the HIP
+        optimizer bumps: its kernels write through raw pointers).  cache=False (training): always re-split."""
+        sp = self._wplanes
+        if sp is None or not sp.matches(self, dev):
+            sp = self._wplanes = _StackPlanes(self, dev)
+            fresh = False
+        else:
+            fresh = cache and sp.sig == sp.signature(self)
+        if not fresh:
+            sp.refresh(self)
+        return sp.layers
 
     def forward(self, emb, seg):
         if emb.dtype != torch.float32 or not emb.is_cuda:
@@ -294,6 +374,7 @@ class TransformerEncoder(nn.Module):
         dwqkv, dbqkv = ws.mat("dwqkv", 3 * E, E), ws.vec("dbqkv", 3 * E)
         pre = self.layernorm_positioning == "pre"
         scale = 1.0 / math.sqrt(float(hd))
+        big_dqkv = ops.use_gemm256(M, E, 3 * E)     # the QKV input gradient goes through a transposed fp32 concatenation only then
         dh = dout.contiguous().view(M, E)
         if self.final_layernorm:
             ln = self.layer_norm
@@ -350,7 +431,7 @@ class TransformerEncoder(nn.Module):
             flip ^= 1
             if pre:
                 d_x1 = mat("d_x1", M, E)
-                engine.linear_dgrad(ws, dqkv_p, w["wqkv"], d_x1, M, E, 3 * E, w_f32=w["wqkv_f32"])
+                engine.linear_dgrad(ws, dqkv_p, w["wqkv"], d_x1, M, E, 3 * E, w_f32=w["wqkv_f32"] if big_dqkv else None)
                 # ... and the layer below gets its dropout_2-masked planes from this LayerNorm backward (dff_p is free again: its
                 # readers of this layer ran earlier on the stream)
                 nxt = i > 0
@@ -359,7 +440,7 @@ class TransformerEncoder(nn.Module):
                                   drop=drop(s0 - 4 + 2) if nxt else None)
                 dff_ready = nxt
             else:
-                engine.linear_dgrad(ws, dqkv_p, w["wqkv"], dprev, M, E, 3 * E, resid=d_t1, w_f32=w["wqkv_f32"])
+                engine.linear_dgrad(ws, dqkv_p, w["wqkv"], dprev, M, E, 3 * E, resid=d_t1, w_f32=w["wqkv_f32"] if big_dqkv else None)
             dh = dprev
             saved["layers"][i] = None                                   # release this layer's activations
         return dh.view(B, L, E), G
