@@ -335,6 +335,28 @@ class TransformerEncoder(nn.Module):
             out = h.view(B, L, E)
         return out, saved
 
+    def _grad_layout(self, flat):
+        """Views of `flat` (numel = all parameters) as {parameter: gradient} plus, per layer, the [3E, E] / [3E] blocks that hold the
+        Q, K, V weight / bias gradients CONTIGUOUSLY: the fused QKV weight gradient (one TN GEMM + its column sums) is written
+        straight into them -- no per-layer copies into three separate tensors."""
+        views, qkv, off = {}, [], 0
+        for layer in self.transformer:
+            lin = layer.self_attn.linear_layers
+            E = lin[0].weight.shape[0]
+            wblk = flat[off:off + 3 * E * E].view(3 * E, E)
+            off += 3 * E * E
+            bblk = flat[off:off + 3 * E]
+            off += 3 * E
+            for j in range(3):
+                views[lin[j].weight] = wblk[j * E:(j + 1) * E]
+                views[lin[j].bias] = bblk[j * E:(j + 1) * E]
+            qkv.append((wblk, bblk))
+        for q in self.parameters():
+            if q not in views:
+                views[q] = flat[off:off + q.numel()].view_as(q)
+                off += q.numel()
+        return views, qkv
+
     def grad_buffers(self):
         """{parameter: gradient} views of ONE persistent flat fp32 buffer (the explicit training path of
         lr2ppo_amd.finetune.features: no per-step allocation, fixed addresses for the optimizer's chunk table and one
@@ -343,10 +365,7 @@ class TransformerEncoder(nn.Module):
         dev = params[0].device
         if getattr(self, "_gflat", None) is None or self._gflat.device != dev:
             self._gflat = torch.zeros(sum(q.numel() for q in params), device=dev)
-            self._gviews, off = {}, 0
-            for q in params:
-                self._gviews[q] = self._gflat[off:off + q.numel()].view_as(q)
-                off += q.numel()
+            self._gviews, self._gqkv = self._grad_layout(self._gflat)
         return self._gviews
 
     @torch.no_grad()
@@ -363,15 +382,13 @@ class TransformerEncoder(nn.Module):
         mat = lambda name, r, c: ws.mat("bwd:" + name, r, c)            # noqa: E731
         pl = lambda name, r, c: ws.planes("bwd:" + name, r, c)          # noqa: E731
         if G is None:
-            params = list(self.parameters())
-            flat = torch.empty(sum(q.numel() for q in params), device=dev)
-            G, off = {}, 0
-            for q in params:
-                G[q] = flat[off:off + q.numel()].view_as(q)
-                off += q.numel()
+            G, qkv_blocks = self._grad_layout(torch.empty(sum(q.numel() for q in self.parameters()), device=dev))
+        else:
+            if G is not getattr(self, "_gviews", None):
+                raise ValueError("_backward_train(G=...): pass grad_buffers()")
+            qkv_blocks = self._gqkv
         partials = ws.vec("ln_partials", ops.LN_BWD_BLOCKS * 2 * E)
         lse_ws, dsum_ws = ws.vec("attn_lse", B * H * L), ws.vec("attn_dsum", B * H * L)
-        dwqkv, dbqkv = ws.mat("dwqkv", 3 * E, E), ws.vec("dbqkv", 3 * E)
         pre = self.layernorm_positioning == "pre"
         scale = 1.0 / math.sqrt(float(hd))
         big_dqkv = ops.use_gemm256(M, E, 3 * E)     # the QKV input gradient goes through a transposed fp32 concatenation only then
@@ -422,10 +439,7 @@ class TransformerEncoder(nn.Module):
             engine.linear_dgrad(ws, dao_p, w["wo"], None, M, E, E, out_planes=do_p, w_f32=att.final_linear.weight.data)
             ops.self_attn_bwd(S["qkv_p"], do_p, seg, dqkv_p, lse_ws, dsum_ws, batch=B, heads=H, L=L, head_dim=hd, scale=scale,
                               drop=drop(s0))
-            engine.linear_wgrad(ws, dqkv_p, S["x_p"], dwqkv, dbqkv, M, E, 3 * E)
-            for j in range(3):
-                G[att.linear_layers[j].weight].copy_(dwqkv[j * E:(j + 1) * E])
-                G[att.linear_layers[j].bias].copy_(dbqkv[j * E:(j + 1) * E])
+            engine.linear_wgrad(ws, dqkv_p, S["x_p"], qkv_blocks[i][0], qkv_blocks[i][1], M, E, 3 * E)     # = the three gradients
             # the gradient handed back to autograd (layer 0) gets its own storage: it outlives this call
             dprev = torch.empty(M, E, device=dev) if i == 0 else mat("dh%d" % flip, M, E)
             flip ^= 1
