@@ -412,6 +412,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partials, dgamma, dbeta, *, rows
                              dx_planes.lo_off if dx_planes is not None else 0, p, seed, site,
                              partials.data_ptr(), nb, rows, D, mode, eps, _stream())
     _nat.check(rc, "lr2_layernorm_bwd")
+    if dbeta.data_ptr() == dgamma.data_ptr() + 4 * D:       # [d gamma | d beta] adjacent (flat gradient buffers): one finishing launch
+        _nat.check(L.lr2_colsum_partials_finish(partials.data_ptr(), nb, 2 * D, 2 * D, dgamma.data_ptr(), 0, _stream()), "finish")
+        return
     _nat.check(L.lr2_colsum_partials_finish(partials.data_ptr(), nb, D, 2 * D, dgamma.data_ptr(), 0, _stream()), "finish")
     _nat.check(L.lr2_colsum_partials_finish(partials.data_ptr() + 4 * D, nb, D, 2 * D, dbeta.data_ptr(), 0, _stream()),
                "finish")
