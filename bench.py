@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed regions")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-GPU extras (encoder fwd / fwd+bwd, stage-1 figures)")
     ap.add_argument("--no-stage1", action="store_true", help="skip the BASELINE configs[1] figures (stage-1 step at 32 x 20 tags)")
+    ap.add_argument("--no-graph", action="store_true", help="skip the HIP-graph replay of the head-only step (head_only_graph)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="one HIP stream for the whole PPO step (LR2_PPO_STREAMS=0): every launch runs alone, so a kernel trace "
                          "of this command shows exclusive per-kernel durations; the default schedule runs the critic beside the actor")
@@ -223,6 +224,35 @@ def main():
             prof_excl = ops.profile_stop()
     head_dt = max_over_ranks(head_dt)
 
+    # the same head-only step captured in a HIP graph (ppo.GraphedPPOStep: dropout seeds and learning rates in device memory),
+    # two-stream schedule and one-stream schedule: host cost of one replay on an empty queue, and the step time
+    graphed = None
+    if world == 1 and not a.no_graph:
+        def graph_measure():
+            gstep = ppo.GraphedPPOStep(margs, model, reward, opt, copt)
+            for i in range(3):                     # eager (sizes the workspaces), capture + replay, replay
+                gm = gstep(*data[i % n_batches])
+            fence()
+            t0 = time.perf_counter()
+            for i in range(3):
+                gstep(*data[i % n_batches])
+            host = (time.perf_counter() - t0) / 3 * 1e3
+            fence()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                gm = gstep(*data[i % n_batches])
+            fence()
+            dt = (time.perf_counter() - t0) / a.steps * 1e3
+            if not torch.isfinite(gm).all():
+                raise SystemExit("bench: non-finite PPO metrics in the graphed step")
+            gstep.release()
+            return {"host_enqueue_ms_per_step": round(host, 3), "ms_per_step": round(dt, 3)}
+        graphed = graph_measure()
+        with exclusive_launches():
+            graphed["one_stream"] = graph_measure()
+        graphed["note"] = ("head-only step as ONE hipGraphLaunch (inputs copied into static buffers + one 64-byte scalar store + "
+                           "replay); same bits as the eager step (tests/test_graph_gpu.py); `value` and head_only_* are the eager step")
+
     # ================= [B] the metric's own configuration: ViT-B/16 + RoBERTa-base in line (frozen), then the PPO step =================
     online = None
     if not a.no_online:
@@ -293,6 +323,7 @@ def main():
         "dtype": "f32 (GEMMs: split-bf16 x3 on MFMA, fp32 accumulate)" if a.passes == 3 else "bf16 inputs, fp32 accumulate (1 pass)",
         "data": "synthetic",
         "head_only_steps_per_sec": round(head_rate, 3), "head_only_ms_per_step": round(head_dt / a.steps * 1e3, 3),
+        "head_only_graph": graphed,
         "config": {"workload": workload, "batch_per_gpu": a.batch, "tags": a.tags, "global_batch": a.batch * world,
                    "parallelism": f"dp{world}", "schedule": sched, "items_per_sec": round(value * a.batch, 1),
                    "algorithmic_tflop_per_step": {"head": 3.44, "dual_encoder_forward": 18.96} if (a.batch, a.tags) == (32, 2) else None},
@@ -336,6 +367,9 @@ def main():
             rl["top_ms_per_step_note"] = "head-only step; exclusive durations: the instrumented warm-up step runs on one stream"
         rl["host_enqueue_ms_per_step"] = round(host_enqueue_ms, 3)
         rl["host_enqueue_note"] = "head-only step, 3 steps enqueued on an empty launch queue (no back-pressure from the GPU)"
+        if graphed is not None:
+            rl["host_enqueue_ms_per_step_graph"] = graphed["host_enqueue_ms_per_step"]
+            rl["host_enqueue_ms_per_step_graph_one_stream"] = graphed["one_stream"]["host_enqueue_ms_per_step"]
         out["roofline_hbm"] = rl
         if "roofline" not in out:
             out["roofline"] = rl

@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 14
+#define LR2_ABI_VERSION 15
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -65,6 +65,13 @@ typedef struct lr2_epilogue {
    * replaces: autograd of the bias of nn.Linear (tencentpretrain/layers/position_ffn.py:12-15, multi_headed_attn.py:55-76). */
   void* colsum;
   void* colsum_ws;
+  /* Device-resident dropout seed (HIP-graph capture of a training step: a seed passed by value would be frozen into the graph):
+   * when non-NULL, the mask stream's seed is *drop_seed_dev + drop_seed (device uint64, read by the kernel at run time);
+   * drop_site must then be below 65536. */
+  const void* drop_seed_dev;
+  /* Device-resident learning rate of the fused optimizer step (same reason: a scheduler changes it every step): when non-NULL the
+   * update uses *adam_lr_dev (device float) and adam_lr is ignored. */
+  const void* adam_lr_dev;
 } lr2_epilogue;
 
 /* C[M,N] = op(A).op(B), fp32 in / fp32 out, computed on bf16 MFMA with fp32 accumulation.
@@ -136,13 +143,14 @@ int lr2_layernorm_fwd(const void* x, const void* gamma, const void* beta, void* 
 /* LayerNorm backward, both semantics (mode / eps as in the forward).  dy uses the same (group, stride) row mapping as the forward output.
  * dx = LN'(dy) (+ resid_grad) -> dx (fp32); optional dxm_hi = bf16 planes of dropout_mask(dx)/(1-p) (the gradient of
  * y = dropout(a) + res with respect to a, finetune/xit.py:34,40; p = 0: planes of dx), the next GEMMs' operand.  dgamma/dbeta are accumulated per block
- * into partials [nblocks][2][D]; finish with lr2_colsum_partials_finish.
+ * into partials [nblocks][2][D]; finish with lr2_colsum_partials_finish.  drop_seed_dev (may be NULL): device uint64 added to drop_seed at run
+ * time, as in lr2_epilogue.
  * replaces: autograd of nn.LayerNorm + the in-place residual adds of finetune/xit.py:45-55,77-86, and of the
  * TencentPretrain LayerNorm (tencentpretrain/layers/layer_norm.py:16-21) in the encoder layers. */
-int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_stride, const void* x, const void* gamma,
-                      const void* mean, const void* rstd, const void* resid_grad, void* dx, void* dxm_hi,
-                      uint64_t dxm_lo_off, float drop_p, uint64_t drop_seed, uint32_t drop_site, void* partials,
-                      int nblocks, int rows, int D, int mode, float eps, void* stream);
+int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_stride, const void* x, const void* gamma, const void* mean,
+                      const void* rstd, const void* resid_grad, void* dx, void* dxm_hi, uint64_t dxm_lo_off, float drop_p,
+                      uint64_t drop_seed, uint32_t drop_site, const void* drop_seed_dev, void* partials, int nblocks, int rows, int D,
+                      int mode, float eps, void* stream);
 /* out[c] = sum_b partials[b*ld + c] for c < cols (deterministic second stage of column reductions). */
 int lr2_colsum_partials_finish(const void* partials, int nblocks, int cols, int ld, void* out, int accumulate,
                                void* stream);
@@ -270,7 +278,16 @@ typedef struct lr2_adamw_chunk {
  *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr * m/(sqrt(v)+eps); then p -= lr*wd*p.
  * replaces: tencentpretrain/utils/optimizers.py:344-402 (AdamW.step), including its decay-after-update order. */
 int lr2_adamw_multi(const lr2_adamw_chunk* table_dev, int n_chunks, double lr, double beta1, double beta2,
-                    double eps, void* stream);
+                    double eps, const void* lr_dev, void* stream);
+/* lr_dev (may be NULL): device float read by the kernel in place of `lr` -- a captured HIP graph of a training step then follows
+ * the scheduler without re-capture.
+ *
+ * The per-step scalars such a graph reads -- dst_dev[0..7] = seed (uint64, the dropout seed of lr2_epilogue.drop_seed_dev /
+ * lr2_layernorm_bwd), dst_dev[8 + 4 i ..] = lrs[i] (float, i < n_lrs <= 14) -- are written by ONE small kernel whose arguments
+ * carry the values: no host buffer has to outlive the call, so steps can be enqueued ahead of the device. */
+#define LR2_STEP_SCALARS_BYTES 64
+#define LR2_STEP_SCALARS_MAX_LRS 14
+int lr2_step_scalars_store(void* dst_dev, uint64_t seed, const float* lrs_host, int n_lrs, void* stream);
 
 /* Tokens -> embeddings: out[r,:] = word[src[r]] + pos[r % L] + seg_table[seg[r]].  Ids outside [0, vocab) / [0, n_seg) never
  * index memory: the row is taken from index 0 and *err_flag (device int, may be NULL) gets bit 0 (token) / bit 1 (segment)

@@ -19,7 +19,7 @@ _AB_LIB = os.environ.get("LR2_AB_LIB")     # tools/dbg only: load another build 
 SOURCES = ["gemm.hip", "gemm256.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
 
-ABI_VERSION = 14     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
+ABI_VERSION = 15     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
 
 _lock = threading.Lock()
 _lib = None
@@ -67,7 +67,7 @@ class Epilogue(C.Structure):
                 ("drop_p", C.c_float), ("drop_site", C.c_uint32), ("_pad", C.c_uint32), ("drop_seed", C.c_uint64),
                 ("adam_p", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("adam_lr", C.c_double),
                 ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
-                ("adam_weight_decay", C.c_double), ("colsum", C.c_void_p), ("colsum_ws", C.c_void_p)]
+                ("adam_weight_decay", C.c_double), ("colsum", C.c_void_p), ("colsum_ws", C.c_void_p), ("drop_seed_dev", C.c_void_p), ("adam_lr_dev", C.c_void_p)]
 
 
 class SplitChunk(C.Structure):
@@ -96,7 +96,7 @@ SIGNATURES = {
     "lr2_split_planes_t": [_P, _P, _U64, _I, _I, _P],
     "lr2_split_planes_multi": [_P, _I, _P],
     "lr2_layernorm_fwd": [_P, _P, _P, _P, _P, _U64, _P, _P, _I, _I, _F, _I, _I, _U64, _P],
-    "lr2_layernorm_bwd": [_P, _I, _U64, _P, _P, _P, _P, _P, _P, _P, _U64, _F, _U64, _U32, _P, _I, _I, _I, _I, _F, _P],
+    "lr2_layernorm_bwd": [_P, _I, _U64, _P, _P, _P, _P, _P, _P, _P, _U64, _F, _U64, _U32, _P, _P, _I, _I, _I, _I, _F, _P],
     "lr2_colsum_partials_finish": [_P, _I, _I, _I, _P, _I, _P],
     "lr2_colsum": [_P, _I, _U64, _I, _I, _I, _P, _I, _P, _P],
     "lr2_xattn_fwd": [_P, _P, _P, _P, _I, _U64, _I, _I, _I, _I, _I, _F, _P],
@@ -117,7 +117,8 @@ SIGNATURES = {
     "lr2_cls_scores_bwd": [_P, _P, _P, _P, _I, _I, _P],
     "lr2_nll_loss": [_P, _P, _I, _I, _P, _P, _P],
     "lr2_pair_hinge": [_P, _I, _F, _P, _P, _P],
-    "lr2_adamw_multi": [_P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _P],
+    "lr2_adamw_multi": [_P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P],
+    "lr2_step_scalars_store": [_P, _U64, _P, _I, _P],
     "lr2_text_embed": [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.c_int64, _I, _P, _P],
     "lr2_patchify_planes": [_P, _I, _P, _U64, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P],
     "lr2_ndcg": [_P, _P, _P, _P, _P, _I, _P, _I, _P],

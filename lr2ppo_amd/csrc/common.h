@@ -147,20 +147,43 @@ struct Epilogue {
   size_t lo_off;
   int ld_planes;
   int ld_resid, ld_aux, ld_out, ld_z;
-  int act;
-  int accumulate;
+  // one 32-bit word for the four switches (the kernels run at 100+ SGPRs: every scalar the epilogue keeps live counts)
+  uint32_t act : 4;          // 0 none, 1 GELU(erf), 2 multiply by GELU'(aux_z)
+  uint32_t accumulate : 1;
+  uint32_t stream_nt : 1;    // optimizer state p / m / v: non-temporal loads and stores (each byte is touched once per launch)
+  uint32_t seed_dev : 1;     // dev_scalar is the device-resident dropout seed (graph capture, see dropout_key_of)
+  uint32_t lr_dev : 1;       // dev_scalar is the device-resident learning rate of the fused AdamW step
+  uint32_t store_nt : 1;     // result stores (out / out_z / planes) non-temporal: large outputs that the next kernel streams from HBM anyway
   float alpha;
   float drop_scale;      // 1/(1-p) or 0 when dropout is off
-  uint32_t drop_thr;
-  uint64_t drop_key;
+  uint32_t drop_thr;     // bits 0-15: threshold; bits 16-31: the site id when the seed is device-resident
+  uint64_t drop_key;     // the mask key -- or, with drop_seed_dev set, the by-value part of the SEED (the key is formed in the kernel)
   float* adam_p;         // fused AdamW step on the result (weight-gradient GEMMs); NULL = store the result
   float* adam_m;
   float* adam_v;
   float adam_lr, adam_b1, adam_b2, adam_ob1, adam_ob2, adam_eps, adam_wd;
-  int stream_nt;         // optimizer state p / m / v: non-temporal loads and stores (each byte is touched once per launch)
   float* colsum_partial; // gemm256 TN: [splits * tiles_n][M] partial column sums of A (bias gradient), or NULL
-  int store_nt;          // result stores (out / out_z / planes) non-temporal: large outputs that the next kernel streams from HBM anyway
+  const void* dev_scalar;  // ONE pointer for the two device-resident scalars (a launch has dropout or the fused optimizer step, never
+                           // both): seed_dev -> uint64 seed (seed = *dev_scalar + drop_key, site = drop_thr >> 16); lr_dev -> float rate
 };
+// the mask key of an epilogue / kernel: precomputed on the host, or formed here when the seed lives in device memory
+// The device seed is read on the SCALAR path (s_load: one SGPR pair for the wave, the 64-bit multiply of the key on the SALU).  A
+// plain `*seed_dev` between the epilogue's global stores is compiled to a vector load per use (the compiler cannot prove the
+// word is not clobbered) and the key to VALU work; the same read of the learning rate cost the 8-wave kernel 28 spilled VGPRs.
+// Not volatile: identical reads merge.
+__device__ __forceinline__ uint64_t scalar_load_u64(const uint64_t* p) {
+  uint64_t v;
+  asm("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+  return v;
+}
+__device__ __forceinline__ float scalar_load_f32(const float* p) {
+  float v;
+  asm("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p));
+  return v;
+}
+__device__ __forceinline__ uint64_t dropout_key_of(const Epilogue& e) {
+  return e.seed_dev ? dropout_key(e.drop_key + scalar_load_u64((const uint64_t*)e.dev_scalar), e.drop_thr >> 16) : e.drop_key;
+}
 
 // One AdamW element update, TencentPretrain semantics (correct_bias=False; eps outside the sqrt; decay after the
 // update, on the updated weight).  Shared by adamw_kernel and the GEMM's fused epilogue so both give the same bits.

@@ -548,19 +548,29 @@ Epilogue to_device_epilogue(const lr2_epilogue* e) {
   d.ld_aux = e->ld_aux;
   d.ld_out = e->ld_out;
   d.ld_z = e->ld_z;
-  d.act = e->act;
-  d.accumulate = e->accumulate;
+  d.act = (uint32_t)e->act & 15u;
+  d.accumulate = e->accumulate ? 1u : 0u;
   d.alpha = e->alpha;
   if (e->drop_p > 0.f) {
     d.drop_scale = 1.0f / (1.0f - e->drop_p);
     d.drop_thr = dropout_threshold(e->drop_p);
     d.drop_key = (((uint64_t)e->drop_site) << 40) ^ (e->drop_seed * 0x9E3779B97F4A7C15ull);
+    if (e->drop_seed_dev) {          // key formed in the kernel: carry the seed's by-value part and the site
+      d.dev_scalar = e->drop_seed_dev;
+      d.seed_dev = 1;
+      d.drop_key = e->drop_seed;
+      d.drop_thr |= e->drop_site << 16;
+    }
   }
   if (e->adam_p) {  // same double -> float conversions as lr2_adamw_multi
     d.adam_p = (float*)e->adam_p;
     d.adam_m = (float*)e->adam_m;
     d.adam_v = (float*)e->adam_v;
     d.adam_lr = (float)e->adam_lr;
+    if (e->adam_lr_dev) {
+      d.dev_scalar = e->adam_lr_dev;
+      d.lr_dev = 1;
+    }
     d.adam_b1 = (float)e->adam_beta1;
     d.adam_b2 = (float)e->adam_beta2;
     d.adam_ob1 = (float)(1.0 - e->adam_beta1);
@@ -584,6 +594,8 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   if (!A || !B || M <= 0 || N <= 0 || K <= 0 || !epi || (!epi->out && !epi->out_hi && !epi->adam_p)) return LR2_ERR_ARG;
   if (epi->adam_p && (!epi->adam_m || !epi->adam_v || epi->out || epi->out_hi || epi->ld_out % 4)) return LR2_ERR_ARG;
   if (passes != 1 && passes != 3) return LR2_ERR_ARG;
+  if (epi->drop_seed_dev && epi->drop_site >= 65536u) return LR2_ERR_ARG;      // the site travels in 16 bits beside the threshold
+  if (epi->adam_p && epi->drop_p > 0.f) return LR2_ERR_ARG;                    // the update consumes the result: nothing to mask
   if (epi->colsum && (!trans_a || !trans_b || !epi->colsum_ws || (M % 4))) return LR2_ERR_ARG;   // weight-gradient form only
   const bool want256 = block_m == 256;
   if (block_m != 64) block_m = 128;

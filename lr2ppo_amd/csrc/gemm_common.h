@@ -115,7 +115,7 @@ __device__ __forceinline__ void epilogue_apply4(const Epilogue& e, float4 v, flo
   }
   if (e.drop_scale != 0.0f) {
     const uint64_t idx = (uint64_t)m * (uint64_t)N + (uint64_t)n;
-    v = dropout_apply4(e.drop_key, idx, e.drop_thr, e.drop_scale, v);     // idx = m * N + n: N and n are multiples of 4
+    v = dropout_apply4(dropout_key_of(e), idx, e.drop_thr & 0xFFFFu, e.drop_scale, v);   // idx = m * N + n, multiples of 4
   }
   if (e.act == 2) {
     const float4 z = L.s[0];
@@ -125,10 +125,11 @@ __device__ __forceinline__ void epilogue_apply4(const Epilogue& e, float4 v, flo
   if (NS == 3 && e.adam_p) {  // fused optimizer step
     const size_t off = (size_t)m * e.ld_out + n;
     float4 p = L.s[0], mm = L.s[SR], vv = L.s[SO];
-    adam_update(p.x, v.x, mm.x, vv.x, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
-    adam_update(p.y, v.y, mm.y, vv.y, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
-    adam_update(p.z, v.z, mm.z, vv.z, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
-    adam_update(p.w, v.w, mm.w, vv.w, e.adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
+const float adam_lr = e.lr_dev ? scalar_load_f32((const float*)e.dev_scalar) : e.adam_lr;
+        adam_update(p.x, v.x, mm.x, vv.x, adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
+    adam_update(p.y, v.y, mm.y, vv.y, adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
+    adam_update(p.z, v.z, mm.z, vv.z, adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
+    adam_update(p.w, v.w, mm.w, vv.w, adam_lr, e.adam_b1, e.adam_b2, e.adam_ob1, e.adam_ob2, e.adam_eps, e.adam_wd);
     if (e.stream_nt) { st4_nt(e.adam_p + off, p); st4_nt(e.adam_m + off, mm); st4_nt(e.adam_v + off, vv); }
     else { st4(e.adam_p + off, p); st4(e.adam_m + off, mm); st4(e.adam_v + off, vv); }
     return;

@@ -593,8 +593,9 @@ struct AdamChunk {
   float wd;
   float pad;
 };
-__global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict__ table, float lr, float b1, float b2,
-                                                    float ob1, float ob2, float eps) {
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict__ table, float lr_host, float b1, float b2,
+                                                    float ob1, float ob2, float eps, const float* __restrict__ lr_dev) {
+  const float lr = lr_dev ? scalar_load_f32(lr_dev) : lr_host;
   const AdamChunk c = table[blockIdx.x];
   const uint64_t n4 = c.count / 4;
   float4* p4 = reinterpret_cast<float4*>(c.p);
@@ -1042,13 +1043,30 @@ extern "C" int lr2_pair_hinge(const void* scores, int bs, float margin, void* lo
   CHECK_LAUNCH();
 }
 
+struct StepScalars {
+  uint64_t seed;
+  float lrs[LR2_STEP_SCALARS_MAX_LRS];
+};
+static_assert(sizeof(StepScalars) == LR2_STEP_SCALARS_BYTES, "step scalars layout");
+__global__ void step_scalars_kernel(StepScalars* __restrict__ dst, StepScalars v) {
+  if (threadIdx.x == 0) *dst = v;
+}
+extern "C" int lr2_step_scalars_store(void* dst_dev, uint64_t seed, const float* lrs_host, int n_lrs, void* stream) {
+  if (!dst_dev || n_lrs < 0 || n_lrs > LR2_STEP_SCALARS_MAX_LRS || (n_lrs && !lrs_host)) return LR2_ERR_ARG;
+  StepScalars v{};
+  v.seed = seed;
+  for (int i = 0; i < n_lrs; ++i) v.lrs[i] = lrs_host[i];
+  LR2_LAUNCH(step_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (StepScalars*)dst_dev, v);
+  CHECK_LAUNCH();
+}
+
 extern "C" int lr2_adamw_multi(const lr2_adamw_chunk* table_dev, int n_chunks, double lr, double beta1, double beta2,
-                               double eps, void* stream) {
+                               double eps, const void* lr_dev, void* stream) {
   static_assert(sizeof(lr2_adamw_chunk) == sizeof(AdamChunk), "chunk layout");
   if (!table_dev || n_chunks <= 0) return LR2_ERR_ARG;
   // (1 - beta) is formed in double like the reference's Python scalars, then rounded once to fp32
   LR2_LAUNCH(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)table_dev,
-                     (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps);
+                     (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (const float*)lr_dev);
   CHECK_LAUNCH();
 }
 

@@ -78,8 +78,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                             const float* __restrict__ resid_grad, float* __restrict__ dx_f32,
                                                             bf16_t* __restrict__ dxm_hi, size_t dxm_lo_off, float drop_scale, uint32_t drop_thr,
-                                                            uint64_t drop_key, float* __restrict__ partials, int rows, int D,
+                                                            uint64_t drop_key_host, const uint64_t* __restrict__ drop_seed_dev, uint64_t drop_seed,
+                                                            uint32_t drop_site, float* __restrict__ partials, int rows, int D,
                                                             int mode, float eps) {
+  const uint64_t drop_key = drop_seed_dev ? dropout_key(drop_seed + scalar_load_u64(drop_seed_dev), drop_site) : drop_key_host;
   __shared__ float red[4][2][MAXV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 dg[MAXV], db[MAXV], gam[MAXV];
@@ -227,8 +229,8 @@ extern "C" int lr2_layernorm_fwd(const void* x, const void* gamma, const void* b
 
 extern "C" int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_stride, const void* x, const void* gamma,
                                  const void* mean, const void* rstd, const void* resid_grad, void* dx, void* dxm_hi,
-                                 uint64_t dxm_lo_off, float drop_p, uint64_t drop_seed, uint32_t drop_site, void* partials,
-                                 int nblocks, int rows, int D, int mode, float eps, void* stream) {
+                                 uint64_t dxm_lo_off, float drop_p, uint64_t drop_seed, uint32_t drop_site, const void* drop_seed_dev,
+                                 void* partials, int nblocks, int rows, int D, int mode, float eps, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !partials || (!dx && !dxm_hi) || rows <= 0 || nblocks <= 0)
     return LR2_ERR_ARG;
   if (mode != 0 && mode != 1) return LR2_ERR_ARG;
@@ -244,7 +246,8 @@ extern "C" int lr2_layernorm_bwd(const void* dy, int group, uint64_t group_strid
   }
   LR2_LAUNCH(layernorm_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, group, group_stride,
              (const float*)x, (const float*)gamma, (const float*)mean, (const float*)rstd, (const float*)resid_grad,
-             (float*)dx, (bf16_t*)dxm_hi, (size_t)dxm_lo_off, scale, thr, key, (float*)partials, rows, D, mode, eps);
+             (float*)dx, (bf16_t*)dxm_hi, (size_t)dxm_lo_off, scale, thr, key, (const uint64_t*)drop_seed_dev, drop_seed, drop_site,
+             (float*)partials, rows, D, mode, eps);
   return lr2_launch_status(__func__);
 }
 

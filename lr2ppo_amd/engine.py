@@ -92,11 +92,15 @@ class Arena:
 class DropCfg:
     """Train-time dropout of one XiT block: three sites (attention out, FFN hidden, FFN out)."""
 
-    def __init__(self, p: float, seed: int, site_base: int):
-        self.p, self.seed, self.site_base = p, seed, site_base
+    def __init__(self, p: float, seed: int, site_base: int, seed_dev: Optional[torch.Tensor] = None):
+        self.p, self.seed, self.site_base, self.seed_dev = p, seed, site_base, seed_dev     # seed_dev: see ops.Drop
 
     def site(self, i: int) -> Optional[ops.Drop]:
-        return ops.Drop(self.p, self.seed, self.site_base + i) if self.p > 0 else None
+        return ops.Drop(self.p, self.seed, self.site_base + i, self.seed_dev) if self.p > 0 else None
+
+    def at(self, site_base: int) -> "DropCfg":
+        """The same mask stream at another site base (the tail block beside the trunk's)."""
+        return DropCfg(self.p, self.seed, site_base, self.seed_dev)
 
 
 class WeightPlanes:

@@ -437,7 +437,7 @@ class _TailHead(_Head):
             img_p = None
             drop = self._drop_cfg(0)
             g2 = engine.trad_trunk_forward(ws, P, W, text_p, bs * t_out, FEAT, save=save, drop=drop)
-            drop_t = engine.DropCfg(drop.p, drop.seed, 3) if drop else None
+            drop_t = drop.at(3) if drop else None
         elif save:
             # train mode: gather the inputs by index exactly like the reference (ppo.py:267-271), then run the trunk
             shared_in = engine._img_shared(img_emb)
@@ -453,11 +453,11 @@ class _TailHead(_Head):
             ops.split_planes(img_g, img_p)
             drop = self._drop_cfg(0)
             g2 = engine.trunk_forward(ws, P, W, text_p, img_p, bs, t_out, n_img, FEAT, save=True, drop=drop, img_shared=False)
-            drop_t = engine.DropCfg(drop.p, drop.seed, 3) if drop else None
+            drop_t = drop.at(3) if drop else None
         else:
             g2_all, drop = trunk_out if trunk_out is not None else self.trunk_no_grad(text_emb, img_emb)
             g2 = self._gather_trunk(g2_all, index, bs, tags_in, t_out)
-            drop_t = engine.DropCfg(drop.p, drop.seed, 3) if drop else None
+            drop_t = drop.at(3) if drop else None
         M = bs * t_out
         xin = ws.mat("xin", M, FEAT)
         ops.add_period_rows(g2, P["pos_emb.weight"], xin, rows=M, D=FEAT, period=t_out)
@@ -898,6 +898,90 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
         metrics.div_(dp.world)
         dist.all_reduce(metrics)
     return metrics
+
+
+class GraphedPPOStep:
+    """rollout_step + update_minibatch on one batch (the per-batch body of the reference's loop, finetune/ppo.py:844-883 then
+    :518-598) captured ONCE in a HIP graph and replayed: ~300 kernel launches, two streams and their joins become one
+    hipGraphLaunch, the host cost per step drops from ~4 ms to the cost of one small launch plus the replay.
+
+    What a graph would freeze is moved to device memory first: the dropout seeds (runtime.device_seed: every train-mode forward
+    inside draws *seed + i) and the learning rates (AdamW.use_device_lr) live in one 64-byte ops.StepScalars block that a single
+    small launch rewrites before each replay from the host's dropout counter and the schedulers' current rates.  Same kernels,
+    same order, same arguments otherwise: the step gives the bits of the eager step (tests/test_graph_gpu.py).
+
+    Call 1 runs eagerly (it sizes the workspaces), call 2 captures and replays, later calls replay.  Inputs are copied into
+    static buffers (pass the buffers themselves -- .text / .img / .tgts -- to skip the copies).  The returned metrics tensor is
+    static too: read it before the next call.  Single rank only: a captured step holds no collectives."""
+
+    def __init__(self, args, model, reward_model, optimizer, critic_optim):
+        if _DataParallel().active:
+            raise NotImplementedError("GraphedPPOStep: single rank only (the data-parallel step interleaves RCCL collectives)")
+        for o in (optimizer, critic_optim):
+            if not hasattr(o, "use_device_lr"):
+                raise TypeError("GraphedPPOStep needs lr2ppo_amd's AdamW (device-resident learning rates)")
+        self.args, self.model, self.reward_model, self.opt, self.copt = args, model, reward_model, optimizer, critic_optim
+        self.graph = None
+        self.calls = 0
+        self.draws = 0
+        self.text = self.img = self.tgts = self.metrics = self.scalars = None
+
+    def _setup(self, text, img, tgts):
+        dev = text.device
+        self.text, self.img, self.tgts = torch.empty_like(text), torch.empty_like(img), torch.empty_like(tgts)
+        self.scalars = ops.StepScalars(dev)
+        for o in (self.opt, self.copt):
+            o.use_device_lr([self.scalars.lr_tensor(self.scalars.new_lr()) for _ in o.param_groups])
+
+    def _store_scalars(self):
+        self.scalars.store(runtime.peek_drop_seed(), [g["lr"] for o in (self.opt, self.copt) for g in o.param_groups])
+
+    def _body(self):
+        self.model.eval()
+        rec = rollout_step(self.model, self.reward_model, self.text, self.img, self.tgts)
+        self.model.train()
+        return update_minibatch(self.args, self.model, self.opt, self.copt, rec)
+
+    def _traced_body(self):
+        with runtime.device_seed(self.scalars.seed) as ds:
+            out = self._body()
+        return out, ds.draws
+
+    def __call__(self, text, img, tgts):
+        if self.text is None:
+            self._setup(text, img, tgts)
+        for dst, src in ((self.text, text), (self.img, img), (self.tgts, tgts)):
+            if src is not dst:
+                if src.shape != dst.shape or src.dtype != dst.dtype:
+                    raise ValueError("GraphedPPOStep: batch shape changed (one graph per shape: build another GraphedPPOStep)")
+                dst.copy_(src)
+        self._store_scalars()
+        self.calls += 1
+        if self.graph is None and self.calls == 1:
+            self.metrics, self.draws = self._traced_body()              # eager, through the same device-resident scalars
+        elif self.graph is None:
+            engine._INPUT_PLANES.clear()       # the splits of the static inputs must be IN the graph, whatever the cache holds
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self.metrics, draws = self._traced_body()
+            if draws != self.draws:
+                raise RuntimeError("GraphedPPOStep: the captured step drew a different number of dropout seeds than the eager one")
+            self.graph = graph
+            graph.replay()
+        else:
+            self.graph.replay()
+            self.opt.count_replayed_step()
+            self.copt.count_replayed_step()
+        runtime.advance(self.draws)
+        return self.metrics
+
+    def release(self):
+        """Back to by-value learning rates; drops the graph and its static buffers."""
+        self.opt.use_device_lr(None)
+        self.copt.use_device_lr(None)
+        self.graph = None
+        self.text = self.img = self.tgts = self.metrics = self.scalars = None
+        self.calls = 0
 
 
 def train_model(args, model, optimizer, critic_optim, scheduler, critic_scheduler, memories, epoch):

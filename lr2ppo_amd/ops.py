@@ -108,11 +108,43 @@ def _chk_f32(*ts):
 
 
 class Drop:
-    """Dropout spec for one site: p, seed, site id (see csrc/common.h::dropout_keep)."""
-    __slots__ = ("p", "seed", "site")
+    """Dropout spec for one site: p, seed, site id (see csrc/common.h::dropout_keep).  seed_dev: int64[1] device tensor whose
+    value the kernels ADD to `seed` at run time (HIP-graph capture of a training step, StepScalars)."""
+    __slots__ = ("p", "seed", "site", "seed_dev")
 
-    def __init__(self, p: float, seed: int, site: int):
-        self.p, self.seed, self.site = float(p), int(seed), int(site)
+    def __init__(self, p: float, seed: int, site: int, seed_dev: Optional[torch.Tensor] = None):
+        self.p, self.seed, self.site, self.seed_dev = float(p), int(seed), int(site), seed_dev
+
+    def seed_dev_ptr(self):
+        return self.seed_dev.data_ptr() if self.seed_dev is not None else None
+
+
+class StepScalars:
+    """The per-step scalars of a captured training step, in device memory (lr2_step_scalars_store): the dropout seed and up to
+    14 learning rates.  store() is one small launch whose kernel arguments carry the values."""
+    MAX_LRS = 14
+
+    def __init__(self, device):
+        self.buf = torch.zeros(8, dtype=torch.int64, device=device)
+        self.seed = self.buf[0:1]
+        self._lr_view = self.buf.view(torch.float32)
+        self._lrs = (C.c_float * self.MAX_LRS)()
+        self.n_lrs = 0
+
+    def new_lr(self) -> int:
+        if self.n_lrs >= self.MAX_LRS:
+            raise ValueError("StepScalars holds at most 14 learning rates")
+        self.n_lrs += 1
+        return self.n_lrs - 1
+
+    def lr_tensor(self, slot: int) -> torch.Tensor:
+        return self._lr_view[2 + slot:3 + slot]
+
+    def store(self, seed: int, lrs):
+        for i, v in enumerate(lrs):
+            self._lrs[i] = v
+        _nat.check(_nat.lib().lr2_step_scalars_store(self.buf.data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF, self._lrs, len(lrs),
+                                                     _stream()), "lr2_step_scalars_store")
 
 
 class Planes:
@@ -211,9 +243,10 @@ def split_planes_multi(table_dev: torch.Tensor, n_chunks: int):
 class AdamArgs:
     """AdamW step fused into a weight-gradient GEMM (lr2_epilogue.adam_*): the GEMM result is the gradient of `p` and is
     consumed on the fly -- m, v, p are updated exactly as lr2_adamw_multi would, the gradient never reaches HBM."""
-    __slots__ = ("p", "m", "v", "lr", "beta1", "beta2", "eps", "weight_decay")
+    __slots__ = ("p", "m", "v", "lr", "beta1", "beta2", "eps", "weight_decay", "lr_dev")
 
-    def __init__(self, p, m, v, lr, beta1, beta2, eps, weight_decay):
+    def __init__(self, p, m, v, lr, beta1, beta2, eps, weight_decay, lr_dev: Optional[torch.Tensor] = None):
+        self.lr_dev = lr_dev        # float32[1] device tensor read by the kernel in place of lr (captured steps)
         _chk_f32(p, m, v)
         if not (p.is_contiguous() and m.is_contiguous() and v.is_contiguous() and p.shape == m.shape == v.shape):
             raise ValueError("AdamArgs: p, m, v must be contiguous and of one shape")
@@ -340,13 +373,14 @@ def gemm(a, b, out: Optional[torch.Tensor], M: int, N: int, K: int, *, trans_a=F
         e.out_hi, e.out_lo_off, e.ld_planes = out_planes.data_ptr(), out_planes.lo_off, out_planes.cols
     e.act, e.accumulate, e.alpha = act, 1 if accumulate else 0, alpha
     if drop is not None and drop.p > 0.0:
-        e.drop_p, e.drop_seed, e.drop_site = drop.p, drop.seed, drop.site
+        e.drop_p, e.drop_seed, e.drop_site, e.drop_seed_dev = drop.p, drop.seed, drop.site, drop.seed_dev_ptr()
     if adam is not None:
         if out is not None or out_planes is not None or adam.p.numel() != M * N or ld_out != N:
             raise ValueError("gemm(adam=...): the result is consumed by the update; p must be [M, N] and out/out_planes None")
         e.adam_p, e.adam_m, e.adam_v = adam.p.data_ptr(), adam.m.data_ptr(), adam.v.data_ptr()
         e.adam_lr, e.adam_beta1, e.adam_beta2 = adam.lr, adam.beta1, adam.beta2
         e.adam_eps, e.adam_weight_decay = adam.eps, adam.weight_decay
+        e.adam_lr_dev = adam.lr_dev.data_ptr() if adam.lr_dev is not None else None
     if colsum is not None:
         # weight-gradient form: colsum[m] = sum_k A[k, m] (the bias gradient) from the same launch (lr2_epilogue.colsum)
         _chk_f32(colsum, colsum_ws)
@@ -410,7 +444,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partials, dgamma, dbeta, *, rows
                              rstd.data_ptr(), _ptr(resid_grad), _ptr(dx),
                              dx_planes.data_ptr() if dx_planes is not None else None,
                              dx_planes.lo_off if dx_planes is not None else 0, p, seed, site,
-                             partials.data_ptr(), nb, rows, D, mode, eps, _stream())
+                             drop.seed_dev_ptr() if drop is not None else None, partials.data_ptr(), nb, rows, D, mode, eps, _stream())
     _nat.check(rc, "lr2_layernorm_bwd")
     if dbeta.data_ptr() == dgamma.data_ptr() + 4 * D:       # [d gamma | d beta] adjacent (flat gradient buffers): one finishing launch
         _nat.check(L.lr2_colsum_partials_finish(partials.data_ptr(), nb, 2 * D, 2 * D, dgamma.data_ptr(), 0, _stream()), "finish")
@@ -641,10 +675,10 @@ def pair_hinge(scores, loss_acc, dscores=None, *, bs, margin=1.0):
 
 
 def adamw_multi(table_dev: torch.Tensor, n_chunks: int, lr: float, beta1: float, beta2: float, eps: float,
-                n_params: int = 0):
+                n_params: int = 0, lr_dev: Optional[torch.Tensor] = None):
     with _Timed(f"adamw_{n_params}", 0.0, 28.0 * n_params):
-        _nat.check(_nat.lib().lr2_adamw_multi(table_dev.data_ptr(), n_chunks, lr, beta1, beta2, eps, _stream()),
-                   "lr2_adamw_multi")
+        _nat.check(_nat.lib().lr2_adamw_multi(table_dev.data_ptr(), n_chunks, lr, beta1, beta2, eps,
+                                              lr_dev.data_ptr() if lr_dev is not None else None, _stream()), "lr2_adamw_multi")
 
 
 def text_embed(src, seg, word, pos, seg_table, out, *, rows, L, D, err: Optional[torch.Tensor] = None):

@@ -37,6 +37,8 @@ class AdamW(Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
         self._tables = {}
         self._external = set()
+        self._external_seen = set()     # ids of parameters ever updated through external_update
+        self._lr_dev = None      # per group: float32[1] device tensor the kernels read the learning rate from (use_device_lr)
 
     def _ensure_state(self, p):
         st = self.state[p]
@@ -46,11 +48,26 @@ class AdamW(Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p.data)
         return st
 
+    def use_device_lr(self, tensors):
+        """tensors: one float32[1] device tensor per param group (ops.StepScalars.lr_tensor), or None to go back to by-value
+        learning rates.  While set, step() / external_update() launch kernels that read the rate from there -- a HIP graph
+        captured around them follows the scheduler; the CALLER stores group["lr"] there before every step."""
+        if tensors is not None and len(tensors) != len(self.param_groups):
+            raise ValueError("use_device_lr: one tensor per param group")
+        self._lr_dev = list(tensors) if tensors is not None else None
+
+    def count_replayed_step(self):
+        """Book-keeping of one step() that ran inside a replayed graph: per-parameter step counters and write marks."""
+        ps = [p for g in self.param_groups for p in g["params"] if p.grad is not None or id(p) in self._external_seen]
+        for p in ps:
+            self._ensure_state(p)["step"] += 1
+        ops.mark_params_written(ps)
+
     def external_update(self, p) -> "ops.AdamArgs":
         """Take parameter `p` out of the next step(): its update is done by a kernel that produces the gradient and
         applies this optimizer's rule in one pass (ops.gemm(adam=...), used for the 2 GB out_layer.fc1.weight).
         Returns the state tensors and the hyper-parameters the next step() would have used; p.grad is not read."""
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             if any(q is p for q in group["params"]):
                 break
         else:
@@ -62,8 +79,9 @@ class AdamW(Optimizer):
         st = self._ensure_state(p)
         st["step"] += 1
         self._external.add(id(p))
+        self._external_seen.add(id(p))
         return ops.AdamArgs(p.data, st["exp_avg"], st["exp_avg_sq"], group["lr"], group["betas"][0], group["betas"][1],
-                            group["eps"], group["weight_decay"])
+                            group["eps"], group["weight_decay"], lr_dev=self._lr_dev[gi] if self._lr_dev else None)
 
     def _table(self, gi: int, group):
         ps = [p for p in group["params"] if p.grad is not None and id(p) not in self._external]
@@ -121,7 +139,10 @@ class AdamW(Optimizer):
                 if group["weight_decay"] > 0.0 and step_size != group["lr"]:
                     # decay must use the raw lr (optimizers.py:399-400): run the decay-free update, then decay
                     raise NotImplementedError("correct_bias=True with weight decay is not used by LR2PPO")
-            ops.adamw_multi(table, n, step_size, beta1, beta2, group["eps"], n_params=n_params)
+            lr_dev = self._lr_dev[gi] if self._lr_dev else None
+            if lr_dev is not None and group["correct_bias"]:
+                raise NotImplementedError("device learning rates need correct_bias=False (what LR2PPO uses)")
+            ops.adamw_multi(table, n, step_size, beta1, beta2, group["eps"], n_params=n_params, lr_dev=lr_dev)
             ops.mark_params_written(ps)
         if self._external:          # parameters a fused kernel updated since the last step (external_update)
             ops.mark_params_written([p for g_ in self.param_groups for p in g_["params"] if id(p) in self._external])
