@@ -47,7 +47,14 @@ __device__ __forceinline__ float erf_fast(float x) {
   const float r = __builtin_fmaf(-(p * t), e, 1.0f);
   return __builtin_copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+// (three roundings, no contraction: the GEMM epilogue has more than one code path for the same element -- gemm_common.h's
+// fast path for interior tiles -- and the compiler must not fuse differently in each)
+__device__ __forceinline__ float gelu_erf(float x) {
+#pragma clang fp contract(off)
+  const float h = 0.5f * x;
+  const float c = 1.0f + erf_fast(x * 0.70710678118654752440f);
+  return h * c;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);

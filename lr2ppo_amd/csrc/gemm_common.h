@@ -87,6 +87,18 @@ struct EpiLoads {
 template <int NS>
 __device__ __forceinline__ void epilogue_load4(const Epilogue& e, EpiLoads<NS>& L, int m, int n) {
   constexpr int SR = NS == 3 ? 1 : 0, SO = NS == 3 ? 2 : 0;
+  if constexpr (NS == 1) {
+    // one request slot (the host sends a launch with two requests to an NS = 3 kernel): choose the source first and issue ONE
+    // load.  Three conditional loads into the same registers made the compiler wait (vmcnt(0): the previous slab's stores
+    // included) before each address computation, on top of the wait at the point of use.
+    const float* src = nullptr;
+    int ld = 0;
+    if (e.act == 2) { src = e.aux_z; ld = e.ld_aux; }
+    else if (e.resid) { src = e.resid; ld = e.ld_resid; }
+    else if (e.out && e.accumulate) { src = e.out; ld = e.ld_out; }
+    if (src) L.s[0] = ld4(src + (size_t)m * ld + n);
+    return;
+  }
   if (e.act == 2) L.s[0] = ld4(e.aux_z + (size_t)m * e.ld_aux + n);
   if (e.resid) L.s[SR] = ld4(e.resid + (size_t)m * e.ld_resid + n);
   if (NS == 3 && e.adam_p) {
@@ -104,11 +116,18 @@ __device__ __forceinline__ void epilogue_load4(const Epilogue& e, EpiLoads<NS>& 
     L.s[SO] = ld4(e.out + (size_t)m * e.ld_out + n);
   }
 }
+// alpha * v (+ bias): ONE fused multiply-add per element when there is a bias, written out so that every code path that forms
+// the same element (general / fast path, reducer) rounds the same way
+__device__ __forceinline__ float4 scale_bias4(const Epilogue& e, float4 v, float4 b) {
+  if (e.bias)
+    return make_float4(__builtin_fmaf(e.alpha, v.x, b.x), __builtin_fmaf(e.alpha, v.y, b.y), __builtin_fmaf(e.alpha, v.z, b.z),
+                       __builtin_fmaf(e.alpha, v.w, b.w));
+  return make_float4(e.alpha * v.x, e.alpha * v.y, e.alpha * v.z, e.alpha * v.w);
+}
 template <int NS>
 __device__ __forceinline__ void epilogue_apply4(const Epilogue& e, float4 v, float4 b, const EpiLoads<NS>& L, int m, int n, int N) {
   constexpr int SR = NS == 3 ? 1 : 0, SO = NS == 3 ? 2 : 0;
-  v.x *= e.alpha; v.y *= e.alpha; v.z *= e.alpha; v.w *= e.alpha;
-  if (e.bias) { v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+  v = scale_bias4(e, v, b);
   if (e.act == 1) {
     if (e.out_z) { if (e.store_nt) st4_nt(e.out_z + (size_t)m * e.ld_z + n, v); else st4(e.out_z + (size_t)m * e.ld_z + n, v); }
     v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
@@ -228,6 +247,61 @@ __device__ __forceinline__ void epilogue_to_slab(f32x4_t (&acc)[MI][NI], float* 
   slab_write_all<WN, MI, NI, HALF, 0, 0>(lds_addr(slab) + (uint32_t)((4 * gq * LDW + c16) * 4), acc);
 }
 
+// Fast path of the forward's two commonest forms -- (alpha * acc + bias) [-> GELU] -> bf16 hi/lo planes, nothing else -- on a
+// wave tile that lies inside the matrix: no range checks and no per-element switches, so the NP passes of a slab are ONE basic
+// block and the compiler interleaves their dependency chains (GELU is rcp + exp + a degree-4 polynomial per element; with two
+// waves per SIMD in the epilogue nothing else hides those latencies).  Same arithmetic, same order per element: same bits.
+template <int NP, int RPP, int ACT, bool NT>
+__device__ __forceinline__ void epilogue_planes_fast(const Epilogue& e, const float4 (&v)[NP], float4 b, int m0, int n) {
+  bf16_t* ph = e.out_hi + (size_t)m0 * e.ld_planes + n;
+  const size_t step = (size_t)RPP * e.ld_planes;
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    float4 x = v[pass];
+    x = scale_bias4(e, x, b);
+    if constexpr (ACT == 1) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
+    u32x2_t hv, lv;
+    split4(x, hv, lv);
+    bf16_t* p = ph + pass * step;
+    if constexpr (NT) {
+      __builtin_nontemporal_store(hv, reinterpret_cast<u32x2_t*>(p));
+      __builtin_nontemporal_store(lv, reinterpret_cast<u32x2_t*>(p + e.lo_off));
+    } else {
+      *reinterpret_cast<u32x2_t*>(p) = hv;
+      *reinterpret_cast<u32x2_t*>(p + e.lo_off) = lv;
+    }
+  }
+}
+
+// The other common form, same idea: (alpha * acc + bias) + residual -> fp32 (the attention-output and FFN-2 products in front of
+// a LayerNorm), optionally also as planes.  The residual rows were requested per pass before the transpose (epilogue_request).
+template <int NP, int RPP, int NS, bool PL, bool NT>
+__device__ __forceinline__ void epilogue_resid_fast(const Epilogue& e, const float4 (&v)[NP], float4 b, const EpiLoads<NS> (&L)[NP],
+                                                    int m0, int n) {
+  float* po = e.out + (size_t)m0 * e.ld_out + n;
+  const size_t step = (size_t)RPP * e.ld_out;
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    float4 x = scale_bias4(e, v[pass], b);
+    const float4 r = L[pass].s[NS == 3 ? 1 : 0];
+    x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
+    if constexpr (NT) st4_nt(po + pass * step, x);
+    else st4(po + pass * step, x);
+    if constexpr (PL) {
+      u32x2_t hv, lv;
+      split4(x, hv, lv);
+      bf16_t* p = e.out_hi + (size_t)(m0 + pass * RPP) * e.ld_planes + n;
+      if constexpr (NT) {
+        __builtin_nontemporal_store(hv, reinterpret_cast<u32x2_t*>(p));
+        __builtin_nontemporal_store(lv, reinterpret_cast<u32x2_t*>(p + e.lo_off));
+      } else {
+        *reinterpret_cast<u32x2_t*>(p) = hv;
+        *reinterpret_cast<u32x2_t*>(p + e.lo_off) = lv;
+      }
+    }
+  }
+}
+
 template <int WN, int HALF, int NS>
 __device__ __forceinline__ void epilogue_from_slab(const GemmParams& g, float* slab, int mw, int nw, int lane, float* partial,
                                                    float4 bias4, const EpiSlab<WN, NS>& S) {
@@ -241,6 +315,33 @@ __device__ __forceinline__ void epilogue_from_slab(const GemmParams& g, float* s
   slab_read_all<WN, NP, 0>(lds_addr(slab) + (uint32_t)((row0 * LDW + col) * 4), v);   // one row segment of 4 columns per lane
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  {
+    const Epilogue& e = g.epi;
+    const bool plain = !partial && e.out_hi && !e.out && !e.out_z && e.drop_scale == 0.0f && e.act != 2 && !e.resid && !e.adam_p;
+    if (plain && mw + 32 * HALF + 32 <= g.M && nw + WN <= g.N) {          // wave-uniform
+      const int m0 = mw + 32 * HALF + row0;
+      if (e.act == 1) {
+        if (e.store_nt) epilogue_planes_fast<NP, RPP, 1, true>(e, v, bias4, m0, n);
+        else epilogue_planes_fast<NP, RPP, 1, false>(e, v, bias4, m0, n);
+      } else {
+        if (e.store_nt) epilogue_planes_fast<NP, RPP, 0, true>(e, v, bias4, m0, n);
+        else epilogue_planes_fast<NP, RPP, 0, false>(e, v, bias4, m0, n);
+      }
+      return;
+    }
+    const bool with_resid = !partial && e.out && e.resid && !e.out_z && e.drop_scale == 0.0f && e.act == 0 && !e.accumulate && !e.adam_p;
+    if (with_resid && mw + 32 * HALF + 32 <= g.M && nw + WN <= g.N) {
+      const int m0 = mw + 32 * HALF + row0;
+      if (e.out_hi) {
+        if (e.store_nt) epilogue_resid_fast<NP, RPP, NS, true, true>(e, v, bias4, S.L, m0, n);
+        else epilogue_resid_fast<NP, RPP, NS, true, false>(e, v, bias4, S.L, m0, n);
+      } else {
+        if (e.store_nt) epilogue_resid_fast<NP, RPP, NS, false, true>(e, v, bias4, S.L, m0, n);
+        else epilogue_resid_fast<NP, RPP, NS, false, false>(e, v, bias4, S.L, m0, n);
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int pass = 0; pass < NP; ++pass) {
     const int m = mw + 32 * HALF + pass * RPP + row0;
@@ -282,6 +383,11 @@ __device__ __forceinline__ void epilogue_wave(const GemmParams& g, f32x4_t (&acc
     if (g.epi.bias && n < g.N) bias4 = ld4(g.epi.bias + n);
     if constexpr (PIPE) epilogue_request<WN, NS, 0>(g, first, mw, nw, lane);
   }
+  // The wait for the bias load belongs HERE, once, in code every lane passes.  Without this use the first reads of bias4 sit
+  // inside the slabs' range-checked (exec-masked) blocks, none of which dominates the next, so the compiler waits before each of
+  // them -- and with loads and stores on one in-order counter the only wait it can write there is vmcnt(0): every slab waited for
+  // the stores of the slab before it, one HBM write latency each (12 us of a 67-us K = 768 tile, tools/dbg/tile_contention.py).
+  asm volatile("" ::"v"(bias4.x), "v"(bias4.y), "v"(bias4.z), "v"(bias4.w));
   epilogue_pipeline<WM, WN, MI, NI, NS, 0, PIPE>(g, acc, slab, mw, nw, lane, partial, bias4, first);
 }
 
