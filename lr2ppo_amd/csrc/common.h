@@ -56,9 +56,10 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return h * c;
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
+#pragma clang fp contract(off)
   const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
-  return cdf + x * pdf;
+  return __builtin_fmaf(x, pdf, cdf);
 }
 
 // exp(x) as one multiply + v_exp_f32 (2^x, ~1 ulp): relative error <= 1e-7 + 6e-8 * |x| * log2(e) -- 1e-6 at x = -10, far

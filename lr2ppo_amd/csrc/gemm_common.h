@@ -247,50 +247,47 @@ __device__ __forceinline__ void epilogue_to_slab(f32x4_t (&acc)[MI][NI], float* 
   slab_write_all<WN, MI, NI, HALF, 0, 0>(lds_addr(slab) + (uint32_t)((4 * gq * LDW + c16) * 4), acc);
 }
 
-// Fast path of the forward's two commonest forms -- (alpha * acc + bias) [-> GELU] -> bf16 hi/lo planes, nothing else -- on a
-// wave tile that lies inside the matrix: no range checks and no per-element switches, so the NP passes of a slab are ONE basic
-// block and the compiler interleaves their dependency chains (GELU is rcp + exp + a degree-4 polynomial per element; with two
-// waves per SIMD in the epilogue nothing else hides those latencies).  Same arithmetic, same order per element: same bits.
-template <int NP, int RPP, int ACT, bool NT>
-__device__ __forceinline__ void epilogue_planes_fast(const Epilogue& e, const float4 (&v)[NP], float4 b, int m0, int n) {
-  bf16_t* ph = e.out_hi + (size_t)m0 * e.ld_planes + n;
-  const size_t step = (size_t)RPP * e.ld_planes;
+// Fast paths for a wave tile that lies inside the matrix.  The general path (epilogue_apply4) decides everything per element
+// group: range checks and a dozen wave-uniform switches cut each pass of a slab into many small basic blocks, and with two waves
+// per SIMD in the epilogue nothing hides the latencies inside one (GELU alone is rcp + exp + a degree-4 polynomial per element).
+// Here the form is decided ONCE per slab and the NP passes are one basic block: the compiler interleaves their dependency chains.
+// Same operations in the same order per element as epilogue_apply4: same bits (tools/dbg/epi_ab.py compares two builds).
+//   ACT 0 / 1 (GELU; Z: store the pre-activation) / 2 (multiply by GELU'(aux));  DROP: mask after the activation;
+//   RESID: add the residual row;  OUT: fp32 result;  PL: bf16 hi / lo planes result;  NT: non-temporal stores.
+template <int NP, int RPP, int NS, int ACT, bool Z, bool DROP, bool RESID, bool OUT, bool PL, bool NT>
+__device__ __forceinline__ void epilogue_fast(const Epilogue& e, const float4 (&v)[NP], float4 b, const EpiLoads<NS> (&L)[NP],
+                                              int m0, int n, int N) {
+  constexpr int SR = NS == 3 ? 1 : 0;
+  uint64_t key = 0;
+  if constexpr (DROP) key = dropout_key_of(e);
 #pragma unroll
   for (int pass = 0; pass < NP; ++pass) {
-    float4 x = v[pass];
-    x = scale_bias4(e, x, b);
-    if constexpr (ACT == 1) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
-    u32x2_t hv, lv;
-    split4(x, hv, lv);
-    bf16_t* p = ph + pass * step;
-    if constexpr (NT) {
-      __builtin_nontemporal_store(hv, reinterpret_cast<u32x2_t*>(p));
-      __builtin_nontemporal_store(lv, reinterpret_cast<u32x2_t*>(p + e.lo_off));
-    } else {
-      *reinterpret_cast<u32x2_t*>(p) = hv;
-      *reinterpret_cast<u32x2_t*>(p + e.lo_off) = lv;
-    }
-  }
-}
-
-// The other common form, same idea: (alpha * acc + bias) + residual -> fp32 (the attention-output and FFN-2 products in front of
-// a LayerNorm), optionally also as planes.  The residual rows were requested per pass before the transpose (epilogue_request).
-template <int NP, int RPP, int NS, bool PL, bool NT>
-__device__ __forceinline__ void epilogue_resid_fast(const Epilogue& e, const float4 (&v)[NP], float4 b, const EpiLoads<NS> (&L)[NP],
-                                                    int m0, int n) {
-  float* po = e.out + (size_t)m0 * e.ld_out + n;
-  const size_t step = (size_t)RPP * e.ld_out;
-#pragma unroll
-  for (int pass = 0; pass < NP; ++pass) {
+    const int m = m0 + pass * RPP;
     float4 x = scale_bias4(e, v[pass], b);
-    const float4 r = L[pass].s[NS == 3 ? 1 : 0];
-    x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
-    if constexpr (NT) st4_nt(po + pass * step, x);
-    else st4(po + pass * step, x);
+    if constexpr (ACT == 1) {
+      if constexpr (Z) {
+        if constexpr (NT) st4_nt(e.out_z + (size_t)m * e.ld_z + n, x);
+        else st4(e.out_z + (size_t)m * e.ld_z + n, x);
+      }
+      x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w);
+    }
+    if constexpr (DROP) x = dropout_apply4(key, (uint64_t)m * (uint64_t)N + (uint64_t)n, e.drop_thr & 0xFFFFu, e.drop_scale, x);
+    if constexpr (ACT == 2) {
+      const float4 z = L[pass].s[0];
+      x.x *= gelu_erf_grad(z.x); x.y *= gelu_erf_grad(z.y); x.z *= gelu_erf_grad(z.z); x.w *= gelu_erf_grad(z.w);
+    }
+    if constexpr (RESID) {
+      const float4 r = L[pass].s[SR];
+      x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
+    }
+    if constexpr (OUT) {
+      if constexpr (NT) st4_nt(e.out + (size_t)m * e.ld_out + n, x);
+      else st4(e.out + (size_t)m * e.ld_out + n, x);
+    }
     if constexpr (PL) {
       u32x2_t hv, lv;
       split4(x, hv, lv);
-      bf16_t* p = e.out_hi + (size_t)(m0 + pass * RPP) * e.ld_planes + n;
+      bf16_t* p = e.out_hi + (size_t)m * e.ld_planes + n;
       if constexpr (NT) {
         __builtin_nontemporal_store(hv, reinterpret_cast<u32x2_t*>(p));
         __builtin_nontemporal_store(lv, reinterpret_cast<u32x2_t*>(p + e.lo_off));
@@ -300,6 +297,37 @@ __device__ __forceinline__ void epilogue_resid_fast(const Epilogue& e, const flo
       }
     }
   }
+}
+
+// -> true when one of the instantiated forms took the slab.  WIDE: the full list (the 256 x 256 kernels, where the encoders'
+// training products run); the general kernel family gets the inference forms only (fifty instantiations: compile time).
+template <int NP, int RPP, int NS, bool WIDE>
+__device__ __forceinline__ bool epilogue_fast_dispatch(const Epilogue& e, const float4 (&v)[NP], float4 b,
+                                                       const EpiLoads<NS> (&L)[NP], int m0, int n, int N) {
+  if (e.adam_p || e.accumulate) return false;
+  const int act = e.act;
+  const bool z = e.out_z != nullptr, drop = e.drop_scale != 0.0f, resid = e.resid != nullptr, out = e.out != nullptr,
+             pl = e.out_hi != nullptr;
+  if (z && act != 1) return false;
+#define LR2_FAST(ACT, Z, DROP, RESID, OUT, PL)                                                                         \
+  if (act == ACT && z == Z && drop == DROP && resid == RESID && out == OUT && pl == PL) {                             \
+    if (e.store_nt) epilogue_fast<NP, RPP, NS, ACT, Z, DROP, RESID, OUT, PL, true>(e, v, b, L, m0, n, N);             \
+    else epilogue_fast<NP, RPP, NS, ACT, Z, DROP, RESID, OUT, PL, false>(e, v, b, L, m0, n, N);                        \
+    return true;                                                                                                     \
+  }
+  LR2_FAST(0, false, false, false, false, true)     // bias -> planes (QKV)
+  LR2_FAST(1, false, false, false, false, true)     // bias, GELU -> planes (FFN-1, inference)
+  LR2_FAST(0, false, false, true, true, false)      // bias + residual -> fp32 (attention output, FFN-2)
+  if constexpr (WIDE) {
+    LR2_FAST(1, true, false, false, false, true)    // FFN-1, training: pre-activation kept
+    LR2_FAST(2, false, false, false, false, true)   // FFN-2 input gradient: GELU' -> planes
+    LR2_FAST(0, false, true, true, true, false)     // training: dropout, + residual -> fp32
+    LR2_FAST(0, false, false, false, true, false)   // plain fp32 result (input gradients)
+    LR2_FAST(0, false, false, true, true, true)     // + residual -> fp32 and planes
+    LR2_FAST(0, false, true, false, false, true)    // dropout -> planes
+  }
+#undef LR2_FAST
+  return false;
 }
 
 template <int WN, int HALF, int NS>
@@ -315,32 +343,8 @@ __device__ __forceinline__ void epilogue_from_slab(const GemmParams& g, float* s
   slab_read_all<WN, NP, 0>(lds_addr(slab) + (uint32_t)((row0 * LDW + col) * 4), v);   // one row segment of 4 columns per lane
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-  {
-    const Epilogue& e = g.epi;
-    const bool plain = !partial && e.out_hi && !e.out && !e.out_z && e.drop_scale == 0.0f && e.act != 2 && !e.resid && !e.adam_p;
-    if (plain && mw + 32 * HALF + 32 <= g.M && nw + WN <= g.N) {          // wave-uniform
-      const int m0 = mw + 32 * HALF + row0;
-      if (e.act == 1) {
-        if (e.store_nt) epilogue_planes_fast<NP, RPP, 1, true>(e, v, bias4, m0, n);
-        else epilogue_planes_fast<NP, RPP, 1, false>(e, v, bias4, m0, n);
-      } else {
-        if (e.store_nt) epilogue_planes_fast<NP, RPP, 0, true>(e, v, bias4, m0, n);
-        else epilogue_planes_fast<NP, RPP, 0, false>(e, v, bias4, m0, n);
-      }
-      return;
-    }
-    const bool with_resid = !partial && e.out && e.resid && !e.out_z && e.drop_scale == 0.0f && e.act == 0 && !e.accumulate && !e.adam_p;
-    if (with_resid && mw + 32 * HALF + 32 <= g.M && nw + WN <= g.N) {
-      const int m0 = mw + 32 * HALF + row0;
-      if (e.out_hi) {
-        if (e.store_nt) epilogue_resid_fast<NP, RPP, NS, true, true>(e, v, bias4, S.L, m0, n);
-        else epilogue_resid_fast<NP, RPP, NS, true, false>(e, v, bias4, S.L, m0, n);
-      } else {
-        if (e.store_nt) epilogue_resid_fast<NP, RPP, NS, false, true>(e, v, bias4, S.L, m0, n);
-        else epilogue_resid_fast<NP, RPP, NS, false, false>(e, v, bias4, S.L, m0, n);
-      }
-      return;
-    }
+  if (!partial && mw + 32 * HALF + 32 <= g.M && nw + WN <= g.N) {          // wave-uniform: the slab lies inside the matrix
+    if (epilogue_fast_dispatch<NP, RPP, NS, NS == 1>(g.epi, v, bias4, S.L, mw + 32 * HALF + row0, n, g.N)) return;
   }
 #pragma unroll
   for (int pass = 0; pass < NP; ++pass) {

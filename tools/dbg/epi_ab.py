@@ -32,6 +32,9 @@ def main():
             "FFN2 bias + resid -> fp32": lambda: ops.gemm(x3072, w_f2, o768, M, 768, 3072, bias=b768, resid=resid, block_m=256, splits=1),
             "FFN2 dgrad GELU' -> planes": lambda: ops.gemm(x768, w_f1, None, M, 3072, 768, act=2, aux_z=z3072, out_planes=p3072, block_m=256, splits=1),
             "proj dgrad accumulate": lambda: ops.gemm(x768, w_proj, o768, M, 768, 768, accumulate=True, block_m=256, splits=1),
+            "FFN1 bias + GELU + z -> planes (train)": lambda: ops.gemm(x768, w_f1, None, M, 3072, 768, bias=b3072, act=1, out_z=z3072, out_planes=p3072, block_m=256, splits=1),
+            "proj bias + dropout + resid (train)": lambda: ops.gemm(x768, w_proj, o768, M, 768, 768, bias=b768, resid=resid, drop=ops.Drop(0.1, 77, 3), block_m=256, splits=1),
+            "FFN1 dgrad plain -> fp32": lambda: ops.gemm(x3072, w_f2, o768, M, 768, 3072, block_m=256, splits=1),
             "FFN2 bias + resid -> fp32 + planes": lambda: ops.gemm(x3072, w_f2, o768, M, 768, 3072, bias=b768, resid=resid, out_planes=p768, block_m=256, splits=1),
         }
         for name, fn in cases.items():
