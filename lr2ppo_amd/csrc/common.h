@@ -103,6 +103,7 @@ __device__ __forceinline__ void dropout_keep4(uint64_t key, uint64_t idx4, uint3
   keep[3] = (h1 >> 16) >= thr16;
 }
 __device__ __forceinline__ float4 dropout_apply4(uint64_t key, uint64_t idx4, uint32_t thr16, float scale, float4 v) {
+#pragma clang fp contract(off)
   bool k[4];
   dropout_keep4(key, idx4, thr16, k);
   return make_float4(k[0] ? v.x * scale : 0.f, k[1] ? v.y * scale : 0.f, k[2] ? v.z * scale : 0.f, k[3] ? v.w * scale : 0.f);
@@ -127,7 +128,10 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // fp32 x 4 -> packed bf16 hi and lo pairs (x = hi + lo, hi = bf16(x), lo = bf16(x - hi)): the operand format of the
 // split-bf16 GEMM.  Element order in memory = argument order.
+// (no contraction: lo must be the residual of the ROUNDED fp32 value -- a multiply in front of the call fused into the subtraction
+// would give planes that differ from the fp32 tensor stored beside them, and differently in each code path)
 __device__ __forceinline__ void split4(float4 v, u32x2_t& hv, u32x2_t& lv) {
+#pragma clang fp contract(off)
   const uint32_t h01 = cvt_pk_bf16(v.x, v.y), h23 = cvt_pk_bf16(v.z, v.w);
   const uint32_t l01 = cvt_pk_bf16(v.x - __uint_as_float(h01 << 16), v.y - __uint_as_float(h01 & 0xffff0000u));
   const uint32_t l23 = cvt_pk_bf16(v.z - __uint_as_float(h23 << 16), v.w - __uint_as_float(h23 & 0xffff0000u));

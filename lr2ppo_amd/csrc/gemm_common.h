@@ -126,6 +126,7 @@ __device__ __forceinline__ float4 scale_bias4(const Epilogue& e, float4 v, float
 }
 template <int NS>
 __device__ __forceinline__ void epilogue_apply4(const Epilogue& e, float4 v, float4 b, const EpiLoads<NS>& L, int m, int n, int N) {
+#pragma clang fp contract(off)      // one rounding per written operation, whatever path forms the element (see epilogue_fast)
   constexpr int SR = NS == 3 ? 1 : 0, SO = NS == 3 ? 2 : 0;
   v = scale_bias4(e, v, b);
   if (e.act == 1) {
@@ -257,6 +258,7 @@ __device__ __forceinline__ void epilogue_to_slab(f32x4_t (&acc)[MI][NI], float* 
 template <int NP, int RPP, int NS, int ACT, bool Z, bool DROP, bool RESID, bool OUT, bool PL, bool NT>
 __device__ __forceinline__ void epilogue_fast(const Epilogue& e, const float4 (&v)[NP], float4 b, const EpiLoads<NS> (&L)[NP],
                                               int m0, int n, int N) {
+#pragma clang fp contract(off)
   constexpr int SR = NS == 3 ? 1 : 0;
   uint64_t key = 0;
   if constexpr (DROP) key = dropout_key_of(e);
@@ -299,8 +301,9 @@ __device__ __forceinline__ void epilogue_fast(const Epilogue& e, const float4 (&
   }
 }
 
-// -> true when one of the instantiated forms took the slab.  WIDE: the full list (the 256 x 256 kernels, where the encoders'
-// training products run); the general kernel family gets the inference forms only (fifty instantiations: compile time).
+// -> true when one of the instantiated forms took the slab.  WIDE: the full list (the 256 x 256 kernels and the 8-wave kernels,
+// where the encoders' and the heads' training products run); the rest of the general kernel family gets the inference forms
+// only (fifty instantiations: compile time).
 template <int NP, int RPP, int NS, bool WIDE>
 __device__ __forceinline__ bool epilogue_fast_dispatch(const Epilogue& e, const float4 (&v)[NP], float4 b,
                                                        const EpiLoads<NS> (&L)[NP], int m0, int n, int N) {
@@ -325,12 +328,14 @@ __device__ __forceinline__ bool epilogue_fast_dispatch(const Epilogue& e, const 
     LR2_FAST(0, false, false, false, true, false)   // plain fp32 result (input gradients)
     LR2_FAST(0, false, false, true, true, true)     // + residual -> fp32 and planes
     LR2_FAST(0, false, true, false, false, true)    // dropout -> planes
+    LR2_FAST(1, true, true, false, false, true)     // XiT FFN-1, training: pre-activation kept, GELU, dropout -> planes
+    LR2_FAST(2, false, true, false, false, true)    // XiT FFN-2 input gradient: dropout mask, GELU' -> planes
   }
 #undef LR2_FAST
   return false;
 }
 
-template <int WN, int HALF, int NS>
+template <int WN, int HALF, int NS, bool WIDE>
 __device__ __forceinline__ void epilogue_from_slab(const GemmParams& g, float* slab, int mw, int nw, int lane, float* partial,
                                                    float4 bias4, const EpiSlab<WN, NS>& S) {
   constexpr int LDW = WN + 4;
@@ -343,8 +348,9 @@ __device__ __forceinline__ void epilogue_from_slab(const GemmParams& g, float* s
   slab_read_all<WN, NP, 0>(lds_addr(slab) + (uint32_t)((row0 * LDW + col) * 4), v);   // one row segment of 4 columns per lane
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-  if (!partial && mw + 32 * HALF + 32 <= g.M && nw + WN <= g.N) {          // wave-uniform: the slab lies inside the matrix
-    if (epilogue_fast_dispatch<NP, RPP, NS, NS == 1>(g.epi, v, bias4, S.L, mw + 32 * HALF + row0, n, g.N)) return;
+  // (LR2_GEMM_ABLATE & 256 switches the fast forms off: tools/dbg/fuzz_epilogue.py compares the two paths bit for bit)
+  if (!partial && !(g.ablate & 256) && mw + 32 * HALF + 32 <= g.M && nw + WN <= g.N) {   // wave-uniform: the slab lies inside the matrix
+    if (epilogue_fast_dispatch<NP, RPP, NS, WIDE>(g.epi, v, bias4, S.L, mw + 32 * HALF + row0, n, g.N)) return;
   }
 #pragma unroll
   for (int pass = 0; pass < NP; ++pass) {
@@ -359,7 +365,7 @@ __device__ __forceinline__ void epilogue_from_slab(const GemmParams& g, float* s
 // PIPE: request slab h+1's HBM operands before slab h's stores (after slab h's accumulators have moved to LDS, so the
 // register peak is acc - 32 + 3 x 32 for NS = 1).  Kernels that keep up to three requests per element (NS = 3) and run
 // several workgroups per CU request per slab instead: their register budget decides their occupancy.
-template <int WM, int WN, int MI, int NI, int NS, int HALF, bool PIPE>
+template <int WM, int WN, int MI, int NI, int NS, int HALF, bool PIPE, bool WIDE>
 __device__ __forceinline__ void epilogue_pipeline(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
                                                   int lane, float* partial, float4 bias4, EpiSlab<WN, NS>& cur) {
   if constexpr (!PIPE) {
@@ -370,12 +376,12 @@ __device__ __forceinline__ void epilogue_pipeline(const GemmParams& g, f32x4_t (
   if constexpr (PIPE && HALF + 1 < WM / 32) {
     if (!partial) epilogue_request<WN, NS, HALF + 1>(g, next, mw, nw, lane);
   }
-  epilogue_from_slab<WN, HALF, NS>(g, slab, mw, nw, lane, partial, bias4, cur);
+  epilogue_from_slab<WN, HALF, NS, WIDE>(g, slab, mw, nw, lane, partial, bias4, cur);
   if constexpr (HALF + 1 < WM / 32)
-    epilogue_pipeline<WM, WN, MI, NI, NS, HALF + 1, PIPE>(g, acc, slab, mw, nw, lane, partial, bias4, PIPE ? next : cur);
+    epilogue_pipeline<WM, WN, MI, NI, NS, HALF + 1, PIPE, WIDE>(g, acc, slab, mw, nw, lane, partial, bias4, PIPE ? next : cur);
 }
 
-template <int WM, int WN, int MI, int NI, int NS = 3>
+template <int WM, int WN, int MI, int NI, int NS = 3, bool WIDE = (NS == 1)>
 __device__ __forceinline__ void epilogue_wave(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
                                               int lane, float* partial) {
   static_assert(WM == 32 || WM == 64 || WM == 128, "wave tile rows");
@@ -392,16 +398,16 @@ __device__ __forceinline__ void epilogue_wave(const GemmParams& g, f32x4_t (&acc
   // them -- and with loads and stores on one in-order counter the only wait it can write there is vmcnt(0): every slab waited for
   // the stores of the slab before it, one HBM write latency each (12 us of a 67-us K = 768 tile, tools/dbg/tile_contention.py).
   asm volatile("" ::"v"(bias4.x), "v"(bias4.y), "v"(bias4.z), "v"(bias4.w));
-  epilogue_pipeline<WM, WN, MI, NI, NS, 0, PIPE>(g, acc, slab, mw, nw, lane, partial, bias4, first);
+  epilogue_pipeline<WM, WN, MI, NI, NS, 0, PIPE, WIDE>(g, acc, slab, mw, nw, lane, partial, bias4, first);
 }
 
 // Fused AdamW epilogue: the weight, exp_avg and exp_avg_sq vectors of all 32 rows of a slab are requested BEFORE the
 // accumulators are transposed through LDS (24 independent 16-B loads per lane in flight; with the loads issued one
 // slab pass at a time the 12 GB p/m/v stream of out_layer.fc1 would be latency-bound at ~3 TB/s).
-template <int WM, int WN, int MI, int NI>
+template <int WM, int WN, int MI, int NI, bool WIDE = false>
 __device__ __forceinline__ void epilogue_wave_adam(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw,
                                                    int nw, int lane) {
-  epilogue_wave<WM, WN, MI, NI>(g, acc, slab, mw, nw, lane, nullptr);
+  epilogue_wave<WM, WN, MI, NI, 3, WIDE>(g, acc, slab, mw, nw, lane, nullptr);
 }
 
 }  // namespace lr2gemm

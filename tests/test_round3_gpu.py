@@ -551,3 +551,16 @@ def test_vit_l14_full_depth_forward_and_gradients_match_oracle(dev):
         ref_g = pg[name].grad
         rel = float((named[name].grad.cpu().double() - ref_g.double()).norm() / ref_g.double().norm())
         assert rel < REL, (name, rel)
+
+
+def test_gemm_epilogue_fast_forms_equal_the_general_path_bit_for_bit(dev):
+    """Slabs inside the matrix take a straight-line form of the epilogue (gemm_common.h::epilogue_fast); slabs across the edge, and
+    every slab under LR2_GEMM_ABLATE=256, the per-element general path.  Same bits: 120 random products over every instantiated form
+    (and two that are not), both kernel families, run in two child processes and compared by hash."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dbg", "fuzz_epilogue.py"), "--n", "120", "--seed", "11"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "120 cases, 0 differ" in r.stdout
