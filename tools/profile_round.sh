@@ -13,28 +13,28 @@ S="python3 $R/tools/rocprof_summary.py"
 # bench.py runs W warm-up + 3 host-enqueue + K timed steps, and (default schedule only) 1 + 4 single-stream steps for the
 # exclusive timing of the dominant launch: 2 + 3 + 8 + 5 = 18 steps in the default trace, 13 in the --serial-streams one.
 echo "== warm-up (discarded: the first process on a fresh box pages the image in and finds the chip cold)"
-python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-online > /dev/null 2>&1
+python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-graph --no-online > /dev/null 2>&1
 echo "== kernel trace of the bench, ONE stream (exclusive per-kernel durations: what roofline.avg_launch_ms must agree with)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online --serial-streams > $O/bench_under_kernel_trace_serial.json 2> $O/kts.err || exit 1
-$S kernel-trace $O/kts --steps 13 --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online --serial-streams ($TAG; 13 PPO steps, one HIP stream)" --md $O/${TAG}_bench_kernel_trace_serial.md --json $O/${TAG}_bench_kernel_trace_serial.json || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kts -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-graph --no-online --serial-streams > $O/bench_under_kernel_trace_serial.json 2> $O/kts.err || exit 1
+$S kernel-trace $O/kts --steps 13 --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-graph --no-online --serial-streams ($TAG; 13 PPO steps, one HIP stream)" --md $O/${TAG}_bench_kernel_trace_serial.md --json $O/${TAG}_bench_kernel_trace_serial.json || exit 1
 rm -rf $O/kts
 echo "== plain bench on the same box, right after the exclusive trace"
-python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/${TAG}_bench_same_box.json 2> $O/bench.err
+python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-extras > $O/${TAG}_bench_same_box.json 2> $O/bench.err
 echo "== kernel trace of the bench, default two-stream schedule (overlapped durations: roofline.in_timed_region)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online > $O/bench_under_kernel_trace.json 2> $O/kt.err || exit 1
-$S kernel-trace $O/kt --steps 18 --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-online ($TAG; 18 PPO steps: 13 on two streams, 5 on one)" --md $O/${TAG}_bench_kernel_trace.md --json $O/${TAG}_bench_kernel_trace.json || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-graph --no-online > $O/bench_under_kernel_trace.json 2> $O/kt.err || exit 1
+$S kernel-trace $O/kt --steps 18 --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-graph --no-online ($TAG; 18 PPO steps: 13 on two streams, 5 on one)" --md $O/${TAG}_bench_kernel_trace.md --json $O/${TAG}_bench_kernel_trace.json || exit 1
 rm -rf $O/kt
 echo "== kernel trace of the VALUE loop (frames + ids -> ViT-B/16 + RoBERTa-base -> PPO step), one stream: head-only loop (2 + 3 + 8 steps) then the composed loop (2 + 8 steps)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktv -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --serial-streams > $O/${TAG}_bench_value_under_kernel_trace_serial.json 2> $O/ktv.err || exit 1
-$S kernel-trace $O/ktv --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extras --serial-streams ($TAG; 13 head-only PPO steps + 10 composed steps = 10 dual-encoder forwards + 10 PPO steps, one HIP stream)" --md $O/${TAG}_bench_value_kernel_trace_serial.md --json $O/${TAG}_bench_value_kernel_trace_serial.json || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktv -- python3 $R/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-graph --no-extras --serial-streams > $O/${TAG}_bench_value_under_kernel_trace_serial.json 2> $O/ktv.err || exit 1
+$S kernel-trace $O/ktv --title "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-graph --no-extras --serial-streams ($TAG; 13 head-only PPO steps + 10 composed steps = 10 dual-encoder forwards + 10 PPO steps, one HIP stream)" --md $O/${TAG}_bench_value_kernel_trace_serial.md --json $O/${TAG}_bench_value_kernel_trace_serial.json || exit 1
 rm -rf $O/ktv
 echo "== FETCH_SIZE pass"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile > /dev/null 2> $O/fetch.err || exit 1
-$S pmc $O/fetch --title "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile ($TAG)" --md $O/${TAG}_bench_pmc_fetch.md --json $O/${TAG}_bench_pmc_fetch.json || exit 1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-online --no-profile > /dev/null 2> $O/fetch.err || exit 1
+$S pmc $O/fetch --title "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-online --no-profile ($TAG)" --md $O/${TAG}_bench_pmc_fetch.md --json $O/${TAG}_bench_pmc_fetch.json || exit 1
 rm -rf $O/fetch
 echo "== WRITE_SIZE pass"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile > /dev/null 2> $O/write.err || exit 1
-$S pmc $O/write --title "rocprofv3 --kernel-trace --pmc WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile ($TAG)" --md $O/${TAG}_bench_pmc_write.md --json $O/${TAG}_bench_pmc_write.json || exit 1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-online --no-profile > /dev/null 2> $O/write.err || exit 1
+$S pmc $O/write --title "rocprofv3 --kernel-trace --pmc WRITE_SIZE -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-online --no-profile ($TAG)" --md $O/${TAG}_bench_pmc_write.md --json $O/${TAG}_bench_pmc_write.json || exit 1
 rm -rf $O/write
 echo "== encoder forward: kernel trace"
 rocprofv3 --kernel-trace --output-format csv -d $O/enc_kt -- python3 $R/tools/encoder_bench.py --ppo-shapes --iters 3 > $O/encoder_under_kernel_trace.txt 2> $O/enc_kt.err || exit 1
