@@ -301,10 +301,10 @@ __device__ __forceinline__ void epilogue_fast(const Epilogue& e, const float4 (&
   }
 }
 
-// -> true when one of the instantiated forms took the slab.  WIDE: the full list (the 256 x 256 kernels and the 8-wave kernels,
-// where the encoders' and the heads' training products run); the rest of the general kernel family gets the inference forms
-// only (fifty instantiations: compile time).
-template <int NP, int RPP, int NS, bool WIDE>
+// -> true when one of the instantiated forms took the slab.  WIDE 2: the full list (the 256 x 256 kernels, where the encoders'
+// training products run); 1: the 8-wave kernels (the heads' M = 12 544 products); 0: the rest of the general kernel family, the
+// inference forms only (fifty instantiations: compile time).
+template <int NP, int RPP, int NS, int WIDE>
 __device__ __forceinline__ bool epilogue_fast_dispatch(const Epilogue& e, const float4 (&v)[NP], float4 b,
                                                        const EpiLoads<NS> (&L)[NP], int m0, int n, int N) {
   if (e.adam_p || e.accumulate) return false;
@@ -321,13 +321,15 @@ __device__ __forceinline__ bool epilogue_fast_dispatch(const Epilogue& e, const 
   LR2_FAST(0, false, false, false, false, true)     // bias -> planes (QKV)
   LR2_FAST(1, false, false, false, false, true)     // bias, GELU -> planes (FFN-1, inference)
   LR2_FAST(0, false, false, true, true, false)      // bias + residual -> fp32 (attention output, FFN-2)
-  if constexpr (WIDE) {
+  if constexpr (WIDE >= 1) {
     LR2_FAST(1, true, false, false, false, true)    // FFN-1, training: pre-activation kept
     LR2_FAST(2, false, false, false, false, true)   // FFN-2 input gradient: GELU' -> planes
     LR2_FAST(0, false, true, true, true, false)     // training: dropout, + residual -> fp32
     LR2_FAST(0, false, false, false, true, false)   // plain fp32 result (input gradients)
     LR2_FAST(0, false, false, true, true, true)     // + residual -> fp32 and planes
     LR2_FAST(0, false, true, false, false, true)    // dropout -> planes
+  }
+  if constexpr (WIDE >= 2) {     // (activation + dropout: 28 spilled VGPRs under the 8-wave kernels' 128-register cap)
     LR2_FAST(1, true, true, false, false, true)     // XiT FFN-1, training: pre-activation kept, GELU, dropout -> planes
     LR2_FAST(2, false, true, false, false, true)    // XiT FFN-2 input gradient: dropout mask, GELU' -> planes
   }
@@ -335,7 +337,7 @@ __device__ __forceinline__ bool epilogue_fast_dispatch(const Epilogue& e, const 
   return false;
 }
 
-template <int WN, int HALF, int NS, bool WIDE>
+template <int WN, int HALF, int NS, int WIDE>
 __device__ __forceinline__ void epilogue_from_slab(const GemmParams& g, float* slab, int mw, int nw, int lane, float* partial,
                                                    float4 bias4, const EpiSlab<WN, NS>& S) {
   constexpr int LDW = WN + 4;
@@ -365,7 +367,7 @@ __device__ __forceinline__ void epilogue_from_slab(const GemmParams& g, float* s
 // PIPE: request slab h+1's HBM operands before slab h's stores (after slab h's accumulators have moved to LDS, so the
 // register peak is acc - 32 + 3 x 32 for NS = 1).  Kernels that keep up to three requests per element (NS = 3) and run
 // several workgroups per CU request per slab instead: their register budget decides their occupancy.
-template <int WM, int WN, int MI, int NI, int NS, int HALF, bool PIPE, bool WIDE>
+template <int WM, int WN, int MI, int NI, int NS, int HALF, bool PIPE, int WIDE>
 __device__ __forceinline__ void epilogue_pipeline(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
                                                   int lane, float* partial, float4 bias4, EpiSlab<WN, NS>& cur) {
   if constexpr (!PIPE) {
@@ -381,7 +383,7 @@ __device__ __forceinline__ void epilogue_pipeline(const GemmParams& g, f32x4_t (
     epilogue_pipeline<WM, WN, MI, NI, NS, HALF + 1, PIPE, WIDE>(g, acc, slab, mw, nw, lane, partial, bias4, PIPE ? next : cur);
 }
 
-template <int WM, int WN, int MI, int NI, int NS = 3, bool WIDE = (NS == 1)>
+template <int WM, int WN, int MI, int NI, int NS = 3, int WIDE = (NS == 1 ? 2 : 0)>
 __device__ __forceinline__ void epilogue_wave(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
                                               int lane, float* partial) {
   static_assert(WM == 32 || WM == 64 || WM == 128, "wave tile rows");
@@ -404,7 +406,7 @@ __device__ __forceinline__ void epilogue_wave(const GemmParams& g, f32x4_t (&acc
 // Fused AdamW epilogue: the weight, exp_avg and exp_avg_sq vectors of all 32 rows of a slab are requested BEFORE the
 // accumulators are transposed through LDS (24 independent 16-B loads per lane in flight; with the loads issued one
 // slab pass at a time the 12 GB p/m/v stream of out_layer.fc1 would be latency-bound at ~3 TB/s).
-template <int WM, int WN, int MI, int NI, bool WIDE = false>
+template <int WM, int WN, int MI, int NI, int WIDE = 0>
 __device__ __forceinline__ void epilogue_wave_adam(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw,
                                                    int nw, int lane) {
   epilogue_wave<WM, WN, MI, NI, 3, WIDE>(g, acc, slab, mw, nw, lane, nullptr);
