@@ -10,8 +10,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _args(dev):
-    return argparse.Namespace(mode="reg", labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768, is_master=True,
+def _args(dev, mode="reg"):
+    return argparse.Namespace(mode=mode, labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768, is_master=True,
                               kl_div_loss_weight=0.001, entropy_weight=0.001, value_clip=0.5, optimizer="adamw",
                               scheduler="linear", learning_rate=1e-3, critic_learning_rate=1e-3, train_steps=41, warmup=0.1,
                               device=dev)
@@ -68,10 +68,11 @@ def test_device_seed_and_device_lr_give_the_by_value_bits(dev):
     assert float((outs[0][1] == 0).float().mean()) > 0.05
 
 
-def test_graphed_ppo_step_equals_eager_bits_and_follows_the_scheduler(dev):
+@pytest.mark.parametrize("mode", ["reg", "cls"])
+def test_graphed_ppo_step_equals_eager_bits_and_follows_the_scheduler(dev, mode):
     from lr2ppo_amd import runtime
     from lr2ppo_amd.finetune import ppo
-    args = _args(dev)
+    args = _args(dev, mode)
     A = _build(ppo, args, dev)
     state = ({k: v.detach().cpu().clone() for k, v in A[0].state_dict().items()},
              {k: v.detach().cpu().clone() for k, v in A[1].state_dict().items()})
