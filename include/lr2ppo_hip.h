@@ -52,7 +52,8 @@ typedef struct lr2_epilogue {
   uint64_t drop_seed;
   /* Fused optimizer step (weight-gradient GEMMs): when adam_p is set the result g[m,n] (after alpha) is not stored but
    * consumed by the AdamW update of lr2_adamw_multi on (adam_p, adam_m, adam_v)[m, ld_out*m + n]; `out` may be NULL.
-   * The 2 GB gradient of out_layer.fc1.weight is then never written to or read back from HBM.
+   * The 2 GB gradient of out_layer.fc1.weight is then never written to or read back from HBM.  drop_p must be 0 with adam_p
+   * (the update consumes the result: there is nothing to mask; LR2_ERR_ARG otherwise).
    * replaces: the fc1.weight slice of optimizers.py:344-402 + the .grad write of loss.backward(). */
   void* adam_p;
   void* adam_m;
