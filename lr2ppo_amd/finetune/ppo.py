@@ -928,7 +928,8 @@ class GraphedPPOStep:
 
     def _setup(self, text, img, tgts):
         dev = text.device
-        self.text, self.img, self.tgts = torch.empty_like(text), torch.empty_like(img), torch.empty_like(tgts)
+        # (`_trad` heads take no image features: img_emb is None there, ppo_trad.py:431-433)
+        self.text, self.img, self.tgts = torch.empty_like(text), None if img is None else torch.empty_like(img), torch.empty_like(tgts)
         self.scalars = ops.StepScalars(dev)
         for o in (self.opt, self.copt):
             o.use_device_lr([self.scalars.lr_tensor(self.scalars.new_lr()) for _ in o.param_groups])
@@ -952,6 +953,8 @@ class GraphedPPOStep:
             self._setup(text, img, tgts)
         for dst, src in ((self.text, text), (self.img, img), (self.tgts, tgts)):
             if src is not dst:
+                if (src is None) != (dst is None):
+                    raise ValueError("GraphedPPOStep: img_emb given for one call and None for another")
                 if src.shape != dst.shape or src.dtype != dst.dtype:
                     raise ValueError("GraphedPPOStep: batch shape changed (one graph per shape: build another GraphedPPOStep)")
                 dst.copy_(src)

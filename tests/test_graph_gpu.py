@@ -136,3 +136,55 @@ def test_graphed_ppo_step_equals_eager_bits_and_follows_the_scheduler(dev, mode)
     rec = ppo.rollout_step(model, reward, *batches[0])
     model.train()
     assert torch.isfinite(ppo.update_minibatch(args, model, opt, copt, rec)).all()
+
+
+def test_graphed_step_of_the_sequence_length_1_heads(dev):
+    """finetune/ppo_trad.py's models (no image features, no 2-GB matrix, every gradient through the multi-tensor AdamW) through the
+    same GraphedPPOStep: bits of the eager rollout + update over 5 steps with a moving schedule."""
+    from lr2ppo_amd import runtime
+    from lr2ppo_amd.finetune import ppo_trad as pt
+    from oracle import lr2ppo_oracle as O
+    args = argparse.Namespace(mode="reg", labels_num=3, is_master=False, kl_div_loss_weight=0.001, entropy_weight=0.001,
+                              value_clip=0.5, optimizer="adamw", scheduler="linear", learning_rate=1e-3, critic_learning_rate=1e-3,
+                              train_steps=41, warmup=0.1, device=dev)
+
+    def build():
+        model, reward = pt.ActorCritic(args, None), pt.Reward(args, None)
+        for mod, kind, seed in ((model.actor, "actor", 37), (model.critic, "critic", 38), (reward, "reward", 39)):
+            mod.load_state_dict(O.seeded_params(O.trad_head_param_spec(kind), seed=seed), strict=True)
+        model, reward = model.to(dev), reward.to(dev).eval()
+        opt, copt, sch, csch = pt.build_optimizer(args, model)
+        model.actor.bind_grads(), model.critic.bind_grads()
+        for _ in range(3):
+            sch.step(), csch.step()
+        return model, reward, opt, copt, sch, csch
+
+    gen = torch.Generator().manual_seed(5)
+    batches = [(torch.randn(6, 2, 768, generator=gen).to(dev), torch.randint(0, 3, (6, 2), generator=gen).to(dev)) for _ in range(5)]
+    runtime.set_dropout_seed(7)
+    model, reward, opt, copt, sch, csch = A = build()
+    ref = []
+    for text, tgts in batches:
+        model.eval()
+        rec = pt.rollout_step(model, reward, text, None, tgts)
+        model.train()
+        ref.append(pt.update_minibatch(args, model, opt, copt, rec).clone())
+        sch.step(), csch.step()
+    runtime.set_dropout_seed(7)
+    model, reward, opt, copt, sch, csch = B = build()
+    step = ppo_mod().GraphedPPOStep(args, model, reward, opt, copt)
+    got = []
+    for text, tgts in batches:
+        got.append(step(text, None, tgts).clone())
+        sch.step(), csch.step()
+    torch.cuda.synchronize()
+    assert step.graph is not None
+    for i, (x, y) in enumerate(zip(got, ref)):
+        assert torch.equal(x, y), f"metrics of step {i} differ"
+    for (n, p), (_, q) in zip(B[0].named_parameters(), A[0].named_parameters()):
+        assert torch.equal(p, q), f"parameter {n} differs"
+
+
+def ppo_mod():
+    from lr2ppo_amd.finetune import ppo
+    return ppo
