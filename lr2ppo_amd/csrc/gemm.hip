@@ -434,8 +434,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void gemm_kernel(GemmPara
   // ---- epilogue through LDS (operand images are dead after the last barrier) ----
   float* slab = reinterpret_cast<float*>(smem) + wave * (32 * (WN + 4));
   float* part = g.partial ? g.partial + (size_t)split * (size_t)g.M * (size_t)g.N : nullptr;
-  if (g.epi.adam_p && !part) epilogue_wave_adam<WM, WN, MI, NI, (NW == 8 ? 1 : 0)>(g, acc, slab, m0 + wm0, n0 + wn0, lane);
-  else epilogue_wave<WM, WN, MI, NI, 3, (NW == 8 ? 1 : 0)>(g, acc, slab, m0 + wm0, n0 + wn0, lane, part);
+  if (g.epi.adam_p && !part) epilogue_wave_adam<WM, WN, MI, NI, ((APL && BPL) ? (NW == 8 ? 1 : 0) : -1)>(g, acc, slab, m0 + wm0, n0 + wn0, lane);
+  else epilogue_wave<WM, WN, MI, NI, 3, ((APL && BPL) ? (NW == 8 ? 1 : 0) : -1)>(g, acc, slab, m0 + wm0, n0 + wn0, lane, part);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N,

@@ -302,11 +302,12 @@ __device__ __forceinline__ void epilogue_fast(const Epilogue& e, const float4 (&
 }
 
 // -> true when one of the instantiated forms took the slab.  WIDE 2: the full list (the 256 x 256 kernels, where the encoders'
-// training products run); 1: the 8-wave kernels (the heads' M = 12 544 products); 0: the rest of the general kernel family, the
-// inference forms only (fifty instantiations: compile time).
+// training products run); 1: the 8-wave kernels (the heads' M = 12 544 products); 0: the other planes x planes kernels of the general
+// family, the inference forms only; -1: none (fifty kernel instantiations: compile time).
 template <int NP, int RPP, int NS, int WIDE>
 __device__ __forceinline__ bool epilogue_fast_dispatch(const Epilogue& e, const float4 (&v)[NP], float4 b,
                                                        const EpiLoads<NS> (&L)[NP], int m0, int n, int N) {
+  if constexpr (WIDE < 0) return false;        // kernels with an fp32 operand: HBM-bound weight streams, the epilogue is not their cost
   if (e.adam_p || e.accumulate) return false;
   const int act = e.act;
   const bool z = e.out_z != nullptr, drop = e.drop_scale != 0.0f, resid = e.resid != nullptr, out = e.out != nullptr,
