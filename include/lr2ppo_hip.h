@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 15
+#define LR2_ABI_VERSION 16
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -335,6 +335,17 @@ int lr2_ndcg(const void* scores, const int64_t* gold, const int64_t* offsets, co
  * replaces: patch_embedding.py:28-29 (cls concat) + pos_embedding.py:30-35 + embedding.py:27-30. */
 int lr2_vit_assemble(const void* patch_proj, const void* cls, const void* pos, void* out, int B, int P, int D,
                      void* stream);
+
+/* MX-FP8 products on gfx950's block-scaled matrix instruction (BASELINE.json configs[4]: "fp8 MFMA"; an inference-only fast mode,
+ * NOT the parity path: e4m3 keeps 3 mantissa bits).  Format: OCP MX v1.0 -- e4m3fn elements, one E8M0 scale byte (2^(s - 127)) per 32
+ * consecutive elements of a row, shared exponent floor(log2(amax)) - 8, round-to-nearest-even, saturating at +-448.
+ *   lr2_quant_mxfp8: x fp32 [rows, K] (row stride ldx) -> q uint8 [rows, K], scales uint8 [rows, K / 32].  K % 32 == 0.
+ *   lr2_gemm_mxfp8 : out[M, N] fp32 = A_q . B_q^T (+ bias[N]) (act 1: GELU) (+ resid[M, ld_resid]); A_q [M, K], B_q [N, K] and their
+ *                    scales as written by lr2_quant_mxfp8.  N % 128 == 0, K % 128 == 0, any M.
+ * replaces: nn.Linear forward (tencentpretrain/layers/position_ffn.py:12-15, multi_headed_attn.py:55-76) in that mode. */
+int lr2_quant_mxfp8(const void* x, int ldx, void* q, void* scales, int rows, int K, void* stream);
+int lr2_gemm_mxfp8(const void* a_q, const void* a_scales, const void* b_q, const void* b_scales, void* out, int ld_out,
+                   const void* bias, const void* resid, int ld_resid, int act, int M, int N, int K, void* stream);
 
 #ifdef __cplusplus
 }

@@ -681,6 +681,54 @@ def adamw_multi(table_dev: torch.Tensor, n_chunks: int, lr: float, beta1: float,
                                               lr_dev.data_ptr() if lr_dev is not None else None, _stream()), "lr2_adamw_multi")
 
 
+class Mx8:
+    """A matrix in MX-FP8 (OCP MX v1.0: e4m3fn bytes + one E8M0 scale byte per 32 consecutive elements of a row) -- the operand
+    format of gemm_mxfp8, the inference-only fp8 fast mode (csrc/fp8.hip; NOT the parity path)."""
+    __slots__ = ("q", "s", "rows", "cols")
+
+    def __init__(self, q: torch.Tensor, s: torch.Tensor, rows: int, cols: int):
+        if q.dtype != torch.uint8 or s.dtype != torch.uint8 or not q.is_cuda or q.numel() < rows * cols or s.numel() < rows * (cols // 32):
+            raise TypeError("Mx8: uint8 HIP tensors [rows, cols] and [rows, cols / 32]")
+        self.q, self.s, self.rows, self.cols = q, s, rows, cols
+
+    @staticmethod
+    def empty(rows: int, cols: int, device) -> "Mx8":
+        return Mx8(torch.empty(rows * cols, dtype=torch.uint8, device=device), torch.empty(rows * (cols // 32), dtype=torch.uint8, device=device),
+                   rows, cols)
+
+    def to_float(self) -> torch.Tensor:
+        """Dequantised fp32 matrix (tests / debugging)."""
+        v = self.q[:self.rows * self.cols].view(torch.float8_e4m3fn).float().view(self.rows, self.cols // 32, 32)
+        sc = torch.exp2(self.s[:self.rows * (self.cols // 32)].float() - 127.0).view(self.rows, self.cols // 32, 1)
+        return (v * sc).view(self.rows, self.cols)
+
+
+def quant_mxfp8(x: torch.Tensor, dst: Optional[Mx8] = None) -> Mx8:
+    """x fp32 [rows, K] (rows may be strided, K % 32 == 0) -> Mx8 (lr2_quant_mxfp8)."""
+    _chk_f32(x)
+    if x.dim() != 2 or x.stride(1) != 1 or x.shape[1] % 32:
+        raise ValueError("quant_mxfp8: a 2-D fp32 matrix with contiguous rows and K % 32 == 0")
+    R, K = x.shape
+    dst = dst or Mx8.empty(R, K, x.device)
+    if dst.rows != R or dst.cols != K:
+        raise ValueError("quant_mxfp8: destination shape")
+    _nat.check(_nat.lib().lr2_quant_mxfp8(x.data_ptr(), x.stride(0), dst.q.data_ptr(), dst.s.data_ptr(), R, K, _stream()), "lr2_quant_mxfp8")
+    return dst
+
+
+def gemm_mxfp8(a: Mx8, b: Mx8, out: torch.Tensor, *, bias=None, resid=None, act: int = 0):
+    """out[M, N] fp32 = a . b^T (+ bias) (act 1: GELU) (+ resid) with a [M, K], b [N, K] in MX-FP8 (lr2_gemm_mxfp8)."""
+    _chk_f32(out, bias, resid)
+    M, N, K = a.rows, b.rows, a.cols
+    if b.cols != K or out.dim() != 2 or out.shape[0] != M or out.shape[1] != N or out.stride(1) != 1:
+        raise ValueError("gemm_mxfp8: a [M, K], b [N, K], out [M, N]")
+    with _Timed(f"gemm_mxfp8_M{M}_N{N}_K{K}", 2.0 * M * N * K, float(M * K + N * K + 4 * M * N)):
+        _nat.check(_nat.lib().lr2_gemm_mxfp8(a.q.data_ptr(), a.s.data_ptr(), b.q.data_ptr(), b.s.data_ptr(), out.data_ptr(), out.stride(0),
+                                             _ptr(bias), _ptr(resid), resid.stride(0) if resid is not None else 0, act, M, N, K, _stream()),
+                   "lr2_gemm_mxfp8")
+    return out
+
+
 def text_embed(src, seg, word, pos, seg_table, out, *, rows, L, D, err: Optional[torch.Tensor] = None):
     """err: optional int32[1] device word; bit 0 / bit 1 are set when a token / segment id is out of range."""
     _chk_f32(word, pos, seg_table, out)

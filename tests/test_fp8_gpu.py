@@ -1,0 +1,63 @@
+"""MX-FP8 fast mode (csrc/fp8.hip, BASELINE.json configs[4] "fp8 MFMA"): the quantiser against the OCP MX v1.0 rule restated with torch
+(bytes and scale bytes equal), the product against an fp64 product of the DEQUANTISED operands (the instruction's adder tree is not
+an fp32 sum: bounded by 2e-3 of the sum of |terms|), fused bias / GELU / residual, ragged M.  Not a parity path: how far a product is
+from the fp32 one is measured and printed, not gated."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_quant(x):
+    R, K = x.shape
+    xb = x.double().view(R, K // 32, 32)
+    amax = xb.abs().amax(-1, keepdim=True)
+    e = torch.floor(torch.log2(amax.clamp_min(1e-300))) - 8
+    e = torch.where(amax < 1.17549435e-38, torch.full_like(e, -127.0), e).clamp(-127, 127)
+    q = (xb * torch.exp2(-e)).clamp(-448, 448).float().to(torch.float8_e4m3fn)
+    return q.view(R, K).view(torch.uint8), (e + 127).to(torch.uint8).view(R, K // 32)
+
+
+@pytest.mark.parametrize("R,K", [(64, 128), (300, 768), (17, 4096)])
+def test_quantiser_matches_the_mx_rule(dev, R, K):
+    from lr2ppo_amd import ops
+    g = torch.Generator().manual_seed(R + K)
+    x = torch.randn(R, K, generator=g) * torch.exp(torch.randn(R, 1, generator=g) * 3)
+    x[0, :32] = 0.0                                          # an all-zero block
+    x[1, 5] = 1e30                                           # a huge outlier in a block
+    m = ops.quant_mxfp8(x.to(dev))
+    q_ref, s_ref = _ref_quant(x)
+    assert torch.equal(m.s.view(R, K // 32).cpu(), s_ref)
+    got = m.q.view(R, K).cpu()
+    same = (got == q_ref) | ((got & 0x7F) == 0) & ((q_ref & 0x7F) == 0)           # +0 / -0
+    assert bool(same.all()), f"{int((~same).sum())} of {R * K} bytes differ"
+    assert torch.equal(m.to_float().cpu(), (q_ref.view(torch.float8_e4m3fn).float().view(R, K // 32, 32)
+                                            * torch.exp2(s_ref.float() - 127).view(R, K // 32, 1)).view(R, K))
+
+
+@pytest.mark.parametrize("M,N,K,act,with_resid", [(128, 128, 128, 0, False), (300, 256, 768, 1, True), (1000, 384, 3072, 0, True),
+                                                   (64, 1024, 1024, 1, False)])
+def test_product_matches_the_dequantised_operands(dev, M, N, K, act, with_resid):
+    from lr2ppo_amd import ops
+    from oracle import lr2ppo_oracle as O
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g) * 0.1
+    resid = torch.randn(M, N, generator=g) if with_resid else None
+    am, bm = ops.quant_mxfp8(a.to(dev)), ops.quant_mxfp8(b.to(dev))
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm_mxfp8(am, bm, out, bias=bias.to(dev), resid=None if resid is None else resid.to(dev), act=act)
+    da, db = am.to_float().double().cpu(), bm.to_float().double().cpu()
+    pre = da @ db.t() + bias.double()
+    want = O.gelu_erf(pre) if act else pre
+    if resid is not None:
+        want = want + resid.double()
+    bound = 2e-3 * (da.abs() @ db.abs().t()) + 1e-5         # the instruction's adder tree, relative to the sum of |terms|
+    err = (out.double().cpu() - want).abs()
+    assert bool((err <= bound).all()), f"worst excess {(err - bound).max().item():.3e} (err {err.max().item():.3e})"
+    exact = a.double() @ b.double().t()                                       # how far fp8 is from the fp32 product (printed)
+    rel = ((da @ db.t()) - exact).norm() / exact.norm()
+    print(f"M {M} N {N} K {K}: MX-FP8 product vs fp32 product, relative L2 error {rel.item():.3e}")
+    assert rel < 0.06
