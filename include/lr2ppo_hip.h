@@ -341,11 +341,14 @@ int lr2_vit_assemble(const void* patch_proj, const void* cls, const void* pos, v
  * consecutive elements of a row, shared exponent floor(log2(amax)) - 8, round-to-nearest-even, saturating at +-448.
  *   lr2_quant_mxfp8: x fp32 [rows, K] (row stride ldx) -> q uint8 [rows, K], scales uint8 [rows, K / 32].  K % 32 == 0.
  *   lr2_gemm_mxfp8 : out[M, N] fp32 = A_q . B_q^T (+ bias[N]) (act 1: GELU) (+ resid[M, ld_resid]); A_q [M, K], B_q [N, K] and their
- *                    scales as written by lr2_quant_mxfp8.  N % 128 == 0, K % 128 == 0, any M.
+ *                    scales as written by lr2_quant_mxfp8.  N % 128 == 0, K % 128 == 0, any M.  out_q / out_scales (both or neither;
+ *                    out may then be NULL): the result also / instead quantised to MX-FP8 [M, N] + [M, N / 32] by the same rule --
+ *                    the A operand of the next product without an fp32 round trip.
  * replaces: nn.Linear forward (tencentpretrain/layers/position_ffn.py:12-15, multi_headed_attn.py:55-76) in that mode. */
 int lr2_quant_mxfp8(const void* x, int ldx, void* q, void* scales, int rows, int K, void* stream);
 int lr2_gemm_mxfp8(const void* a_q, const void* a_scales, const void* b_q, const void* b_scales, void* out, int ld_out,
-                   const void* bias, const void* resid, int ld_resid, int act, int M, int N, int K, void* stream);
+                   const void* bias, const void* resid, int ld_resid, int act, void* out_q, void* out_scales, int M, int N, int K,
+                   void* stream);
 
 #ifdef __cplusplus
 }

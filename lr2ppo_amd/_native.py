@@ -120,7 +120,7 @@ SIGNATURES = {
     "lr2_adamw_multi": [_P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P],
     "lr2_step_scalars_store": [_P, _U64, _P, _I, _P],
     "lr2_quant_mxfp8": [_P, _I, _P, _P, _I, _I, _P],
-    "lr2_gemm_mxfp8": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "lr2_gemm_mxfp8": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _I, _P],
     "lr2_text_embed": [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.c_int64, _I, _P, _P],
     "lr2_patchify_planes": [_P, _I, _P, _U64, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P],
     "lr2_ndcg": [_P, _P, _P, _P, _P, _I, _P, _I, _P],

@@ -69,6 +69,8 @@ struct Mx8Params {
   const float* bias;
   const float* resid;
   int M, N, K, ld_out, ld_resid, act;
+  uint8_t* out_q;      // result ALSO / INSTEAD as MX-FP8 [M, N] + scales [M, N / 32] (the next product's A operand): LDS kernel only
+  uint8_t* out_s;
 };
 
 struct Frags {
@@ -149,6 +151,170 @@ __global__ __launch_bounds__(256) void gemm_mxfp8_kernel(Mx8Params p) {
   }
 }
 
+// ---- the same product with the operand tiles staged through LDS (two stages of 128 rows x 128 bytes per operand = 64 KiB) ----
+// A 16-byte chunk c of tile row r lives at r * 128 + ((c ^ (r & 7)) << 4): the 16 lanes of a fragment read (rows r .. r + 15, one
+// chunk column) then hit 8 different 16-byte bank groups twice instead of one group 16 times.  Each thread moves four chunks of A
+// and four of B per K step: requested from global memory before the step's matrix instructions, written to the other stage after.
+__device__ __forceinline__ int mx_off(int r, int c) { return r * 128 + ((c ^ (r & 7)) << 4); }
+
+__global__ __launch_bounds__(256, 2) void gemm_mxfp8_lds_kernel(Mx8Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                     // [2][128 * 128]
+  char* sB = smem + 2 * 16384;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = p.N / 128;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int r16 = lane & 15, q = lane >> 4;
+  // this thread's four chunks of a stage: rows (tid >> 3) + 32 it, chunk tid & 7
+  const int cr = tid >> 3, cc = tid & 7;
+  const uint8_t* ga[4];
+  const uint8_t* gb[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    int m = tm * 128 + cr + 32 * it;
+    if (m >= p.M) m = p.M - 1;
+    ga[it] = p.aq + (size_t)m * p.K + 16 * cc;
+    gb[it] = p.bq + (size_t)(tn * 128 + cr + 32 * it) * p.K + 16 * cc;
+  }
+  const uint8_t* asrow[4];
+  const uint8_t* bsrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int m = tm * 128 + wr * 64 + 16 * i + r16;
+    if (m >= p.M) m = p.M - 1;
+    asrow[i] = p.as + (size_t)m * (p.K / 32) + q;
+    bsrow[i] = p.bs + (size_t)(tn * 128 + wc * 64 + 16 * i + r16) * (p.K / 32) + q;
+  }
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  v4i_t ra[4], rb[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    ra[it] = *reinterpret_cast<const v4i_t*>(ga[it]);
+    rb[it] = *reinterpret_cast<const v4i_t*>(gb[it]);
+  }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    *reinterpret_cast<v4i_t*>(sA + mx_off(cr + 32 * it, cc)) = ra[it];
+    *reinterpret_cast<v4i_t*>(sB + mx_off(cr + 32 * it, cc)) = rb[it];
+  }
+  __syncthreads();
+  int st = 0;
+  for (int k0 = 0; k0 < p.K; k0 += 128) {
+    const bool more = k0 + 128 < p.K;
+    if (more) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        ra[it] = *reinterpret_cast<const v4i_t*>(ga[it] + k0 + 128);
+        rb[it] = *reinterpret_cast<const v4i_t*>(gb[it] + k0 + 128);
+      }
+    }
+    int sa[4], sb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sa[i] = (int)asrow[i][k0 >> 5];
+      sb[i] = (int)bsrow[i][k0 >> 5];
+    }
+    const char* cA = sA + st * 16384;
+    const char* cB = sB + st * 16384;
+    v8i_t fb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wc * 64 + 16 * j + r16;
+      const v4i_t b0 = *reinterpret_cast<const v4i_t*>(cB + mx_off(row, q));
+      const v4i_t b1 = *reinterpret_cast<const v4i_t*>(cB + mx_off(row, 4 + q));
+      fb[j] = v8i_t{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wr * 64 + 16 * i + r16;
+      const v4i_t a0 = *reinterpret_cast<const v4i_t*>(cA + mx_off(row, q));
+      const v4i_t a1 = *reinterpret_cast<const v4i_t*>(cA + mx_off(row, 4 + q));
+      const v8i_t fa = v8i_t{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa, fb[j], acc[i][j], 0, 0, 0, sa[i], 0, sb[j]);
+    }
+    if (more) {
+      char* nA = sA + (st ^ 1) * 16384;
+      char* nB = sB + (st ^ 1) * 16384;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        *reinterpret_cast<v4i_t*>(nA + mx_off(cr + 32 * it, cc)) = ra[it];
+        *reinterpret_cast<v4i_t*>(nB + mx_off(cr + 32 * it, cc)) = rb[it];
+      }
+    }
+    __syncthreads();
+    st ^= 1;
+  }
+  // epilogue: the wave's 64 x 64 results through a wave-private LDS slab, 32 rows at a time (the operand stages are dead: the loop
+  // ended with a barrier), so that a row leaves as 256 contiguous bytes instead of 16 four-byte pieces
+  const int m0 = tm * 128 + wr * 64, n0 = tn * 128 + wc * 64;
+  float* slab = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+  const int orow = lane >> 4, ocol = (lane & 15) * 4;
+  const int n = n0 + ocol;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(16 * ii + 4 * q + r) * 68 + 16 * j + r16] = acc[2 * half + ii][j][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int lr = 4 * pass + orow;
+      const int m = m0 + 32 * half + lr;
+      if (m < p.M) {
+        float4 v = *reinterpret_cast<const float4*>(slab + lr * 68 + ocol);
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (p.act == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        if (p.resid) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ld_resid + n);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ld_out + n) = v;
+      }
+      if (p.out_q) {
+        // a row's 32-column MX block = 8 consecutive lanes x 4 columns (the wave tile's 64 columns are two blocks per row):
+        // quantise here, as lr2_quant_mxfp8 would the stored row (rows past M compute on garbage and store nothing)
+        float4 v = *reinterpret_cast<const float4*>(slab + lr * 68 + ocol);
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (p.act == 1) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        if (p.resid && m < p.M) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.resid + (size_t)m * p.ld_resid + n);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+        int e = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127 - 8;
+        if (amax < 1.17549435e-38f) e = -127;
+        if (e < -127) e = -127;
+        if (e > 127) e = 127;
+        const uint32_t ef = (uint32_t)(127 - e);
+        const float inv = __uint_as_float(ef ? ef << 23 : 0x00400000u);
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v.x * inv, -448.f, 448.f), __builtin_amdgcn_fmed3f(v.y * inv, -448.f, 448.f), w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v.z * inv, -448.f, 448.f), __builtin_amdgcn_fmed3f(v.w * inv, -448.f, 448.f), w, true);
+        if (m < p.M) {
+          *reinterpret_cast<int*>(p.out_q + (size_t)m * p.N + n) = w;
+          if ((lane & 7) == 0) p.out_s[(size_t)m * (p.N / 32) + (n >> 5)] = (uint8_t)(e + 127);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace
 
 extern "C" int lr2_quant_mxfp8(const void* x, int ldx, void* q, void* scales, int rows, int K, void* stream) {
@@ -163,12 +329,25 @@ extern "C" int lr2_quant_mxfp8(const void* x, int ldx, void* q, void* scales, in
 }
 
 extern "C" int lr2_gemm_mxfp8(const void* a_q, const void* a_scales, const void* b_q, const void* b_scales, void* out, int ld_out,
-                              const void* bias, const void* resid, int ld_resid, int act, int M, int N, int K, void* stream) {
-  if (!a_q || !a_scales || !b_q || !b_scales || !out || M <= 0 || N <= 0 || K <= 0 || (act != 0 && act != 1)) return LR2_ERR_ARG;
-  if (N % 128 || K % 128 || ld_out < N || (resid && ld_resid < N)) return LR2_ERR_SHAPE;
+                              const void* bias, const void* resid, int ld_resid, int act, void* out_q, void* out_scales, int M, int N,
+                              int K, void* stream) {
+  if (!a_q || !a_scales || !b_q || !b_scales || (!out && !out_q) || M <= 0 || N <= 0 || K <= 0 || (act != 0 && act != 1)) return LR2_ERR_ARG;
+  if ((out_q != nullptr) != (out_scales != nullptr)) return LR2_ERR_ARG;
+  if (N % 128 || K % 128 || ld_out < N || ld_out % 4 || (resid && (ld_resid < N || ld_resid % 4))) return LR2_ERR_SHAPE;
   Mx8Params p{(const uint8_t*)a_q, (const uint8_t*)a_scales, (const uint8_t*)b_q, (const uint8_t*)b_scales, (float*)out,
-              (const float*)bias, (const float*)resid, M, N, K, ld_out, ld_resid, act};
+              (const float*)bias, (const float*)resid, M, N, K, ld_out, ld_resid, act, (uint8_t*)out_q, (uint8_t*)out_scales};
   const int tiles = ((M + 127) / 128) * (N / 128);
-  LR2_LAUNCH(gemm_mxfp8_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
+  const char* e = getenv("LR2_FP8_LDS");          // 0: fragments straight from global memory (the first version; A/B)
+  if (e && atoi(e) == 0) {
+    if (out_q || !out) return LR2_ERR_ARG;          // the first version writes fp32 only
+    LR2_LAUNCH(gemm_mxfp8_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
+    return lr2_launch_status(__func__);
+  }
+  static bool attr = false;
+  if (!attr) {
+    if (lr2_allow_dynamic_lds(gemm_mxfp8_lds_kernel, 65536, "gemm_mxfp8")) return LR2_ERR_LAUNCH;
+    attr = true;
+  }
+  LR2_LAUNCH(gemm_mxfp8_lds_kernel, dim3(tiles), dim3(256), 65536, (hipStream_t)stream, p);
   return lr2_launch_status(__func__);
 }

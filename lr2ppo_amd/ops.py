@@ -716,17 +716,24 @@ def quant_mxfp8(x: torch.Tensor, dst: Optional[Mx8] = None) -> Mx8:
     return dst
 
 
-def gemm_mxfp8(a: Mx8, b: Mx8, out: torch.Tensor, *, bias=None, resid=None, act: int = 0):
-    """out[M, N] fp32 = a . b^T (+ bias) (act 1: GELU) (+ resid) with a [M, K], b [N, K] in MX-FP8 (lr2_gemm_mxfp8)."""
+def gemm_mxfp8(a: Mx8, b: Mx8, out: Optional[torch.Tensor], *, bias=None, resid=None, act: int = 0, out_mx: Optional[Mx8] = None):
+    """out[M, N] fp32 = a . b^T (+ bias) (act 1: GELU) (+ resid) with a [M, K], b [N, K] in MX-FP8 (lr2_gemm_mxfp8).
+    out_mx: the result also (out given) or only (out None) as MX-FP8 -- the next product's A operand."""
     _chk_f32(out, bias, resid)
     M, N, K = a.rows, b.rows, a.cols
-    if b.cols != K or out.dim() != 2 or out.shape[0] != M or out.shape[1] != N or out.stride(1) != 1:
-        raise ValueError("gemm_mxfp8: a [M, K], b [N, K], out [M, N]")
+    if b.cols != K or (out is None and out_mx is None):
+        raise ValueError("gemm_mxfp8: a [M, K], b [N, K], out [M, N] and / or out_mx")
+    if out is not None and (out.dim() != 2 or out.shape[0] != M or out.shape[1] != N or out.stride(1) != 1):
+        raise ValueError("gemm_mxfp8: out must be [M, N] with contiguous rows")
+    if out_mx is not None and (out_mx.rows != M or out_mx.cols != N):
+        raise ValueError("gemm_mxfp8: out_mx must be [M, N]")
     with _Timed(f"gemm_mxfp8_M{M}_N{N}_K{K}", 2.0 * M * N * K, float(M * K + N * K + 4 * M * N)):
-        _nat.check(_nat.lib().lr2_gemm_mxfp8(a.q.data_ptr(), a.s.data_ptr(), b.q.data_ptr(), b.s.data_ptr(), out.data_ptr(), out.stride(0),
-                                             _ptr(bias), _ptr(resid), resid.stride(0) if resid is not None else 0, act, M, N, K, _stream()),
-                   "lr2_gemm_mxfp8")
-    return out
+        _nat.check(_nat.lib().lr2_gemm_mxfp8(a.q.data_ptr(), a.s.data_ptr(), b.q.data_ptr(), b.s.data_ptr(), _ptr(out),
+                                             out.stride(0) if out is not None else N, _ptr(bias), _ptr(resid),
+                                             resid.stride(0) if resid is not None else 0, act,
+                                             out_mx.q.data_ptr() if out_mx is not None else None,
+                                             out_mx.s.data_ptr() if out_mx is not None else None, M, N, K, _stream()), "lr2_gemm_mxfp8")
+    return out if out is not None else out_mx
 
 
 def text_embed(src, seg, word, pos, seg_table, out, *, rows, L, D, err: Optional[torch.Tensor] = None):

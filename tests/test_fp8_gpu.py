@@ -61,3 +61,21 @@ def test_product_matches_the_dequantised_operands(dev, M, N, K, act, with_resid)
     rel = ((da @ db.t()) - exact).norm() / exact.norm()
     print(f"M {M} N {N} K {K}: MX-FP8 product vs fp32 product, relative L2 error {rel.item():.3e}")
     assert rel < 0.06
+
+
+def test_product_can_hand_its_result_on_as_mx_fp8(dev):
+    """out_mx: the epilogue quantises the row it would have stored -- bytes and scales equal to lr2_quant_mxfp8 of the fp32 result."""
+    from lr2ppo_amd import ops
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 333, 512, 256
+    a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g) * 0.1
+    am, bm = ops.quant_mxfp8(a.to(dev)), ops.quant_mxfp8(b.to(dev))
+    out = torch.empty(M, N, device=dev)
+    mx = ops.Mx8.empty(M, N, dev)
+    ops.gemm_mxfp8(am, bm, out, bias=bias.to(dev), act=1, out_mx=mx)
+    want = ops.quant_mxfp8(out)
+    assert torch.equal(mx.s, want.s) and torch.equal(mx.q, want.q)
+    only = ops.Mx8.empty(M, N, dev)
+    ops.gemm_mxfp8(am, bm, None, bias=bias.to(dev), act=1, out_mx=only)
+    assert torch.equal(only.s, want.s) and torch.equal(only.q, want.q)
