@@ -556,7 +556,34 @@ def main():
             out["config"]["vit_l14_forward"] = {"ms": round(l_ms, 3), "algorithmic_tflop": round(l_fl / 1e12, 1), "frames": nfr,
                                                 "workload": "ViT-L/14 (hidden 1024, 24 layers, 16 heads, 257 tokens: key-block attention) "
                                                             "full forward, random weights"}
-            del vl, limg, lseg
+            # the same stack with its projections as MX-FP8 products (BASELINE configs[4] "fp8 MFMA"; csrc/fp8.hip): an explicit,
+            # non-parity fast mode -- time of the encoder stack alone (embedding excluded in both figures) and its distance
+            # from the split-bf16 forward
+            with torch.no_grad():
+                lemb = vl.embedding(limg, lseg)
+                ref = vl.encoder(lemb, lseg)
+                got = vl.encoder.forward_fp8(lemb, lseg)
+                rel = float((got - ref).norm() / ref.norm())
+                torch.cuda.synchronize()
+                ev0.record()
+                for _ in range(2):
+                    vl.encoder.forward_fp8(lemb, lseg)
+                ev1.record()
+                torch.cuda.synchronize()
+                f8_ms = ev0.elapsed_time(ev1) / 2
+                ev0.record()
+                for _ in range(2):
+                    vl.encoder(lemb, lseg)
+                ev1.record()
+                torch.cuda.synchronize()
+                b3_ms = ev0.elapsed_time(ev1) / 2
+            out["config"]["vit_l14_encoder_mxfp8"] = {
+                "ms": round(f8_ms, 3), "split_bf16_x3_ms": round(b3_ms, 3), "speedup": round(b3_ms / f8_ms, 3),
+                "relative_l2_distance_from_the_split_bf16_output": round(rel, 4),
+                "note": "24 encoder layers over 512 x 257 tokens; QKV / output / FFN projections as MX-FP8 products on "
+                        "v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 elements: NOT within north_star's 1e-3 -- a separate mode, never "
+                        "part of `value`), LayerNorm / attention / residual stream as in the default path"}
+            del vl, limg, lseg, lemb, ref, got
         del fx, raw
     # ================= [D] CPU baseline: the oracle on this box's host cores, bounded sample =================
     if world == 1 and not a.no_cpu_baseline:

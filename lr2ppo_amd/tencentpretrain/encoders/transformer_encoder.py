@@ -216,6 +216,78 @@ class TransformerEncoder(nn.Module):
             out.view(M, E).copy_(h)
         return out
 
+    # ---- MX-FP8 inference (BASELINE.json configs[4] "fp8 MFMA"): NOT the parity path, an explicit fast mode ------------------
+    def _fp8_weights(self):
+        """Per layer: the four projection weights quantised to MX-FP8 once (ops.quant_mxfp8), re-done when a parameter is rewritten."""
+        sig = tuple((p.data_ptr(), p._version, ops.param_write_count(p)) for p in self.parameters())
+        if getattr(self, "_fp8_sig", None) != sig:
+            out = []
+            for layer in self.transformer:
+                att, ffn = layer.self_attn, layer.feed_forward
+                wqkv = torch.cat([l.weight.data for l in att.linear_layers], 0)
+                out.append({"wqkv": ops.quant_mxfp8(wqkv), "bqkv": torch.cat([l.bias.data for l in att.linear_layers], 0),
+                            "wo": ops.quant_mxfp8(att.final_linear.weight.data), "w1": ops.quant_mxfp8(ffn.linear_1.weight.data),
+                            "w2": ops.quant_mxfp8(ffn.linear_2.weight.data)})
+            self._fp8_w, self._fp8_sig = out, sig
+        return self._fp8_w
+
+    @torch.no_grad()
+    def forward_fp8(self, emb, seg):
+        """forward(emb, seg) with the four projections of every layer as MX-FP8 products (csrc/fp8.hip); LayerNorm, attention and the
+        residual stream stay fp32 / split-bf16.  An element keeps 3 mantissa bits: expect the output a few per cent away from
+        forward()'s -- this mode exists for throughput experiments, never for the parity tests."""
+        if emb.dtype != torch.float32 or not emb.is_cuda:
+            raise TypeError("lr2ppo_amd: emb must be a float32 tensor on the HIP device (no CPU path)")
+        B, L, E = emb.shape
+        H, hd, M = self.heads_num, E // self.heads_num, B * L
+        F = self.transformer[0].feed_forward.linear_1.out_features
+        if E % 128 or F % 128:
+            raise ValueError("forward_fp8: hidden and feed-forward widths must be multiples of 128")
+        if self._ws is None or self._ws.device != emb.device:
+            self._ws = engine.Workspace(emb.device)
+        ws, dev = self._ws, emb.device
+        seg = seg.to(device=dev, dtype=torch.int64).contiguous().view(-1)
+        W = self._fp8_weights()
+        pre = self.layernorm_positioning == "pre"
+        h, h2, xn = ws.mat("h", M, E), ws.mat("h2", M, E), ws.mat("fp8_xn", M, E)
+        qkv32, o32 = ws.mat("fp8_qkv", M, 3 * E), ws.mat("fp8_o", M, E)
+        qkv_p = ws.planes("qkv_p", M, 3 * E)
+        if getattr(self, "_fp8_act", None) is None or self._fp8_act[0].rows != M:
+            self._fp8_act = (ops.Mx8.empty(M, E, dev), ops.Mx8.empty(M, F, dev))
+        x_q, ff_q = self._fp8_act
+        h.copy_(emb.contiguous().view(M, E))
+        scale = 1.0 / math.sqrt(float(hd))
+        src = h                                           # what the QKV projection reads ('post': the stream itself)
+        for layer, w in zip(self.transformer, W):
+            att, ffn, ln1, ln2 = layer.self_attn, layer.feed_forward, layer.layer_norm_1, layer.layer_norm_2
+            if pre:
+                ops.layernorm_fwd(h, ln1.gamma.data, ln1.beta.data, xn, rows=M, D=E, eps=ln1.eps, mode=1)
+                src = xn
+            ops.quant_mxfp8(src, x_q)
+            ops.gemm_mxfp8(x_q, w["wqkv"], qkv32, bias=w["bqkv"])
+            ops.split_planes(qkv32, qkv_p)                # the attention kernels take bf16 hi / lo planes
+            ops.self_attn_fwd(qkv_p, seg, o32, batch=B, heads=H, L=L, head_dim=hd, scale=scale)
+            ops.quant_mxfp8(o32, x_q)
+            ops.gemm_mxfp8(x_q, w["wo"], h2, bias=att.final_linear.bias.data, resid=h)
+            if pre:                                                   # layers/transformer.py:63-73
+                ops.layernorm_fwd(h2, ln2.gamma.data, ln2.beta.data, xn, rows=M, D=E, eps=ln2.eps, mode=1)
+                ops.quant_mxfp8(xn, x_q)
+                ops.gemm_mxfp8(x_q, w["w1"], None, bias=ffn.linear_1.bias.data, act=1, out_mx=ff_q)
+                ops.gemm_mxfp8(ff_q, w["w2"], h, bias=ffn.linear_2.bias.data, resid=h2)
+            else:                                                     # layers/transformer.py:54-61
+                ops.layernorm_fwd(h2, ln1.gamma.data, ln1.beta.data, xn, rows=M, D=E, eps=ln1.eps, mode=1)
+                ops.quant_mxfp8(xn, x_q)
+                ops.gemm_mxfp8(x_q, w["w1"], None, bias=ffn.linear_1.bias.data, act=1, out_mx=ff_q)
+                ops.gemm_mxfp8(ff_q, w["w2"], h2, bias=ffn.linear_2.bias.data, resid=xn)
+                ops.layernorm_fwd(h2, ln2.gamma.data, ln2.beta.data, h, rows=M, D=E, eps=ln2.eps, mode=1)
+        out = torch.empty(B, L, E, device=dev)
+        if self.final_layernorm:
+            ops.layernorm_fwd(h, self.layer_norm.gamma.data, self.layer_norm.beta.data, out.view(M, E), rows=M, D=E,
+                              eps=self.layer_norm.eps, mode=1)
+        else:
+            out.view(M, E).copy_(h)
+        return out
+
     def _last_layer_first_token(self, ws, layer, w, h, x_p, seg, B, L, E, F):
         """Last layer of the inference schedule for row 0 of every sequence.  h: the layer's input [B*L, E] (fp32); x_p: the
         planes its QKV projection reads (LayerNorm_1(h) for 'pre', h itself for 'post').  K, V: all rows; everything after the
