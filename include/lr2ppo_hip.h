@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 16
+#define LR2_ABI_VERSION 17
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -343,12 +343,17 @@ int lr2_vit_assemble(const void* patch_proj, const void* cls, const void* pos, v
  *   lr2_gemm_mxfp8 : out[M, N] fp32 = A_q . B_q^T (+ bias[N]) (act 1: GELU) (+ resid[M, ld_resid]); A_q [M, K], B_q [N, K] and their
  *                    scales as written by lr2_quant_mxfp8.  N % 128 == 0, K % 128 == 0, any M.  out_q / out_scales (both or neither;
  *                    out may then be NULL): the result also / instead quantised to MX-FP8 [M, N] + [M, N / 32] by the same rule --
- *                    the A operand of the next product without an fp32 round trip.
+ *                    the A operand of the next product without an fp32 round trip.  out_hi / out_lo_off / ld_planes: the result also /
+ *                    instead as bf16 hi / lo planes (the operand format of lr2_self_attn_fwd and of the split-bf16 products).
  * replaces: nn.Linear forward (tencentpretrain/layers/position_ffn.py:12-15, multi_headed_attn.py:55-76) in that mode. */
 int lr2_quant_mxfp8(const void* x, int ldx, void* q, void* scales, int rows, int K, void* stream);
+/* LayerNorm (lr2_layernorm_fwd's semantics, modes 0 / 1) whose result leaves as MX-FP8 [rows, D] + [rows, D / 32] (and as fp32 when out is
+ * given): the A operand of the projection that follows, without an fp32 round trip.  D % 32 == 0. */
+int lr2_layernorm_fwd_mxfp8(const void* x, const void* gamma, const void* beta, void* out, void* out_q, void* out_scales, int rows,
+                            int D, float eps, int mode, void* stream);
 int lr2_gemm_mxfp8(const void* a_q, const void* a_scales, const void* b_q, const void* b_scales, void* out, int ld_out,
-                   const void* bias, const void* resid, int ld_resid, int act, void* out_q, void* out_scales, int M, int N, int K,
-                   void* stream);
+                   const void* bias, const void* resid, int ld_resid, int act, void* out_q, void* out_scales, void* out_hi,
+                   uint64_t out_lo_off, int ld_planes, int M, int N, int K, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ _AB_LIB = os.environ.get("LR2_AB_LIB")     # tools/dbg only: load another build 
 SOURCES = ["gemm.hip", "gemm256.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip", "fp8.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
 
-ABI_VERSION = 16     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
+ABI_VERSION = 17     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
 
 _lock = threading.Lock()
 _lib = None
@@ -120,7 +120,8 @@ SIGNATURES = {
     "lr2_adamw_multi": [_P, _I, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P],
     "lr2_step_scalars_store": [_P, _U64, _P, _I, _P],
     "lr2_quant_mxfp8": [_P, _I, _P, _P, _I, _I, _P],
-    "lr2_gemm_mxfp8": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _I, _P],
+    "lr2_layernorm_fwd_mxfp8": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
+    "lr2_gemm_mxfp8": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _U64, _I, _I, _I, _I, _P],
     "lr2_text_embed": [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.c_int64, _I, _P, _P],
     "lr2_patchify_planes": [_P, _I, _P, _U64, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P],
     "lr2_ndcg": [_P, _P, _P, _P, _P, _I, _P, _I, _P],

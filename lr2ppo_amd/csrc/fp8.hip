@@ -71,6 +71,9 @@ struct Mx8Params {
   int M, N, K, ld_out, ld_resid, act;
   uint8_t* out_q;      // result ALSO / INSTEAD as MX-FP8 [M, N] + scales [M, N / 32] (the next product's A operand): LDS kernel only
   uint8_t* out_s;
+  bf16_t* out_hi;      // result ALSO / INSTEAD as bf16 hi / lo planes [M, ld_planes] (what the attention kernels read): LDS kernel only
+  size_t out_lo_off;
+  int ld_planes;
 };
 
 struct Frags {
@@ -281,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mxfp8_lds_kernel(Mx8Params p) {
           v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
         if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ld_out + n) = v;
+        if (p.out_hi) store_planes4(p.out_hi + (size_t)m * p.ld_planes + n, p.out_lo_off, v);
       }
       if (p.out_q) {
         // a row's 32-column MX block = 8 consecutive lanes x 4 columns (the wave tile's 64 columns are two blocks per row):
@@ -329,17 +333,20 @@ extern "C" int lr2_quant_mxfp8(const void* x, int ldx, void* q, void* scales, in
 }
 
 extern "C" int lr2_gemm_mxfp8(const void* a_q, const void* a_scales, const void* b_q, const void* b_scales, void* out, int ld_out,
-                              const void* bias, const void* resid, int ld_resid, int act, void* out_q, void* out_scales, int M, int N,
-                              int K, void* stream) {
-  if (!a_q || !a_scales || !b_q || !b_scales || (!out && !out_q) || M <= 0 || N <= 0 || K <= 0 || (act != 0 && act != 1)) return LR2_ERR_ARG;
+                              const void* bias, const void* resid, int ld_resid, int act, void* out_q, void* out_scales,
+                              void* out_hi, uint64_t out_lo_off, int ld_planes, int M, int N, int K, void* stream) {
+  if (!a_q || !a_scales || !b_q || !b_scales || (!out && !out_q && !out_hi) || M <= 0 || N <= 0 || K <= 0 || (act != 0 && act != 1))
+    return LR2_ERR_ARG;
+  if (out_hi && (ld_planes < N || ld_planes % 4 || out_lo_off % 4)) return LR2_ERR_SHAPE;
   if ((out_q != nullptr) != (out_scales != nullptr)) return LR2_ERR_ARG;
-  if (N % 128 || K % 128 || ld_out < N || ld_out % 4 || (resid && (ld_resid < N || ld_resid % 4))) return LR2_ERR_SHAPE;
+  if (N % 128 || K % 128 || (out && (ld_out < N || ld_out % 4)) || (resid && (ld_resid < N || ld_resid % 4))) return LR2_ERR_SHAPE;
   Mx8Params p{(const uint8_t*)a_q, (const uint8_t*)a_scales, (const uint8_t*)b_q, (const uint8_t*)b_scales, (float*)out,
-              (const float*)bias, (const float*)resid, M, N, K, ld_out, ld_resid, act, (uint8_t*)out_q, (uint8_t*)out_scales};
+              (const float*)bias, (const float*)resid, M, N, K, ld_out, ld_resid, act, (uint8_t*)out_q, (uint8_t*)out_scales,
+              (bf16_t*)out_hi, (size_t)out_lo_off, ld_planes};
   const int tiles = ((M + 127) / 128) * (N / 128);
   const char* e = getenv("LR2_FP8_LDS");          // 0: fragments straight from global memory (the first version; A/B)
   if (e && atoi(e) == 0) {
-    if (out_q || !out) return LR2_ERR_ARG;          // the first version writes fp32 only
+    if (out_q || out_hi || !out) return LR2_ERR_ARG;          // the first version writes fp32 only
     LR2_LAUNCH(gemm_mxfp8_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
     return lr2_launch_status(__func__);
   }

@@ -18,7 +18,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                                                             bf16_t* __restrict__ out_hi, size_t out_lo_off,
                                                             float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out, int rows, int D, float eps,
-                                                            int mode, int group, uint64_t group_stride) {
+                                                            int mode, int group, uint64_t group_stride,
+                                                            uint8_t* __restrict__ out_q, uint8_t* __restrict__ out_s) {
   const int lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -65,6 +66,25 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
       y.w = (v[i].w - mean) * rstd * g.w + b.w;
       if (out) *reinterpret_cast<float4*>(out + off + e) = y;
       if (out_hi) store_planes4(out_hi + off + e, out_lo_off, y);
+      if (out_q) {
+        // MX-FP8 (csrc/fp8.hip's rule): a 32-column block = 8 consecutive lanes x 4 columns; D % 32 == 0, so a block's lanes are
+        // all inside the row or all outside
+        float amax = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+        int ex = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127 - 8;
+        if (amax < 1.17549435e-38f) ex = -127;
+        if (ex < -127) ex = -127;
+        if (ex > 127) ex = 127;
+        const uint32_t ef = (uint32_t)(127 - ex);
+        const float inv = __uint_as_float(ef ? ef << 23 : 0x00400000u);
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(y.x * inv, -448.f, 448.f), __builtin_amdgcn_fmed3f(y.y * inv, -448.f, 448.f), w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(y.z * inv, -448.f, 448.f), __builtin_amdgcn_fmed3f(y.w * inv, -448.f, 448.f), w, true);
+        *reinterpret_cast<int*>(out_q + (size_t)r * D + e) = w;
+        if ((lane & 7) == 0) out_s[(size_t)r * (D / 32) + (e >> 5)] = (uint8_t)(ex + 127);
+      }
     }
   }
 }
@@ -223,7 +243,18 @@ extern "C" int lr2_layernorm_fwd(const void* x, const void* gamma, const void* b
   if (group <= 0) { group = rows; group_stride = 0; }
   LR2_LAUNCH(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x,
              (const float*)gamma, (const float*)beta, (float*)out, (bf16_t*)out_hi, (size_t)out_lo_off, (float*)mean,
-             (float*)rstd, rows, D, eps, mode, group, group_stride);
+             (float*)rstd, rows, D, eps, mode, group, group_stride, (uint8_t*)nullptr, (uint8_t*)nullptr);
+  return lr2_launch_status(__func__);
+}
+
+extern "C" int lr2_layernorm_fwd_mxfp8(const void* x, const void* gamma, const void* beta, void* out, void* out_q, void* out_scales,
+                                       int rows, int D, float eps, int mode, void* stream) {
+  if (!x || !gamma || !beta || !out_q || !out_scales || rows <= 0) return LR2_ERR_ARG;
+  if (mode != 0 && mode != 1) return LR2_ERR_ARG;
+  if (D % 32 != 0 || D > MAXV * 256 || D < 32) return LR2_ERR_SHAPE;
+  LR2_LAUNCH(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+             (const float*)gamma, (const float*)beta, (float*)out, (bf16_t*)nullptr, (size_t)0, (float*)nullptr,
+             (float*)nullptr, rows, D, eps, mode, rows, (uint64_t)0, (uint8_t*)out_q, (uint8_t*)out_scales);
   return lr2_launch_status(__func__);
 }
 

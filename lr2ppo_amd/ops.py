@@ -716,13 +716,27 @@ def quant_mxfp8(x: torch.Tensor, dst: Optional[Mx8] = None) -> Mx8:
     return dst
 
 
-def gemm_mxfp8(a: Mx8, b: Mx8, out: Optional[torch.Tensor], *, bias=None, resid=None, act: int = 0, out_mx: Optional[Mx8] = None):
+def layernorm_fwd_mxfp8(x, gamma, beta, dst: Mx8, out: Optional[torch.Tensor] = None, *, rows, D, eps=1e-5, mode=0) -> Mx8:
+    """LN(x) as MX-FP8 (and as fp32 when `out` is given) -- lr2_layernorm_fwd_mxfp8."""
+    _chk_f32(x, gamma, beta, out)
+    if dst.rows != rows or dst.cols != D:
+        raise ValueError("layernorm_fwd_mxfp8: destination shape")
+    with _Timed(f"lnfwd_mx_R{rows}_D{D}", 0.0, 5.0 * rows * D):
+        _nat.check(_nat.lib().lr2_layernorm_fwd_mxfp8(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(out), dst.q.data_ptr(),
+                                                      dst.s.data_ptr(), rows, D, eps, mode, _stream()), "lr2_layernorm_fwd_mxfp8")
+    return dst
+
+
+def gemm_mxfp8(a: Mx8, b: Mx8, out: Optional[torch.Tensor], *, bias=None, resid=None, act: int = 0, out_mx: Optional[Mx8] = None,
+               out_planes: Optional[Planes] = None):
     """out[M, N] fp32 = a . b^T (+ bias) (act 1: GELU) (+ resid) with a [M, K], b [N, K] in MX-FP8 (lr2_gemm_mxfp8).
     out_mx: the result also (out given) or only (out None) as MX-FP8 -- the next product's A operand."""
     _chk_f32(out, bias, resid)
     M, N, K = a.rows, b.rows, a.cols
-    if b.cols != K or (out is None and out_mx is None):
-        raise ValueError("gemm_mxfp8: a [M, K], b [N, K], out [M, N] and / or out_mx")
+    if b.cols != K or (out is None and out_mx is None and out_planes is None):
+        raise ValueError("gemm_mxfp8: a [M, K], b [N, K], out [M, N] and / or out_mx / out_planes")
+    if out_planes is not None and (out_planes.rows != M or out_planes.cols != N):
+        raise ValueError("gemm_mxfp8: out_planes must be [M, N]")
     if out is not None and (out.dim() != 2 or out.shape[0] != M or out.shape[1] != N or out.stride(1) != 1):
         raise ValueError("gemm_mxfp8: out must be [M, N] with contiguous rows")
     if out_mx is not None and (out_mx.rows != M or out_mx.cols != N):
@@ -732,8 +746,11 @@ def gemm_mxfp8(a: Mx8, b: Mx8, out: Optional[torch.Tensor], *, bias=None, resid=
                                              out.stride(0) if out is not None else N, _ptr(bias), _ptr(resid),
                                              resid.stride(0) if resid is not None else 0, act,
                                              out_mx.q.data_ptr() if out_mx is not None else None,
-                                             out_mx.s.data_ptr() if out_mx is not None else None, M, N, K, _stream()), "lr2_gemm_mxfp8")
-    return out if out is not None else out_mx
+                                             out_mx.s.data_ptr() if out_mx is not None else None,
+                                             out_planes.data_ptr() if out_planes is not None else None,
+                                             out_planes.lo_off if out_planes is not None else 0,
+                                             out_planes.cols if out_planes is not None else 0, M, N, K, _stream()), "lr2_gemm_mxfp8")
+    return out if out is not None else (out_mx if out_mx is not None else out_planes)
 
 
 def text_embed(src, seg, word, pos, seg_table, out, *, rows, L, D, err: Optional[torch.Tensor] = None):

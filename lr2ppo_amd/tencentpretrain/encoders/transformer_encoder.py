@@ -250,33 +250,29 @@ class TransformerEncoder(nn.Module):
         W = self._fp8_weights()
         pre = self.layernorm_positioning == "pre"
         h, h2, xn = ws.mat("h", M, E), ws.mat("h2", M, E), ws.mat("fp8_xn", M, E)
-        qkv32, o32 = ws.mat("fp8_qkv", M, 3 * E), ws.mat("fp8_o", M, E)
+        o32 = ws.mat("fp8_o", M, E)
         qkv_p = ws.planes("qkv_p", M, 3 * E)
         if getattr(self, "_fp8_act", None) is None or self._fp8_act[0].rows != M:
             self._fp8_act = (ops.Mx8.empty(M, E, dev), ops.Mx8.empty(M, F, dev))
         x_q, ff_q = self._fp8_act
         h.copy_(emb.contiguous().view(M, E))
         scale = 1.0 / math.sqrt(float(hd))
-        src = h                                           # what the QKV projection reads ('post': the stream itself)
         for layer, w in zip(self.transformer, W):
             att, ffn, ln1, ln2 = layer.self_attn, layer.feed_forward, layer.layer_norm_1, layer.layer_norm_2
             if pre:
-                ops.layernorm_fwd(h, ln1.gamma.data, ln1.beta.data, xn, rows=M, D=E, eps=ln1.eps, mode=1)
-                src = xn
-            ops.quant_mxfp8(src, x_q)
-            ops.gemm_mxfp8(x_q, w["wqkv"], qkv32, bias=w["bqkv"])
-            ops.split_planes(qkv32, qkv_p)                # the attention kernels take bf16 hi / lo planes
+                ops.layernorm_fwd_mxfp8(h, ln1.gamma.data, ln1.beta.data, x_q, rows=M, D=E, eps=ln1.eps, mode=1)
+            else:
+                ops.quant_mxfp8(h, x_q)
+            ops.gemm_mxfp8(x_q, w["wqkv"], None, bias=w["bqkv"], out_planes=qkv_p)     # the attention kernels take bf16 hi / lo planes
             ops.self_attn_fwd(qkv_p, seg, o32, batch=B, heads=H, L=L, head_dim=hd, scale=scale)
             ops.quant_mxfp8(o32, x_q)
             ops.gemm_mxfp8(x_q, w["wo"], h2, bias=att.final_linear.bias.data, resid=h)
             if pre:                                                   # layers/transformer.py:63-73
-                ops.layernorm_fwd(h2, ln2.gamma.data, ln2.beta.data, xn, rows=M, D=E, eps=ln2.eps, mode=1)
-                ops.quant_mxfp8(xn, x_q)
+                ops.layernorm_fwd_mxfp8(h2, ln2.gamma.data, ln2.beta.data, x_q, rows=M, D=E, eps=ln2.eps, mode=1)
                 ops.gemm_mxfp8(x_q, w["w1"], None, bias=ffn.linear_1.bias.data, act=1, out_mx=ff_q)
                 ops.gemm_mxfp8(ff_q, w["w2"], h, bias=ffn.linear_2.bias.data, resid=h2)
             else:                                                     # layers/transformer.py:54-61
-                ops.layernorm_fwd(h2, ln1.gamma.data, ln1.beta.data, xn, rows=M, D=E, eps=ln1.eps, mode=1)
-                ops.quant_mxfp8(xn, x_q)
+                ops.layernorm_fwd_mxfp8(h2, ln1.gamma.data, ln1.beta.data, x_q, xn, rows=M, D=E, eps=ln1.eps, mode=1)
                 ops.gemm_mxfp8(x_q, w["w1"], None, bias=ffn.linear_1.bias.data, act=1, out_mx=ff_q)
                 ops.gemm_mxfp8(ff_q, w["w2"], h2, bias=ffn.linear_2.bias.data, resid=xn)
                 ops.layernorm_fwd(h2, ln2.gamma.data, ln2.beta.data, h, rows=M, D=E, eps=ln2.eps, mode=1)

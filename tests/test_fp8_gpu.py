@@ -76,6 +76,9 @@ def test_product_can_hand_its_result_on_as_mx_fp8(dev):
     ops.gemm_mxfp8(am, bm, out, bias=bias.to(dev), act=1, out_mx=mx)
     want = ops.quant_mxfp8(out)
     assert torch.equal(mx.s, want.s) and torch.equal(mx.q, want.q)
+    pl = ops.Planes.empty(M, N, dev)                     # ... and as bf16 hi / lo planes: the split of the same fp32 row
+    ops.gemm_mxfp8(am, bm, None, bias=bias.to(dev), act=1, out_planes=pl)
+    assert torch.equal(pl.buf, ops.split_planes(out, ops.Planes.empty(M, N, dev)).buf)
     only = ops.Mx8.empty(M, N, dev)
     ops.gemm_mxfp8(am, bm, None, bias=bias.to(dev), act=1, out_mx=only)
     assert torch.equal(only.s, want.s) and torch.equal(only.q, want.q)
@@ -112,3 +115,19 @@ def test_encoder_forward_fp8_stays_near_the_default_forward(dev, positioning):
     rel = float((got - ref).norm() / ref.norm())
     print(f"{positioning}-LN, 3 layers: forward_fp8 vs forward, relative L2 distance {rel:.3e}")
     assert rel < 0.15
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_layernorm_can_leave_as_mx_fp8(dev, mode):
+    """lr2_layernorm_fwd_mxfp8 = lr2_layernorm_fwd followed by lr2_quant_mxfp8 of its fp32 result, byte for byte."""
+    from lr2ppo_amd import ops
+    g = torch.Generator(device=dev).manual_seed(4)
+    rows, D = 301, 768
+    x = torch.randn(rows, D, device=dev, generator=g) * 3
+    gamma, beta = torch.randn(D, device=dev, generator=g), torch.randn(D, device=dev, generator=g)
+    ref32 = torch.empty(rows, D, device=dev)
+    ops.layernorm_fwd(x, gamma, beta, ref32, rows=rows, D=D, eps=1e-6, mode=mode)
+    want = ops.quant_mxfp8(ref32)
+    got, out32 = ops.Mx8.empty(rows, D, dev), torch.empty(rows, D, device=dev)
+    ops.layernorm_fwd_mxfp8(x, gamma, beta, got, out32, rows=rows, D=D, eps=1e-6, mode=mode)
+    assert torch.equal(out32, ref32) and torch.equal(got.s, want.s) and torch.equal(got.q, want.q)

@@ -162,7 +162,8 @@ def test_no_cpu_fallback_and_bad_arguments_are_errors(native, small_models):
     assert lib.lr2_adamw_multi(None, 0, 1e-3, 0.9, 0.999, 1e-6, None, None) == -1
     assert lib.lr2_step_scalars_store(None, 1, None, 0, None) == -1
     assert lib.lr2_quant_mxfp8(None, 0, None, None, 1, 32, None) == -1
-    assert lib.lr2_gemm_mxfp8(None, None, None, None, None, 0, None, None, 0, 0, None, None, 1, 128, 128, None) == -1
+    assert lib.lr2_layernorm_fwd_mxfp8(None, None, None, None, None, None, 1, 768, 1e-6, 1, None) == -1
+    assert lib.lr2_gemm_mxfp8(None, None, None, None, None, 0, None, None, 0, 0, None, None, None, 0, 0, 1, 128, 128, None) == -1
     assert lib.lr2_step_scalars_store(None, 1, None, 15, None) == -1         # at most LR2_STEP_SCALARS_MAX_LRS rates
 
 
