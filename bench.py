@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--fuse-fc1", type=int, default=1, choices=[0, 1],
                     help="1: AdamW step of out_layer.fc1.weight inside its weight-gradient GEMM (default); 0: separate passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=1, help="measured CPU-baseline steps at --batch (after one untimed warm-up step)")
+    ap.add_argument("--cpu-steps", type=int, default=3,
+                    help="measured CPU-baseline steps at --batch (after one untimed warm-up step); the median is reported (BASELINE.md 3)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE configs[4] figures (ViT-L/14 tower + projection, MX-FP8)")
     ap.add_argument("--no-online", action="store_true",
                     help="head-only run: skip the composed loop (then `value` is the head-only rate and the line says so)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed regions")
@@ -82,10 +84,14 @@ def _roofline(key, rec, passes, note=None):
         alg = rec["flops"] / (avg_ms * 1e-3) / 1e12
         ach = passes * alg if key.startswith("gemm") else alg
         return {"kernel": key, "bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_BF16_PEAK_TF, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": rec["n"],
+                "frac": round(ach / MFMA_BF16_PEAK_TF, 4), "frac_algorithmic": round(alg / MFMA_BF16_PEAK_TF, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches": rec["n"],
                 "algorithmic_tflops_fp32_equivalent": round(alg, 1), "flops_per_launch": int(passes * rec["flops"]),
+                "algorithmic_flops_per_launch": int(rec["flops"]),
                 "note": note or ("achieved = bf16 MFMA flops issued per launch (%d split-bf16 products x 2MNK, the algorithm's own "
-                                 "count) / average launch duration; algorithmic_tflops_fp32_equivalent = 2MNK / duration" % passes)}
+                                 "count) / average launch duration; frac_algorithmic = (2MNK / duration) / the same bf16 peak -- SURVEY "
+                                 "8(d)'s count, i.e. the useful fp32-grade flops (the chip's native fp32-matrix peak is 157 TFLOP/s = "
+                                 "0.063 on this scale)" % passes)}
     ach = rec["bytes"] / (avg_ms * 1e-3) / 1e9
     return {"kernel": key, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": rec["n"]}
@@ -99,8 +105,49 @@ def _pmc(key):
         return None
 
 
+def launcher_command(gpus: int, argv, script: str, port: int):
+    """What `python bench.py --gpus N` (N > 1) runs when no launcher set WORLD_SIZE: the reference's own way of starting ranks
+    (ppo.sh:59: torchrun, one process per GPU), on this node, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script] + list(argv)
+
+
+def self_launch(gpus: int, argv, script: str = os.path.abspath(__file__)) -> int:
+    """Start `gpus` ranks of `script` as a FRESH child process tree (this process has made no GPU call and makes none: it never
+    re-execs, it only waits), relay rank 0's JSON line, and fail loudly -- non-zero exit -- when a rank fails, when no line comes
+    back, or when the line does not report n_gpus == gpus."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), LR2_BENCH_CHILD="1")
+    p = subprocess.run(launcher_command(gpus, argv, script, port), env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0:
+        print(f"[bench] the {gpus}-rank run failed (exit code {p.returncode})", file=sys.stderr)
+        return p.returncode or 1
+    try:
+        n = json.loads(line)["n_gpus"] if line else None
+    except (ValueError, KeyError):
+        n = None
+    if n != gpus:
+        print(f"[bench] asked for {gpus} ranks, the result line reports n_gpus = {n}: refusing to pass it on", file=sys.stderr)
+        return 3
+    print(line)
+    return 0
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (before anything touches the GPU)
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -113,8 +160,15 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL ("nccl") is the product path; LR2_BENCH_BACKEND=gloo exists only to rehearse the N > 1 code on one GPU
         dist.init_process_group(os.environ.get("LR2_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
-    if a.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    if a.gpus != world:
+        raise SystemExit(f"bench: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    ranks_seen = 1
+    if world > 1:        # every rank really is in the job: an all-reduce of ones over the product's backend
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)
+        ranks_seen = int(probe.item())
+        if ranks_seen != dist.get_world_size():
+            raise SystemExit(f"bench: the all-reduce probe saw {ranks_seen} ranks of {dist.get_world_size()}")
 
     if a.serial_streams:
         os.environ["LR2_PPO_STREAMS"] = "0"
@@ -223,6 +277,18 @@ def main():
             fence()
             prof_excl = ops.profile_stop()
     head_dt = max_over_ranks(head_dt)
+    # the ONE-stream schedule, eager: what world > 1 runs by default, so that the N = 1 -> N = 2 step of a scaling
+    # curve can be read against the same schedule at N = 1
+    one_stream_ms = None
+    if two_streams:
+        with exclusive_launches():
+            step(0)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                step(1 + i)
+            fence()
+            one_stream_ms = max_over_ranks(time.perf_counter() - t0) / a.steps * 1e3
 
     # the same head-only step captured in a HIP graph (ppo.GraphedPPOStep: dropout seeds and learning rates in device memory),
     # two-stream schedule and one-stream schedule: host cost of one replay on an empty queue, and the step time
@@ -318,11 +384,13 @@ def main():
         unit = "PPO steps/s, HEAD ONLY (--no-online): 1 rollout batch + 1 update minibatch on pre-extracted features, 32 items x 2 tags per GPU"
         workload = "LR2PPO stage-3 head-only PPO step on LRMovieNet-shaped synthetic features: text_emb [32,2,196,768], img_emb [32,16,768]"
     out = {
-        "metric": "ppo_steps_per_sec", "value": round(value, 3), "unit": unit, "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "metric": "ppo_steps_per_sec", "value": round(value, 3), "unit": unit, "n_gpus": world, "rccl_ranks_seen": ranks_seen,
+        "backend": (dist.get_backend() if world > 1 else None), "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 (GEMMs: split-bf16 x3 on MFMA, fp32 accumulate)" if a.passes == 3 else "bf16 inputs, fp32 accumulate (1 pass)",
         "data": "synthetic",
         "head_only_steps_per_sec": round(head_rate, 3), "head_only_ms_per_step": round(head_dt / a.steps * 1e3, 3),
+        "head_only_one_stream_ms": None if one_stream_ms is None else round(one_stream_ms, 3),
         "head_only_graph": graphed,
         "config": {"workload": workload, "batch_per_gpu": a.batch, "tags": a.tags, "global_batch": a.batch * world,
                    "parallelism": f"dp{world}", "schedule": sched, "items_per_sec": round(value * a.batch, 1),
@@ -584,6 +652,72 @@ def main():
                         "v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 elements: NOT within north_star's 1e-3 -- a separate mode, never "
                         "part of `value`), LayerNorm / attention / residual stream as in the default path"}
             del vl, limg, lseg, lemb, ref, got
+        # BASELINE configs[4] COMPOSED: "Reward-pair training + PPO, ViT-L/14 encoder swap, fp8 MFMA" -- the image tower is ViT-L/14
+        # (24 layers, 257 tokens) ending in the 1024 -> 768 visual projection, the text tower RoBERTa-base, both frozen and in line,
+        # every encoder projection an MX-FP8 product (FeatureExtractor(precision="mxfp8")); behind them (i) the PPO step of `value`
+        # (32 items x 2 tags) and (ii) one stage-2 reward-pair step at the launcher's batch (reward_pair_dataloader.sh:21: 64 items,
+        # 2 tags per training item).  The same two steps with the towers in split-bf16 are timed beside them.
+        if not a.no_config5:
+            from lr2ppo_amd.finetune import reward_pair_dataloader as rp
+            from lr2ppo_amd.finetune.features import VIT_L14_CONFIG, encoder_args
+            torch.manual_seed(12)
+            fx5 = FeatureExtractor(encoder_args(VIT_L14_CONFIG), precision="mxfp8")
+            fx5.init_normal()
+            fx5 = fx5.to(dev).eval()
+            pargs5 = argparse.Namespace(**{**vars(margs), "train_steps": 1000, "batch_size": 64})
+            rmodel = rp.Classifier(pargs5, None).to(dev)
+            with torch.no_grad():
+                for p in rmodel.parameters():
+                    p.normal_(0, 0.02)
+            ropt, rsch = rp.build_optimizer(pargs5, rmodel)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for _ in range(20):
+                    rsch.step()
+            rmodel.train()
+            g5 = torch.Generator(device=dev).manual_seed(5000)
+            raw64 = synthetic_raw_batch(64, 2, device=dev, generator=g5)
+            lay = torch.tensor([[0, 1, 0, 1], [1, 0, 0, 1]], device=dev)[torch.randint(0, 2, (64,), device=dev, generator=g5)]
+            chosen5, reject5 = lay, torch.cat([lay[:, :2], lay[:, 2:].flip(1)], dim=1)
+
+            def c5_ppo(i):
+                frames, ids, seg, tg = raw[i % len(raw)]
+                text, img = fx5.extract(frames, ids, seg, check_ids=False)
+                return ppo_step(text, img, tg)
+
+            def c5_pair(i):
+                frames, ids, seg, tg = raw64
+                text, img = fx5.extract(frames, ids, seg, check_ids=False)
+                return rp.train_model(pargs5, rmodel, ropt, rsch, text, img, tg, chosen5, reject5)[0]
+
+            c5 = {}
+            n5 = max(3, min(a.steps, 5))
+            for prec in ("mxfp8", "split_bf16"):
+                fx5.precision = prec
+                for name, fn in (("ppo_step", c5_ppo), ("reward_pair_step", c5_pair)):
+                    for i in range(2):
+                        r5 = fn(i)
+                    fence()
+                    t0 = time.perf_counter()
+                    for i in range(n5):
+                        r5 = fn(i)
+                    fence()
+                    dt5 = (time.perf_counter() - t0) / n5
+                    if not torch.isfinite(r5).all():
+                        raise SystemExit(f"bench: non-finite result in the config-5 {name} ({prec})")
+                    c5[f"{name}_{prec}_ms"] = round(dt5 * 1e3, 3)
+            fx5.text.embedding.check_ids()
+            out["config5_step_ms"] = c5["ppo_step_mxfp8_ms"]
+            out["config5_steps_per_sec"] = round(1e3 / c5["ppo_step_mxfp8_ms"], 3)
+            out["config5_reward_pair_step_ms"] = c5["reward_pair_step_mxfp8_ms"]
+            out["config"]["config5"] = dict(c5, steps=n5, measured=True, workload=(
+                "BASELINE configs[4] on one GPU: uint8 frames + token ids -> ViT-L/14 (24 layers, 257 tokens) + visual projection "
+                "1024 -> 768 and RoBERTa-base, frozen, in line -> (ppo_step) the PPO step of `value`, 32 items x 2 tags; "
+                "(reward_pair_step) one finetune/reward_pair_dataloader.py train step, 64 items x 2 tags (1024 frames).  mxfp8: every "
+                "encoder projection on v_mfma_scale_f32_16x16x128_f8f6f4 -- features a few per cent from the split-bf16 ones, score / "
+                "pair-order / NDCG@3 drift measured in tests/test_config5_gpu.py; config5_step_ms = ppo_step_mxfp8_ms"))
+            del fx5, rmodel, ropt, rsch, raw64
+            torch.cuda.empty_cache()
         del fx, raw
     # ================= [D] CPU baseline: the oracle on this box's host cores, bounded sample =================
     if world == 1 and not a.no_cpu_baseline:
@@ -591,12 +725,12 @@ def main():
         torch.cuda.empty_cache()
         from oracle import cpu_baseline
         r = cpu_baseline.time_ppo_steps(a.batch, a.tags, steps=a.cpu_steps, warmup_bs=2)
-        sample = (f"oracle (torch CPU fp32, dropout on in the update) on {r['steps']} measured PPO step(s) at batch {a.batch} x {a.tags} "
+        sample = (f"oracle (torch CPU fp32, dropout on in the update): MEDIAN of {r['steps']} measured PPO step(s) at batch {a.batch} x {a.tags} "
                   f"tags after one untimed warm-up step at batch {r['warmup_bs']} (Adam state allocation): rollout {r['rollout_s']:.1f}s + "
                   f"update fwd/bwd {r['fwd_bwd_s']:.1f}s + AdamW(1.045B) {r['adamw_s']:.1f}s = {r['total_s']:.1f}s per head-only step")
         total = r["total_s"]
         if online is not None:
-            fb = max(1, a.batch // 16)         # ~10 s of host time for 2 of 32 items; the encoders are per-frame / per-sequence
+            fb = max(1, a.batch // 4)          # 8 of 32 items (~40 s of host time); the encoders are per-frame / per-sequence
             fe = cpu_baseline.time_feature_extraction(fb, a.tags) * (a.batch / fb)
             total += fe
             sample += (f"; + dual-encoder forward (oracle ViT-B/16 + RoBERTa-base, 12 layers each) timed on {fb} of the {a.batch} items "

@@ -15,6 +15,12 @@ module is that missing stage, built from the reference's own TencentPretrain com
 
 `img_emb` is shared by the T tags of an item (the reference materialises the repeat at finetune/ppo.py:831; the heads
 accept the shared form).  Everything runs on the HIP kernels of this package; there is no CPU path.
+
+An image tower wider than the heads' feature width (BASELINE.json configs[4]: ViT-L/14, hidden 1024, in front of heads that
+hard-code 768: finetune/ppo.py:202-208,219-220) ends in a `VisualProjection` -- the bias-free `[hidden_img -> visual_feat_dim]`
+map CLIP applies to its pooled [CLS] row (`x = ln_post(x[:, 0, :]) @ proj`, the `encode_image` preprocess.py:59-61,83 calls to make
+the reference's img_emb); absent when the widths agree.  `precision="mxfp8"` routes both stacks through the MX-FP8 products of
+csrc/fp8.hip (inference only; the parity path stays split-bf16).
 """
 from __future__ import annotations
 
@@ -26,13 +32,14 @@ from typing import Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import engine, ops
 from ..tencentpretrain.embeddings import Embedding, str2embedding
 from ..tencentpretrain.encoders import str2encoder
 from ..tencentpretrain.opts import finetune_opts, tokenizer_opts
 
 _CFG_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "configs")
 VIT_CONFIG = os.path.join(_CFG_DIR, "vit_base_16_224.json")
+VIT_L14_CONFIG = os.path.join(_CFG_DIR, "vit_large_14_224.json")       # BASELINE.json configs[4]: the image-tower swap
 TEXT_CONFIG = os.path.join(_CFG_DIR, "roberta_base.json")
 ROBERTA_VOCAB = 50265      # models/huggingface_gpt2_vocab.txt + the xlm-roberta specials used by roberta_base_en_model
 
@@ -68,22 +75,105 @@ class EncoderStack(nn.Module):
         return self.encoder.forward_first_token(self.embedding(src, seg), seg)
 
 
+class VisualProjection(nn.Module):
+    """The map from the image tower's width to the heads' feature width: `y = x @ weight.T`, bias-free, on the pooled [CLS]
+    rows -- CLIP's `proj` behind `ln_post` (the encoder stack's final LayerNorm plays ln_post here).  `weight` keeps nn.Linear's
+    `[out, in]` orientation; state_dict key `visual_projection.weight`.  Forward, input gradient and weight gradient are the
+    package's GEMM kernel (fp32 operands, split-bf16 products: engine.linear_fwd / linear_dgrad / linear_wgrad)."""
+
+    def __init__(self, hidden: int, feat: int):
+        super().__init__()
+        self.in_features, self.out_features = hidden, feat
+        self.weight = nn.Parameter(torch.empty(feat, hidden))
+        nn.init.normal_(self.weight, 0.0, hidden ** -0.5)       # CLIP's own initialiser for `proj` (scale = width ** -0.5)
+        self._ws = None
+        self._gflat = None
+
+    def _workspace(self, dev):
+        if self._ws is None or self._ws.device != dev:
+            self._ws = engine.Workspace(dev)
+        return self._ws
+
+    @torch.no_grad()
+    def _fwd(self, x):
+        if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 2 or x.shape[1] != self.in_features:
+            raise TypeError(f"VisualProjection: a float32 [rows, {self.in_features}] tensor on the HIP device")
+        x = x.contiguous()
+        n = x.shape[0]
+        out = torch.empty(n, self.out_features, device=x.device)
+        engine.linear_fwd(self._workspace(x.device), x, self.weight.data, None, out, n, self.out_features, self.in_features)
+        return out
+
+    @torch.no_grad()
+    def _bwd(self, x, dy, dw, need_dx=True):
+        """dw [out, in] <- dy^T x (overwritten); -> dx [rows, in] = dy W, or None."""
+        ws, n = self._workspace(x.device), x.shape[0]
+        x, dy = x.contiguous(), dy.contiguous()
+        engine.linear_wgrad(ws, dy, x, dw, None, n, self.in_features, self.out_features)
+        if not need_dx:
+            return None
+        dx = torch.empty(n, self.in_features, device=x.device)
+        engine.linear_dgrad(ws, dy, self.weight.data, dx, n, self.in_features, self.out_features)
+        return dx
+
+    def grad_buffers(self):
+        """{parameter: gradient}: one persistent tensor (see TransformerEncoder.grad_buffers)."""
+        dev = self.weight.device
+        if self._gflat is None or self._gflat.device != dev:
+            self._gflat = torch.zeros(self.weight.numel(), device=dev)
+            self._gviews = {self.weight: self._gflat.view_as(self.weight)}
+        return self._gviews
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return _ProjectionFn.apply(self, x, self.weight)
+        return self._fwd(x)
+
+
+class _ProjectionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, x, weight):
+        ctx.mod, ctx.need_dx = mod, x.requires_grad
+        ctx.save_for_backward(x)
+        return mod._fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dw = torch.empty_like(ctx.mod.weight)
+        dx = ctx.mod._bwd(x, dy, dw, need_dx=ctx.need_dx)
+        return None, dx, (dw if ctx.mod.weight.requires_grad else None)
+
+
 class FeatureExtractor(nn.Module):
-    """ViT-B/16 over the frames of an item and RoBERTa-base over its tags' token sequences (module docstring).
-    `image` / `text` are EncoderStacks whose state_dict keys are the reference's (`embedding.patch.*`,
-    `encoder.transformer.{i}.*`, ...), so `vit_base_patch16_224_model.bin` / `roberta_base_en_model.bin` load with
-    `load_pretrained`."""
+    """An image tower (ViT-B/16; ViT-L/14 with `vit_args=encoder_args(VIT_L14_CONFIG)`) over the frames of an item and RoBERTa-base
+    over its tags' token sequences (module docstring).  `image` / `text` are EncoderStacks whose state_dict keys are the reference's
+    (`embedding.patch.*`, `encoder.transformer.{i}.*`, ...), so `vit_base_patch16_224_model.bin` / `roberta_base_en_model.bin` load
+    with `load_pretrained`.  feat_dim: the width of both outputs = the heads' `visual_feat_dim` (default: the text stack's hidden
+    size); an image tower of another width gets `visual_projection` (VisualProjection) behind its pooled row.
+    precision: "split_bf16" (default: the fp32-grade parity path) or "mxfp8" -- extract() / no-grad forward() run every
+    projection of both stacks as an MX-FP8 product (TransformerEncoder.forward_fp8); training paths refuse that mode."""
+
+    PRECISIONS = ("split_bf16", "mxfp8")
 
     def __init__(self, vit_args: Optional[argparse.Namespace] = None, text_args: Optional[argparse.Namespace] = None,
-                 vocab_size: int = ROBERTA_VOCAB, seq_length: int = 196):
+                 vocab_size: int = ROBERTA_VOCAB, seq_length: int = 196, feat_dim: Optional[int] = None,
+                 precision: str = "split_bf16"):
         super().__init__()
         self.vit_args = vit_args or encoder_args(VIT_CONFIG)
         self.text_args = text_args or encoder_args(TEXT_CONFIG)
         self.seq_length = seq_length
-        if self.vit_args.hidden_size != self.text_args.hidden_size:
-            raise ValueError("image and text encoders must share the feature width (the heads take one visual_feat_dim)")
+        self.feat_dim = int(feat_dim or self.text_args.hidden_size)
+        if self.text_args.hidden_size != self.feat_dim:
+            raise ValueError("the text stack feeds text_proj directly (finetune/ppo.py:202,215): its hidden size must equal the "
+                             f"heads' feature width {self.feat_dim}, got {self.text_args.hidden_size}")
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {self.PRECISIONS}")
+        self.precision = precision
         self.image = EncoderStack(self.vit_args, vocab_size)
         self.text = EncoderStack(self.text_args, vocab_size)
+        self.visual_projection = (VisualProjection(self.vit_args.hidden_size, self.feat_dim)
+                                  if self.vit_args.hidden_size != self.feat_dim else None)
         self.text.embedding.defer_id_check = True          # one check per extract() at its end, not one sync per call
 
     def load_pretrained(self, vit_path: Optional[str] = None, text_path: Optional[str] = None):
@@ -108,8 +198,23 @@ class FeatureExtractor(nn.Module):
         seg = torch.ones(B * n_img, L, dtype=torch.int64, device=frames.device)
         # pooling(h, seg, "first") of utils/misc.py:23-35 = (h * seg)[:, 0, :]: only token 0 of the encoder output is consumed,
         # so the last layer is evaluated for that token only (inference; bit-for-bit the full schedule's kernels on B rows)
-        h0 = self.image.forward_first_token(flat, seg)
-        return (h0 * seg[:, :1].type_as(h0)).reshape(B, n_img, -1)
+        if self._fp8_now():
+            h0 = self.image.encoder.forward_fp8(self.image.embedding(flat, seg), seg, first_only=True)
+        else:
+            h0 = self.image.forward_first_token(flat, seg)
+        h0 = h0 * seg[:, :1].type_as(h0)
+        if self.visual_projection is not None:
+            h0 = self.visual_projection(h0)
+        return h0.reshape(B, n_img, -1)
+
+    def _fp8_now(self) -> bool:
+        """True when this call takes the MX-FP8 route: precision "mxfp8" and nothing asks for gradients or dropout."""
+        if self.precision != "mxfp8":
+            return False
+        if self.training or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("FeatureExtractor(precision='mxfp8') is an inference mode (frozen feature extraction: "
+                                      "extract(), or eval() under torch.no_grad()); train the encoders in 'split_bf16'")
+        return True
 
     def text_features(self, ids: torch.Tensor, seg: Optional[torch.Tensor] = None) -> torch.Tensor:
         """ids [B, T, L] int64 (+ seg [B, T, L]; default all ones) -> text_emb [B, T, L, hidden]."""
@@ -118,7 +223,11 @@ class FeatureExtractor(nn.Module):
             raise ValueError(f"token sequences must have length {self.seq_length} (finetune/ppo.py:219-220), got {L}")
         if seg is None:
             seg = torch.ones_like(ids)
-        h = self.text(ids.reshape(B * T, L), seg.reshape(B * T, L))
+        ids2, seg2 = ids.reshape(B * T, L), seg.reshape(B * T, L)
+        if self._fp8_now():
+            h = self.text.encoder.forward_fp8(self.text.embedding(ids2, seg2), seg2)
+        else:
+            h = self.text(ids2, seg2)
         return h.reshape(B, T, L, -1)
 
     def forward(self, frames, ids, seg=None) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -135,23 +244,27 @@ class FeatureExtractor(nn.Module):
     # gradients (engine_backward(input_grads=True)) and writes every encoder / embedding gradient into persistent flat buffers
     # that bind_grads() exposes as p.grad.  Same kernels and numerics as the autograd route (Actor(*fx(frames, ids, seg)) with
     # loss.backward()), which stays available; this one allocates nothing per step but the activation arenas.
-    def _stacks(self):
-        return ((self.image.embedding, self.image.encoder), (self.text.embedding, self.text.encoder))
+    def _grad_modules(self):
+        """Modules with a persistent flat gradient buffer, in backward order of completion (text stack first)."""
+        mods = [self.text.encoder, self.text.embedding]
+        if self.visual_projection is not None:
+            mods.append(self.visual_projection)
+        return mods + [self.image.encoder, self.image.embedding]
 
     def bind_grads(self):
-        """p.grad of every encoder / embedding parameter -> its slice of the module's persistent gradient buffer."""
-        for emb, enc in self._stacks():
-            for mod in (emb, enc):
-                for q, g in mod.grad_buffers().items():
-                    if q.grad is None or q.grad.data_ptr() != g.data_ptr():
-                        q.grad = g
+        """p.grad of every encoder / embedding / projection parameter -> its slice of the module's persistent gradient buffer."""
+        for mod in self._grad_modules():
+            for q, g in mod.grad_buffers().items():
+                if q.grad is None or q.grad.data_ptr() != g.data_ptr():
+                    q.grad = g
 
-    def grad_flats(self):
-        """The four flat gradient buffers (image embedding / encoder, text embedding / encoder): what a data-parallel run
-        all-reduces, one collective each."""
+    def grad_flats(self, part: Optional[str] = None):
+        """The flat gradient buffers (text encoder / embedding, [visual projection,] image encoder / embedding): what a
+        data-parallel run all-reduces, one collective each.  part: "text" / "image" = that tower's buffers only."""
         out = []
-        for emb, enc in self._stacks():
-            for mod in (emb, enc):
+        for mod in self._grad_modules():
+            is_text = mod is self.text.encoder or mod is self.text.embedding
+            if part is None or (part == "text") == is_text:
                 mod.grad_buffers()
                 out.append(mod._gflat)
         return out
@@ -163,6 +276,8 @@ class FeatureExtractor(nn.Module):
         multi_headed_attn.py:68); ctx goes to backward_train."""
         if not frames.is_cuda or not ids.is_cuda:
             raise TypeError("lr2ppo_amd: frames / ids must live on the HIP device (no CPU path)")
+        if self.precision != "split_bf16":
+            raise NotImplementedError("forward_train: the encoders train in 'split_bf16' (precision='mxfp8' is inference only)")
         B, n_img = frames.shape[:2]
         T, L = ids.shape[1:]
         if L != self.seq_length:
@@ -172,27 +287,37 @@ class FeatureExtractor(nn.Module):
         vseg = torch.ones(B * n_img, self.vit_args.max_seq_length, dtype=torch.int64, device=frames.device)
         e_img, s_img_emb = self.image.embedding._run(frames.reshape(B * n_img, *frames.shape[2:]), vseg, save=True)
         h_img, s_img_enc = self.image.encoder._forward_train(e_img, vseg)
-        img_emb = h_img[:, 0, :].reshape(B, n_img, -1).contiguous()      # pooling 'first' with seg == 1 (utils/misc.py:23-35)
+        cls = h_img[:, 0, :].contiguous()                                # pooling 'first' with seg == 1 (utils/misc.py:23-35)
+        img_emb = (cls if self.visual_projection is None else self.visual_projection._fwd(cls)).reshape(B, n_img, -1)
         tseg = seg.reshape(B * T, L)
         e_txt, s_txt_emb = self.text.embedding._run(ids.reshape(B * T, L), tseg, save=True)
         h_txt, s_txt_enc = self.text.encoder._forward_train(e_txt, tseg)
         text_emb = h_txt.reshape(B, T, L, -1).clone()                    # not a view of the activation arena
-        ctx = {"img": (s_img_emb, s_img_enc, tuple(h_img.shape)), "txt": (s_txt_emb, s_txt_enc)}
+        ctx = {"img": (s_img_emb, s_img_enc, tuple(h_img.shape), cls if self.visual_projection is not None else None),
+               "txt": (s_txt_emb, s_txt_enc)}
         return text_emb, img_emb, ctx
 
     @torch.no_grad()
-    def backward_train(self, ctx, d_text, d_img):
-        """Gradients of every encoder / embedding parameter for the forward that produced ctx, given d loss / d text_emb and
-        d loss / d img_emb; written into the persistent buffers (bind_grads())."""
+    def backward_train(self, ctx, d_text, d_img, after_text=None):
+        """Gradients of every encoder / embedding / projection parameter for the forward that produced ctx, given
+        d loss / d text_emb and d loss / d img_emb; written into the persistent buffers (bind_grads()).
+        after_text: called once the text tower's gradients are complete (its buffers can start travelling -- the data-parallel
+        all-reduce of ~500 MB -- while the image tower's backward still runs)."""
         s_txt_emb, s_txt_enc = ctx.pop("txt")
         B_, L, E = s_txt_enc["dims"][:3]
         d_emb, _ = self.text.encoder._backward_train(s_txt_enc, d_text.reshape(B_, L, E).contiguous(),
                                                      G=self.text.encoder.grad_buffers())
         self.text.embedding._backward(s_txt_emb, d_emb, G_out=self.text.embedding.grad_buffers())
         del s_txt_enc, s_txt_emb, d_emb
-        s_img_emb, s_img_enc, hshape = ctx.pop("img")
+        if after_text is not None:
+            after_text()
+        s_img_emb, s_img_enc, hshape, cls = ctx.pop("img")
+        d_cls = d_img.reshape(hshape[0], -1)
+        if self.visual_projection is not None:
+            vp = self.visual_projection
+            d_cls = vp._bwd(cls, d_cls, vp.grad_buffers()[vp.weight])
         dout = torch.zeros(hshape, device=d_img.device)                  # only the pooled [CLS] row carries a gradient
-        dout[:, 0, :] = d_img.reshape(-1, hshape[-1])
+        dout[:, 0, :] = d_cls
         d_emb, _ = self.image.encoder._backward_train(s_img_enc, dout, G=self.image.encoder.grad_buffers())
         self.image.embedding._backward(s_img_emb, d_emb, G_out=self.image.embedding.grad_buffers())
 
@@ -220,6 +345,84 @@ def synthetic_raw_batch(batch: int, tags: int, n_img: int = 16, seq_length: int 
     seg = (torch.arange(seq_length, device=device).view(1, 1, -1) < lens).to(torch.int64)
     tgts = torch.randint(0, 3, (batch, tags), device=device, generator=generator)
     return frames, ids, seg, tgts
+
+
+# ---- launcher plumbing shared by the three stages' main(): raw items in, features extracted in line ---------------------------
+IMAGE_TOWERS = {"vit_base_16_224": VIT_CONFIG, "vit_large_14_224": VIT_L14_CONFIG}
+
+
+def raw_input_opts(parser):
+    """Flags of this build (not in the reference, whose loaders read pre-extracted features: finetune/ppo.py:115-148): run the
+    encoder stacks in front of a stage's head.  The reference's launchers already carry --pretrained_model_path /
+    --vit_pretrained_model_path for the RoBERTa and ViT checkpoints; with --raw_inputs they load into the two stacks."""
+    parser.add_argument("--raw_inputs", action="store_true",
+                        help="items are raw (uint8 frames, tag token ids, seg): features come from the image tower + RoBERTa-base in line")
+    parser.add_argument("--encoder_layers", type=int, default=0, help="override layers_num of both encoder configs (0 = as shipped)")
+    parser.add_argument("--image_tower", type=str, default="vit_base_16_224",
+                        help="with --raw_inputs: vit_base_16_224 | vit_large_14_224 (BASELINE configs[4]; ends in the 1024 -> "
+                             "visual_feat_dim projection) | path of a TencentPretrain model JSON")
+    parser.add_argument("--fp8_features", action="store_true",
+                        help="with --raw_inputs and frozen encoders: every projection of both stacks as an MX-FP8 product on the "
+                             "block-scaled MFMA (FeatureExtractor(precision='mxfp8'); a few per cent from the default features)")
+    return parser
+
+
+def build_extractor(args, num_tasks: int = 1, trainable: bool = False) -> FeatureExtractor:
+    """The FeatureExtractor a launcher's flags describe, on args.device, identical on every rank."""
+    import torch.distributed as dist
+    over = {"layers_num": args.encoder_layers} if getattr(args, "encoder_layers", 0) else {}
+    tower = getattr(args, "image_tower", "vit_base_16_224")
+    fp8 = bool(getattr(args, "fp8_features", False))
+    if fp8 and trainable:
+        raise ValueError("--fp8_features is for frozen feature extraction; drop it or --finetune_encoders")
+    fx = FeatureExtractor(encoder_args(IMAGE_TOWERS.get(tower, tower), **over), encoder_args(TEXT_CONFIG, **over),
+                          seq_length=args.seq_length, feat_dim=args.visual_feat_dim, precision="mxfp8" if fp8 else "split_bf16")
+    text_path, vit_path = getattr(args, "pretrained_model_path", None), getattr(args, "vit_pretrained_model_path", None)
+    if text_path or vit_path:
+        if not (text_path and vit_path):
+            raise ValueError("--raw_inputs: give both --pretrained_model_path (RoBERTa) and --vit_pretrained_model_path, or neither")
+        fx.load_pretrained(vit_path, text_path)
+    else:
+        fx.init_normal()
+    fx = fx.to(args.device)
+    if num_tasks > 1:
+        for p in fx.parameters():
+            dist.broadcast(p.data, src=0)
+    return fx
+
+
+class SyntheticRawItems(torch.utils.data.Dataset):
+    """Seeded raw stand-in for LRMovieNet items: uint8 frames [max_imgs, 3, H, W], tag token ids [tags, 196] uniform
+    in [5, vocab), seg = 1 on the first len ~ U{4..196} tokens, targets in {0, 1, 2} -> (frames, ids, seg, tgts, *extra(i, tgts, g)).
+    extra: a stage's additional per-item fields (stage 2: chosen / reject index)."""
+
+    def __init__(self, n_items, tags, max_imgs=16, seed=7, extra=None):
+        self.n, self.tags, self.max_imgs, self.seed, self.extra = n_items, tags, max_imgs, seed, extra
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        frames, ids, seg, tgts = synthetic_raw_batch(1, self.tags, n_img=self.max_imgs, generator=g)
+        item = (frames[0], ids[0], seg[0], tgts[0])
+        return item + tuple(self.extra(i, tgts[0], g)) if self.extra is not None else item
+
+
+class ExtractingLoader:
+    """A loader of raw batches (frames, ids, seg, *rest) seen as the reference's loader of (text_emb, img_emb, *rest): the frozen
+    extractor runs in line, on the device, as each batch is drawn."""
+
+    def __init__(self, loader, fx: FeatureExtractor, device):
+        self.loader, self.fx, self.device, self.sampler = loader, fx, device, getattr(loader, "sampler", None)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for frames, ids, seg, *rest in self.loader:
+            text_emb, img_emb = self.fx.extract(frames.to(self.device), ids.to(self.device), seg.to(self.device))
+            yield (text_emb, img_emb, *rest)
 
 
 def build_encoder_optimizer(args, fx: FeatureExtractor):
@@ -264,12 +467,17 @@ def finetune_pointwise_step(args, fx: FeatureExtractor, model, optimizer, schedu
     d_text, d_img = model.engine_backward(dlogits, dp, fc1_update=fa, input_grads=True)
     wh = dp.reduce_start(model)                      # the head's tail all-reduce overlaps the encoder backward
     del text_emb, logits
-    fx.backward_train(ctx, d_text, d_img)
     works = []
-    if dp.active:
-        for g in fx.grad_flats():
-            g.div_(dp.world)
-            works.append(dist.all_reduce(g, async_op=True))
+
+    def exchange(part):
+        # one all-reduce per flat buffer, issued as soon as that tower's backward has been enqueued: RCCL's stream waits for the
+        # compute stream at that point, so the text tower's ~500 MB travel while the image tower's backward runs
+        if dp.active:
+            for g in fx.grad_flats(part):
+                g.div_(dp.world)
+                works.append(dist.all_reduce(g, async_op=True))
+    fx.backward_train(ctx, d_text, d_img, after_text=lambda: exchange("text"))
+    exchange("image")
     dp.finish(wh)
     optimizer.step()
     for w in works:

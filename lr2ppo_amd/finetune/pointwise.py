@@ -230,48 +230,24 @@ def build_parser():
     # launcher already carries --pretrained_model_path / --vit_pretrained_model_path for the RoBERTa and ViT checkpoints but loads them
     # into a module that holds only the head (pointwise.py:239-271); with --raw_inputs they load into the two encoder stacks that run
     # in front of it, and --finetune_encoders trains those stacks from the head's loss.
-    parser.add_argument("--raw_inputs", action="store_true",
-                        help="items are raw (uint8 frames, tag token ids, seg): features come from ViT-B/16 + RoBERTa-base in line")
+    from .features import raw_input_opts
+    raw_input_opts(parser)
     parser.add_argument("--finetune_encoders", action="store_true",
                         help="with --raw_inputs: train both encoder stacks end to end (AdamW, the head's schedule) instead of freezing them")
-    parser.add_argument("--encoder_layers", type=int, default=0, help="override layers_num of both encoder configs (0 = the shipped 12)")
     return parser
 
 
-class SyntheticRawMovieNet(Dataset):
-    """Seeded raw stand-in for an LRMovieNet item: uint8 frames [max_imgs, 3, 224, 224], tag token ids [tags, 196]
-    uniform in [5, vocab), seg = 1 on the first len ~ U{4..196} tokens, targets in {0, 1, 2}."""
-
-    def __init__(self, n_items, tags, max_imgs=16, seed=7):
-        self.n, self.tags, self.max_imgs, self.seed = n_items, tags, max_imgs, seed
-
-    def __len__(self):
-        return self.n
-
-    def __getitem__(self, i):
-        from .features import synthetic_raw_batch
-        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
-        frames, ids, seg, tgts = synthetic_raw_batch(1, self.tags, n_img=self.max_imgs, generator=g)
-        return frames[0], ids[0], seg[0], tgts[0]
+def SyntheticRawMovieNet(n_items, tags, max_imgs=16, seed=7):
+    """Seeded raw stand-in for an LRMovieNet item (features.SyntheticRawItems): (frames, ids, seg, tgts)."""
+    from .features import SyntheticRawItems
+    return SyntheticRawItems(n_items, tags, max_imgs, seed)
 
 
 def _run_raw(args, model, num_tasks, global_rank):
     """The training loop of main() on raw items: FeatureExtractor in front of the head, frozen (features extracted in line, then
     train_model) or fine-tuned (features.finetune_pointwise_step); validation extracts in line and calls evaluate()."""
-    from .features import (TEXT_CONFIG, VIT_CONFIG, FeatureExtractor, build_encoder_optimizer, encoder_args,
-                           finetune_pointwise_step)
-    over = {"layers_num": args.encoder_layers} if args.encoder_layers else {}
-    fx = FeatureExtractor(encoder_args(VIT_CONFIG, **over), encoder_args(TEXT_CONFIG, **over))
-    if args.pretrained_model_path or args.vit_pretrained_model_path:
-        if not (args.pretrained_model_path and args.vit_pretrained_model_path):
-            raise ValueError("--raw_inputs: give both --pretrained_model_path (RoBERTa) and --vit_pretrained_model_path, or neither")
-        fx.load_pretrained(args.vit_pretrained_model_path, args.pretrained_model_path)
-    else:
-        fx.init_normal()
-    fx = fx.to(args.device)
-    if num_tasks > 1:
-        for p in fx.parameters():
-            dist.broadcast(p.data, src=0)
+    from .features import build_encoder_optimizer, build_extractor, finetune_pointwise_step
+    fx = build_extractor(args, num_tasks, trainable=args.finetune_encoders)
     if args.synthetic_items <= 0:
         raise RuntimeError("--raw_inputs: the repository holds no raw LRMovieNet reader (the reference reads pre-extracted features, "
                            "finetune/pointwise.py:77-167); use --synthetic_items N")

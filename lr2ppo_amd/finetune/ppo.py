@@ -1140,6 +1140,8 @@ def build_parser():
     parser.add_argument("--synthetic_items", type=int, default=0, help="use SyntheticMovieNet with this many train items")
     parser.add_argument("--synthetic_val_items", type=int, default=16)
     parser.add_argument("--max_cycles", type=int, default=0, help="stop after this many update cycles (0 = run all epochs)")
+    from .features import raw_input_opts
+    raw_input_opts(parser)      # --raw_inputs [--image_tower vit_large_14_224] [--fp8_features]: frozen encoder stacks in line
     return parser
 
 
@@ -1159,7 +1161,26 @@ def main(argv=None):
     misc.init_distributed_mode(args)
     misc.setup_seed(args.seed + misc.get_rank())
     args.is_master = misc.is_main_process()
-    return run_training(args, vit_args, ActorCritic, Reward, None, None)
+    if not args.raw_inputs:
+        return run_training(args, vit_args, ActorCritic, Reward, None, None)
+    # the metric's own composition (BASELINE.json: "PPO steps/sec (ViT-B+RoBERTa-base, batch 32)"; configs[4] with
+    # --image_tower vit_large_14_224 --fp8_features): raw items, frozen encoder stacks in line, then the unchanged stage-3 loop
+    from .features import SyntheticRawItems, build_extractor
+    if args.synthetic_items <= 0:
+        raise RuntimeError("--raw_inputs: the repository holds no raw LRMovieNet reader (the reference reads pre-extracted features, "
+                           "finetune/ppo.py:58-151); use --synthetic_items N")
+    args.device = torch.device("cuda", torch.cuda.current_device())
+    fx = build_extractor(args, misc.get_world_size())
+
+    def make_sets():
+        return (SyntheticRawItems(args.synthetic_items, 2, args.max_imgs, args.seed),
+                SyntheticRawItems(args.synthetic_val_items, 20, args.max_imgs, args.seed + 1))
+
+    def batch_map(batch):
+        frames, ids, seg, tgts = batch
+        text_emb, img_emb = fx.extract(frames.to(args.device), ids.to(args.device), seg.to(args.device))
+        return text_emb, img_emb, tgts
+    return run_training(args, vit_args, ActorCritic, Reward, make_sets, batch_map)
 
 
 class _MappedLoader:

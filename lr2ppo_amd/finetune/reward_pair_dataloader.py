@@ -120,6 +120,19 @@ class SyntheticPairs(Dataset):
         return text, img, labels, torch.tensor(chosen), torch.tensor(reject)
 
 
+def _synthetic_layout(is_train):
+    """chosen / reject index of a synthetic item with the given labels (SyntheticPairs' rule), for features.SyntheticRawItems."""
+    def extra(i, labels, g):
+        if is_train:
+            chosen, reject = TRAIN_LAYOUTS[int(torch.randint(0, 2, (1,), generator=g))]
+        else:
+            order = torch.randperm(3, generator=g)[:2].tolist()
+            keep, swap = order + order, order + order[::-1]
+            chosen, reject = (keep, swap) if labels[order[0]] >= labels[order[1]] else (swap, keep)
+        return torch.tensor(chosen), torch.tensor(reject)
+    return extra
+
+
 class Classifier(Reward):
     """reward_pair_dataloader.py:233-283: forward(text_emb, img_emb, tgts, index[bs,4]) -> score[bs] (last position).
     `args.mode` is stored and never read by the upstream forward (its launcher passes --mode cls): any value is accepted."""
@@ -220,7 +233,7 @@ def evaluate(args, model, dataloader, step, split="test", num_tasks=None):
 def get_dataloader(args, dataset, num_tasks, global_rank, is_train=False):
     """reward_pair_dataloader.py:418-434: args.batch_size for both splits."""
     sampler = DistributedSampler(dataset, num_replicas=num_tasks, rank=global_rank, shuffle=is_train)
-    workers = getattr(args, "num_workers", 32 if not isinstance(dataset, SyntheticPairs) else 2)
+    workers = getattr(args, "num_workers", 32 if isinstance(dataset, MovieNet) else 2)
     return DataLoader(dataset=dataset, batch_size=args.batch_size, sampler=sampler, num_workers=workers, drop_last=False)
 
 
@@ -245,6 +258,8 @@ def build_parser():
     parser.add_argument("--synthetic_items", type=int, default=0, help="use SyntheticPairs with this many train items")
     parser.add_argument("--synthetic_val_items", type=int, default=16)
     parser.add_argument("--max_steps", type=int, default=0, help="stop after this many training steps (0 = run all epochs)")
+    from .features import raw_input_opts
+    raw_input_opts(parser)      # --raw_inputs [--image_tower vit_large_14_224] [--fp8_features]: frozen encoder stacks in line
     return parser
 
 
@@ -271,13 +286,25 @@ def main(argv=None):
     if num_tasks > 1:
         for p in model.parameters():
             dist.broadcast(p.data, src=0)
-    if args.synthetic_items > 0:
+    fx = None
+    if args.raw_inputs:
+        # BASELINE.json configs[4]'s first half: reward-pair training behind frozen encoder stacks (ViT-L/14 swap, MX-FP8 products)
+        from .features import ExtractingLoader, SyntheticRawItems, build_extractor
+        if args.synthetic_items <= 0:
+            raise RuntimeError("--raw_inputs: the repository holds no raw LRMovieNet reader (the reference reads pre-extracted "
+                               "features, finetune/reward_pair_dataloader.py:87-211); use --synthetic_items N")
+        fx = build_extractor(args, num_tasks)
+        trainset = SyntheticRawItems(args.synthetic_items, 2, args.max_imgs, args.seed, extra=_synthetic_layout(True))
+        valset = SyntheticRawItems(args.synthetic_val_items, 3, args.max_imgs, args.seed + 1, extra=_synthetic_layout(False))
+    elif args.synthetic_items > 0:
         trainset = SyntheticPairs(args.synthetic_items, True, args.max_imgs, args.seed)
         valset = SyntheticPairs(args.synthetic_val_items, False, args.max_imgs, args.seed + 1)
     else:
         trainset, valset = MovieNet(args, args.train_path, is_train=True), MovieNet(args, args.dev_path, is_train=False)
     train_loader = get_dataloader(args, trainset, num_tasks, global_rank, is_train=True)
     val_loader = get_dataloader(args, valset, num_tasks, global_rank, is_train=False)
+    if fx is not None:
+        train_loader, val_loader = ExtractingLoader(train_loader, fx, args.device), ExtractingLoader(val_loader, fx, args.device)
     args.train_steps = int(len(trainset) * args.epochs_num / args.batch_size) + 1
     if args.is_master:
         args.logger.info("Batch size: {}".format(args.batch_size))

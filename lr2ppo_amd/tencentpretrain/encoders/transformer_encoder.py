@@ -224,18 +224,22 @@ class TransformerEncoder(nn.Module):
             out = []
             for layer in self.transformer:
                 att, ffn = layer.self_attn, layer.feed_forward
-                wqkv = torch.cat([l.weight.data for l in att.linear_layers], 0)
-                out.append({"wqkv": ops.quant_mxfp8(wqkv), "bqkv": torch.cat([l.bias.data for l in att.linear_layers], 0),
+                wqkv = ops.quant_mxfp8(torch.cat([l.weight.data for l in att.linear_layers], 0))
+                E = wqkv.cols                                          # rows [E, 3E) = [Wk; Wv]: the pruned last layer's product
+                wkv = ops.Mx8(wqkv.q[E * E:], wqkv.s[E * (E // 32):], 2 * E, E)
+                out.append({"wqkv": wqkv, "wkv": wkv, "bqkv": torch.cat([l.bias.data for l in att.linear_layers], 0),
                             "wo": ops.quant_mxfp8(att.final_linear.weight.data), "w1": ops.quant_mxfp8(ffn.linear_1.weight.data),
                             "w2": ops.quant_mxfp8(ffn.linear_2.weight.data)})
             self._fp8_w, self._fp8_sig = out, sig
         return self._fp8_w
 
     @torch.no_grad()
-    def forward_fp8(self, emb, seg):
+    def forward_fp8(self, emb, seg, first_only: bool = False):
         """forward(emb, seg) with the four projections of every layer as MX-FP8 products (csrc/fp8.hip); LayerNorm, attention and the
         residual stream stay fp32 / split-bf16.  An element keeps 3 mantissa bits: expect the output a few per cent away from
-        forward()'s -- this mode exists for throughput experiments, never for the parity tests."""
+        forward()'s -- the throughput mode of BASELINE.json configs[4] (FeatureExtractor(precision="mxfp8")), never the parity path.
+        first_only: -> hidden[:, 0, :] ([batch, hidden]); the last layer then computes keys / values for every row (MX-FP8) and
+        everything behind the scores for row 0 only (forward_first_token's schedule, B rows: split-bf16)."""
         if emb.dtype != torch.float32 or not emb.is_cuda:
             raise TypeError("lr2ppo_amd: emb must be a float32 tensor on the HIP device (no CPU path)")
         B, L, E = emb.shape
@@ -257,12 +261,16 @@ class TransformerEncoder(nn.Module):
         x_q, ff_q = self._fp8_act
         h.copy_(emb.contiguous().view(M, E))
         scale = 1.0 / math.sqrt(float(hd))
-        for layer, w in zip(self.transformer, W):
+        for li, (layer, w) in enumerate(zip(self.transformer, W)):
             att, ffn, ln1, ln2 = layer.self_attn, layer.feed_forward, layer.layer_norm_1, layer.layer_norm_2
             if pre:
                 ops.layernorm_fwd_mxfp8(h, ln1.gamma.data, ln1.beta.data, x_q, rows=M, D=E, eps=ln1.eps, mode=1)
             else:
                 ops.quant_mxfp8(h, x_q)
+            if first_only and li == self.layers_num - 1:
+                kv_p = ws.planes("kv_p", M, 2 * E)
+                ops.gemm_mxfp8(x_q, w["wkv"], None, bias=w["bqkv"][E:], out_planes=kv_p)
+                return self._last_layer_first_token(ws, layer, self._weight_planes(dev)[li], h, None, seg, B, L, E, F, kv_p=kv_p)
             ops.gemm_mxfp8(x_q, w["wqkv"], None, bias=w["bqkv"], out_planes=qkv_p)     # the attention kernels take bf16 hi / lo planes
             ops.self_attn_fwd(qkv_p, seg, o32, batch=B, heads=H, L=L, head_dim=hd, scale=scale)
             ops.quant_mxfp8(o32, x_q)
@@ -284,18 +292,20 @@ class TransformerEncoder(nn.Module):
             out.view(M, E).copy_(h)
         return out
 
-    def _last_layer_first_token(self, ws, layer, w, h, x_p, seg, B, L, E, F):
+    def _last_layer_first_token(self, ws, layer, w, h, x_p, seg, B, L, E, F, kv_p=None):
         """Last layer of the inference schedule for row 0 of every sequence.  h: the layer's input [B*L, E] (fp32); x_p: the
         planes its QKV projection reads (LayerNorm_1(h) for 'pre', h itself for 'post').  K, V: all rows; everything after the
-        scores: B rows.  Same kernels and epilogues as the full schedule (the row-0 GEMMs run at M = B)."""
+        scores: B rows.  Same kernels and epilogues as the full schedule (the row-0 GEMMs run at M = B).
+        kv_p: the [K | V] planes already computed by the caller (forward_fp8); x_p is then unused."""
         att, ffn, ln1, ln2 = layer.self_attn, layer.feed_forward, layer.layer_norm_1, layer.layer_norm_2
         H, hd, M = self.heads_num, E // self.heads_num, B * L
         pre = self.layernorm_positioning == "pre"
         wqkv, dev = w["wqkv"], h.device
         w_q = ops.Planes(wqkv.buf, E, E, lo_off=wqkv.lo_off)                       # rows [0, E) of [Wq; Wk; Wv]
         w_kv = ops.Planes(wqkv.buf[E * E:], 2 * E, E, lo_off=wqkv.lo_off)          # rows [E, 3E)
-        kv_p = ws.planes("kv_p", M, 2 * E)
-        engine.linear_fwd(ws, x_p, w_kv, w["bqkv"][E:], None, M, 2 * E, E, out_planes=kv_p)
+        if kv_p is None:
+            kv_p = ws.planes("kv_p", M, 2 * E)
+            engine.linear_fwd(ws, x_p, w_kv, w["bqkv"][E:], None, M, 2 * E, E, out_planes=kv_p)
         h0 = h.view(B, L, E)[:, 0, :].contiguous()                                  # the layer's input at row 0
         x0_p, q0, o0, o0_p = ws.planes("x0_p", B, E), ws.mat("q0", B, E), ws.mat("o0", B, E), ws.planes("o0_p", B, E)
         if pre:

@@ -551,6 +551,43 @@ def pooling_first(hidden: torch.Tensor, seg: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # the stage-1 (pointwise) and stage-2 (pairwise reward) training steps
 # ---------------------------------------------------------------------------------------------
+def visual_projection(weight: torch.Tensor, cls_rows: torch.Tensor) -> torch.Tensor:
+    """The bias-free map from an image tower's width to the feature width the heads hard-code (finetune/ppo.py:202-208): CLIP's
+    `x = ln_post(x[:, 0, :]); x = x @ proj` -- the `model.encode_image` the reference's preprocess.py:59-61,83 calls to produce
+    img_emb.  `clip` is a third-party dependency absent from /root/reference (pip3_list.txt pins clip 1.0, openai/CLIP
+    clip/model.py VisionTransformer.forward); restated from its published form.  weight: [feat, hidden] (nn.Linear orientation =
+    proj^T); cls_rows: [N, hidden], the pooled row behind the stack's final LayerNorm (= ln_post)."""
+    return cls_rows @ weight.t()
+
+
+def feature_chain(pv: Params, pt: Params, frames_u8: torch.Tensor, ids: torch.Tensor, seg: torch.Tensor, *, patch: int, vit_layers: int,
+                  vit_heads: int, text_layers: int, text_heads: int = 12, proj: Optional[torch.Tensor] = None,
+                  mean=(0.48145466, 0.4578275, 0.40821073), std=(0.26862954, 0.26130258, 0.27577711), drop=None):
+    """uint8 frames [B, n_img, 3, H, W] + token ids / seg [B, T, L] -> (text_emb [B, T, L, E], img_emb [B, n_img, feat]): the
+    composition tencentpretrain/models/model.py:32-41 (`encoder(embedding(src, seg), seg)`) of both stacks, `/255` + CLIP mean / std
+    (tencentpretrain/utils/dataloader.py:559-561), pooling 'first' (utils/misc.py:23-35) and, for a tower wider than the heads,
+    visual_projection.  pv / pt: {"embedding.*", "encoder.*"} parameters of the image / text stack.  drop: None, or a function
+    k -> dropout spec for module call k (0 image embedding, 1 image encoder, 2 text embedding, 3 text encoder)."""
+    B, n_img, _, H, W = frames_u8.shape
+    T, L = ids.shape[1:]
+    d = drop or (lambda k: None)
+    sub = lambda P, pre: {k[len(pre):]: v for k, v in P.items() if k.startswith(pre)}      # noqa: E731
+    x = frames_u8.float().div(255)
+    x = ((x - torch.tensor(mean).view(1, 1, 3, 1, 1)) / torch.tensor(std).view(1, 1, 3, 1, 1)).reshape(B * n_img, 3, H, W)
+    n_tok = (H // patch) * (W // patch) + 1
+    vseg = torch.ones(B * n_img, n_tok, dtype=torch.long)
+    h = transformer_encoder(sub(pv, "encoder."), vit_embedding(sub(pv, "embedding."), x, patch, drop=d(0)), vseg, vit_layers, vit_heads,
+                            True, drop=d(1))
+    cls = pooling_first(h, vseg)
+    if proj is not None:
+        cls = visual_projection(proj, cls)
+    img_emb = cls.reshape(B, n_img, -1)
+    s2 = seg.reshape(B * T, L)
+    e = text_embedding(sub(pt, "embedding."), ids.reshape(B * T, L), s2, drop=d(2))
+    text_emb = transformer_encoder(sub(pt, "encoder."), e, s2, text_layers, text_heads, False, drop=d(3))
+    return text_emb.reshape(B, T, L, -1), img_emb
+
+
 def pair_hinge(chosen: torch.Tensor, reject: torch.Tensor, margin: float = 1.0):
     """finetune/reward_pair_dataloader.py:356-359: loss = relu(m_R - (chosen - reject)).mean(), acc = (chosen > reject).mean()."""
     return torch.relu(margin - (chosen - reject)).mean(), (chosen > reject).float().mean()
