@@ -317,19 +317,21 @@ def test_fp8_features_score_and_ndcg_drift_on_256_items(dev):
     s_ref, s_fp8, gold = torch.cat(s_ref), torch.cat(s_fp8), torch.cat(gold)
     pair_ref, pair_fp8 = torch.cat(pair_ref), torch.cat(pair_fp8)
     n_ref, n_fp8 = _ndcg_at(s_ref, gold), _ndcg_at(s_fp8, gold)
-    d_score = float((s_fp8 - s_ref).abs().max())
+    d_score, d_mean = float((s_fp8 - s_ref).abs().max()), float((s_fp8 - s_ref).abs().mean())
     spread = float(s_ref.std())
     agree = float(((pair_ref > 0) == (pair_fp8 > 0)).float().mean())
     drift = float(n_fp8.mean() - n_ref.mean())
     f_t, f_i = max(e[0] for e in ferr), max(e[1] for e in ferr)
     print(f"\nconfig5 fp8 drift (256 items x 20 tags, random weights): features rel-L2 text {f_t:.3e} image {f_i:.3e}; "
-          f"max |d score| {d_score:.3e} (score std {spread:.3e}); reward pair-order agreement {agree:.4f}; "
+          f"|d score| mean {d_mean:.3e} max {d_score:.3e} (score std {spread:.3e}); reward pair-order agreement {agree:.4f}; "
           f"NDCG@3 {float(n_ref.mean()):.4f} -> {float(n_fp8.mean()):.4f} (drift {drift:+.4f}; north_star bar +-0.002)")
     assert torch.isfinite(s_fp8).all() and torch.isfinite(pair_fp8).all()
     assert 1e-4 < f_t < 0.15 and 1e-4 < f_i < 0.15          # really a different precision, and a few per cent away -- not garbage
-    assert d_score < 0.25 * max(spread, 1e-3) + 5e-2
-    assert agree > 0.6
-    assert abs(drift) < 0.05
+    # first measurement (round 4): features 2.2e-2 / 8.6e-2, |d score| max 8.4e-2 at a score std of 1.0e-1, agreement 0.984,
+    # NDCG@3 0.4372 -> 0.4359 (-0.0013: inside the north_star's +-0.002 even with random weights)
+    assert d_mean < 0.25 * spread and d_score < 1.5 * spread
+    assert agree > 0.95
+    assert abs(drift) < 0.01
 
 
 @pytest.mark.parametrize("stage, extra", [
