@@ -673,7 +673,50 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
   p.dma_stages = stages ? (stages == 1 ? 1 : 2) : (BK == 32 ? 2 : 1);
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (use256) return launch_gemm256_nt(p, s);
+  if (use256) {
+    // ROW SPLIT (round 4).  A 256 x 256 tile owns a whole CU (128 KiB of LDS), so a launch runs in rounds of 256 tiles and a last
+    // round that is mostly empty costs a full tile time on a mostly idle chip (M = 12 544, N = 3072: 588 tiles = 2.3 rounds).  When
+    // the last round would be less than half full, the rows that fill WHOLE rounds go to the 256 x 256 kernel and the remaining
+    // rows to the 128- / 64-row kernels (2-3 workgroups per CU, short tiles): two launches, no partial slabs, no reduction, each
+    // output row computed by exactly one of them.  Measured in one process (tools/dbg/rowsplit_ab.py): 12 544 x 3072 x 768
+    // 199 (NN, 128-row tiles) / 184 (three rounds) -> 166 us; 25 088 x 768 x 3072 340 -> 279; 6272 x 3072 x 768 95 -> 91.
+    // Stream-K over the same tiles was priced and not built: a partial 256 x 256 tile is a 256-KiB fp32 slab, ~2 per workgroup
+    // (128 MB written and read back per launch), more than the idle part of the last round costs.
+    // Not with a fused dropout mask: its element index is relative to the launch's first row.
+    static int rs_env = -1;
+    if (rs_env < 0) {
+      const char* e = getenv("LR2_GEMM_ROWSPLIT");
+      rs_env = e ? atoi(e) : 1;
+    }
+    const int tn256 = (N + 255) / 256, tiles256 = ((M + 255) / 256) * tn256;
+    const int full = tiles256 / 256, rem = tiles256 - full * 256;
+    const int M1 = ((full * 256) / tn256) * 256;          // rows of the tile rows that fit `full` rounds
+    if (rs_env && full >= 1 && rem > 0 && 2 * rem < 256 && (K % 64) == 0 && epi->drop_p <= 0.f && M1 > 0 && M1 < M) {
+      GemmParams p1 = p;
+      p1.M = M1;
+      rc = launch_gemm256_nt(p1, s);
+      if (rc) return rc;
+      GemmParams p2 = p;
+      const int M2 = M - M1;
+      p2.M = M2;
+      p2.A = (const char*)A + (size_t)M1 * (size_t)lda * 2u;              // planes: 2-byte elements, lo plane at the same offset
+      p2.a_bytes = (uint32_t)(a_bytes - (uint64_t)M1 * (uint64_t)lda * 2u);
+      Epilogue& e2 = p2.epi;
+      if (e2.resid) e2.resid += (size_t)M1 * e2.ld_resid;
+      if (e2.aux_z) e2.aux_z += (size_t)M1 * e2.ld_aux;
+      if (e2.out) e2.out += (size_t)M1 * e2.ld_out;
+      if (e2.out_z) e2.out_z += (size_t)M1 * e2.ld_z;
+      if (e2.out_hi) e2.out_hi += (size_t)M1 * e2.ld_planes;
+      p2.k_tiles_per_split = K / 64;
+      p2.partial = nullptr;
+      p2.dma_stages = stages ? (stages == 1 ? 1 : 2) : 1;
+      // tail tiles: 64 rows when 128-row tiles would not fill the 512 resident slots, or would leave a thin last round
+      const int t128 = ((M2 + 127) / 128) * ((N + 127) / 128), last = t128 % 512;
+      const int bm2 = (t128 < 512 || (last > 0 && last <= 128)) ? 64 : 128;
+      return dispatch_form<64, true, true>(p2, 1, bm2, 3, 0, 0, s);
+    }
+    return launch_gemm256_nt(p, s);
+  }
   const bool fused_colsum = use256tn && epi->colsum;
   if (fused_colsum) p.epi.colsum_partial = (float*)epi->colsum_ws;
   if (use256tn) rc = launch_gemm256_tn(p, splits, s);

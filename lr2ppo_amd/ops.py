@@ -268,11 +268,17 @@ def _use_gemm256(M: int, N: int, K: int, passes: int) -> bool:
         return False
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
     rounds = -(-tiles // 256)
-    if tiles >= 256 and tiles >= 0.88 * rounds * 256:
+    if tiles >= 256 and tiles >= 0.85 * rounds * 256:
+        return True
+    # round 4 (tools/dbg/rowsplit_ab.py): more than one round with a last round LESS than half full -- lr2_gemm then sends the rows of
+    # the whole rounds to the 256 x 256 kernel and the remaining rows to the 128- / 64-row kernels (row split: two launches, no
+    # reduction): M = 12544, N = 3072, K = 768 (588 tiles) 166 us against 199 (NN on 128-row tiles) / 184 (three rounds of 256 x 256)
+    if tiles > 256 and 0 < tiles % 256 < 128 and K % 64 == 0 and os.environ.get("LR2_GEMM_ROWSPLIT", "1") != "0":
         return True
     # one partial round, long contraction (M = 12544, N = 768, K = 3072: 147 tiles): each CU runs one tile at the 256 x 256 kernel's
-    # main-loop rate and the epilogue is amortised over 96 K steps -- 182 us against 197 (64-row tiles) / 212 (128-row), round 3
-    return 128 <= tiles <= 256 and K >= 2304
+    # main-loop rate and the epilogue is amortised over 96 K steps -- 182 us against 197 (64-row tiles) / 212 (128-row), round 3;
+    # round 4: also three quarters of a round at K >= 1024 (M = 12544, N = 1024, K = 1024: 196 tiles, 77 us against 86)
+    return (128 <= tiles <= 256 and K >= 2304) or (192 <= tiles <= 256 and K >= 1024)
 
 
 @functools.lru_cache(maxsize=4096)
