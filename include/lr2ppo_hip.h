@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 17
+#define LR2_ABI_VERSION 18
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -98,6 +98,16 @@ typedef struct lr2_epilogue {
 int lr2_gemm(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int trans_a, int trans_b,
              uint64_t a_bytes, uint64_t b_bytes, int a_planes, uint64_t a_lo_off, int b_planes, uint64_t b_lo_off,
              const lr2_epilogue* epi, void* splitk_ws, int splits, int block_m, int passes, void* stream);
+
+/* Round 4 (ABI 18).  How lr2_gemm schedules a large (0,0) product of planes asked for with block_m = 256 and no fused dropout mask:
+ * *rows_256 = the leading rows that run on the 256 x 256 kernel as WHOLE rounds of one workgroup per CU (0 = one launch, no row
+ * split); the remaining rows run on the general kernel with *tail_block_m-row tiles (2-3 workgroups per CU), so that a last round
+ * less than half full does not hold the chip for a full tile time.  Pure host arithmetic; lr2_gemm follows this plan.
+ * LR2_GEMM_ROWSPLIT=0 (read once per process) switches the split off.  Same nn.Linear call sites as lr2_gemm. */
+int lr2_gemm_row_split_plan(int M, int N, int K, int* rows_256, int* tail_block_m);
+/* Diagnostic: launches issued by lr2_gemm since the library was loaded -- counts[0] the 256 x 256 NT kernel, counts[1] its TN form,
+ * counts[2] the general kernel family (tests assert which kernels a call reached; no device call). */
+int lr2_gemm_launch_counts(uint64_t counts[3]);
 
 /* Row gather: dst[b, j, :] = src[b, index[b, j], :]  (rows of row_elems fp32; strides in elements).
  * replaces: text_emb[batch_index, index] / img_emb[batch_index, index] (finetune/ppo.py:268-271,321-324). */

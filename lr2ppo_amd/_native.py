@@ -15,14 +15,23 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "liblr2ppo_hip.so")
-_AB_LIB = os.environ.get("LR2_AB_LIB")     # tools/dbg only: load another build of the same ABI for an A/B timing (never in a test or bench run)
-SOURCES = ["gemm.hip", "gemm256.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip", "fp8.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
+SOURCES = ["gemm.hip", "gemm256.hip", "gemm256_mx.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip", "fp8.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "fp8_common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
 
-ABI_VERSION = 17     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
+ABI_VERSION = 18     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
 
 _lock = threading.Lock()
 _lib = None
+_lib_override = None
+
+
+def use_library(path: str):
+    """Measurement scaffolding (tools/dbg/*_ab.py): load ANOTHER build of the same ABI for an A/B timing.  An explicit call made by
+    the tool itself before the first kernel call -- the product loader reads no environment variable and loads the in-tree library."""
+    global _lib_override
+    if _lib is not None:
+        raise RuntimeError("lr2ppo_amd: the kernel library is already loaded")
+    _lib_override = path
 
 
 def _stale() -> bool:
@@ -86,6 +95,8 @@ SIGNATURES = {
     "lr2_abi_version": [],
     "lr2_device_info": [C.c_char_p, _I],
     "lr2_gemm": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _U64, _U64, _I, _U64, _I, _U64, C.POINTER(Epilogue), _P, _I, _I, _I, _P],
+    "lr2_gemm_row_split_plan": [_I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "lr2_gemm_launch_counts": [C.POINTER(C.c_uint64)],
     "lr2_gather_rows": [_P, _P, _P, _I, _I, _I, _U64, _U64, _U64, _P],
     "lr2_gather_rows_bwd": [_P, _P, _P, _I, _I, _I, _U64, _P],
     "lr2_copy_rows": [_P, _P, _I, _U64, _I, _I, _I, _U64, _U64, _P],
@@ -147,7 +158,7 @@ def lib() -> C.CDLL:
         # process would hold two HIP/HSA runtimes and the second one finds "no ROCm-capable device".
         import torch  # noqa: F401
         try:
-            handle = C.CDLL(_AB_LIB or LIB_PATH)
+            handle = C.CDLL(_lib_override or LIB_PATH)
         except OSError as e:  # e.g. libamdhip64 not loadable
             raise RuntimeError(f"lr2ppo_amd: cannot load {LIB_PATH}: {e}") from e
         for name, argtypes in SIGNATURES.items():

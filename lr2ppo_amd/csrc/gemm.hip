@@ -587,6 +587,36 @@ int launch_gemm256_tn(const GemmParams& p, int splits, hipStream_t stream);
 }  // namespace lr2gemm
 using namespace lr2gemm;
 
+static uint64_t g_launches[3] = {0, 0, 0};     // 256 NT, 256 TN, general family (host-side counters: lr2_gemm_launch_counts)
+extern "C" int lr2_gemm_launch_counts(uint64_t counts[3]) {
+  if (!counts) return LR2_ERR_ARG;
+  for (int i = 0; i < 3; ++i) counts[i] = g_launches[i];
+  return 0;
+}
+
+// How lr2_gemm schedules an eligible large NT product of planes (block_m = 256, no fused dropout): *rows_256 = the leading rows that
+// go to the 256 x 256 kernel as WHOLE rounds of the chip (0: no row split -- one launch), *tail_block_m = the tile height of the
+// general kernel that takes the remaining rows.  Pure host arithmetic (no device call): tests read the plan, lr2_gemm follows it.
+extern "C" int lr2_gemm_row_split_plan(int M, int N, int K, int* rows_256, int* tail_block_m) {
+  if (!rows_256 || !tail_block_m || M <= 0 || N <= 0 || K <= 0) return LR2_ERR_ARG;
+  *rows_256 = 0;
+  *tail_block_m = 128;
+  static int rs_env = -1;
+  if (rs_env < 0) {
+    const char* e = getenv("LR2_GEMM_ROWSPLIT");
+    rs_env = e ? atoi(e) : 1;
+  }
+  const int tn256 = (N + 255) / 256, tiles256 = ((M + 255) / 256) * tn256;
+  const int full = tiles256 / 256, rem = tiles256 - full * 256;
+  const int M1 = ((full * 256) / tn256) * 256;          // rows of the tile rows that fit `full` rounds
+  if (!rs_env || full < 1 || rem <= 0 || 2 * rem >= 256 || (K % 64) != 0 || M1 <= 0 || M1 >= M) return 0;
+  *rows_256 = M1;
+  // tail tiles: 64 rows when 128-row tiles would not fill the 512 resident slots, or would leave a thin last round
+  const int M2 = M - M1, t128 = ((M2 + 127) / 128) * ((N + 127) / 128), last = t128 % 512;
+  *tail_block_m = (t128 < 512 || (last > 0 && last <= 128)) ? 64 : 128;
+  return 0;
+}
+
 extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int lda, int ldb, int trans_a, int trans_b,
                         uint64_t a_bytes, uint64_t b_bytes, int a_planes, uint64_t a_lo_off, int b_planes,
                         uint64_t b_lo_off, const lr2_epilogue* epi, void* splitk_ws, int splits, int block_m, int passes,
@@ -683,19 +713,14 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
     // Stream-K over the same tiles was priced and not built: a partial 256 x 256 tile is a 256-KiB fp32 slab, ~2 per workgroup
     // (128 MB written and read back per launch), more than the idle part of the last round costs.
     // Not with a fused dropout mask: its element index is relative to the launch's first row.
-    static int rs_env = -1;
-    if (rs_env < 0) {
-      const char* e = getenv("LR2_GEMM_ROWSPLIT");
-      rs_env = e ? atoi(e) : 1;
-    }
-    const int tn256 = (N + 255) / 256, tiles256 = ((M + 255) / 256) * tn256;
-    const int full = tiles256 / 256, rem = tiles256 - full * 256;
-    const int M1 = ((full * 256) / tn256) * 256;          // rows of the tile rows that fit `full` rounds
-    if (rs_env && full >= 1 && rem > 0 && 2 * rem < 256 && (K % 64) == 0 && epi->drop_p <= 0.f && M1 > 0 && M1 < M) {
+    int M1 = 0, bm2 = 128;
+    if (epi->drop_p <= 0.f && lr2_gemm_row_split_plan(M, N, K, &M1, &bm2) == 0 && M1 > 0) {
       GemmParams p1 = p;
       p1.M = M1;
       rc = launch_gemm256_nt(p1, s);
       if (rc) return rc;
+      ++g_launches[0];
+      ++g_launches[2];
       GemmParams p2 = p;
       const int M2 = M - M1;
       p2.M = M2;
@@ -710,15 +735,14 @@ extern "C" int lr2_gemm(const void* A, const void* B, int M, int N, int K, int l
       p2.k_tiles_per_split = K / 64;
       p2.partial = nullptr;
       p2.dma_stages = stages ? (stages == 1 ? 1 : 2) : 1;
-      // tail tiles: 64 rows when 128-row tiles would not fill the 512 resident slots, or would leave a thin last round
-      const int t128 = ((M2 + 127) / 128) * ((N + 127) / 128), last = t128 % 512;
-      const int bm2 = (t128 < 512 || (last > 0 && last <= 128)) ? 64 : 128;
       return dispatch_form<64, true, true>(p2, 1, bm2, 3, 0, 0, s);
     }
+    ++g_launches[0];
     return launch_gemm256_nt(p, s);
   }
   const bool fused_colsum = use256tn && epi->colsum;
   if (fused_colsum) p.epi.colsum_partial = (float*)epi->colsum_ws;
+  ++g_launches[use256tn ? 1 : 2];
   if (use256tn) rc = launch_gemm256_tn(p, splits, s);
   else if (a_planes && b_planes && BK == 32) rc = dispatch_form<32, true, true>(p, splits, block_m, passes, trans_a, trans_b, s);
   else if (a_planes && b_planes) rc = dispatch_form<64, true, true>(p, splits, block_m, passes, trans_a, trans_b, s);

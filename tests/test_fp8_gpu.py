@@ -131,3 +131,76 @@ def test_layernorm_can_leave_as_mx_fp8(dev, mode):
     got, out32 = ops.Mx8.empty(rows, D, dev), torch.empty(rows, D, device=dev)
     ops.layernorm_fwd_mxfp8(x, gamma, beta, got, out32, rows=rows, D=D, eps=1e-6, mode=mode)
     assert torch.equal(out32, ref32) and torch.equal(got.s, want.s) and torch.equal(got.q, want.q)
+
+
+# ---- the 256 x 256 LDS-DMA ring (csrc/gemm256_mx.hip): products whose one-workgroup-per-CU rounds are well filled ------------------
+@pytest.mark.parametrize("M,N,K,act,with_resid", [(8192, 2048, 128, 0, False), (8000, 2048, 256, 1, True), (16384, 1024, 384, 0, True),
+                                                   (7937, 2176, 1024, 1, False)])
+def test_ring_product_matches_the_dequantised_operands(dev, M, N, K, act, with_resid):
+    """>= 256 tiles of 256 x 256 -> lr2_gemm_mxfp8 takes the ring kernel: every K-step parity (1, 2, 3, 8 steps), ragged M (a last
+    tile row of 64 / 1 rows), N a multiple of 128 but not of 256 (a half-empty last tile column), fused bias / GELU / residual --
+    against the fp64 product of the dequantised operands (bound of the instruction's adder tree) and against the 128 x 128 kernel
+    (LR2_FP8_256=0 is read once per process, so the comparison value comes from a slice that stays on the small kernel)."""
+    from lr2ppo_amd import ops
+    from oracle import lr2ppo_oracle as O
+    assert ((M + 255) // 256) * ((N + 255) // 256) >= 256
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    a *= torch.exp(torch.randn(M, 1, generator=g))                              # rows of very different scale: the scale bytes matter
+    bias = torch.randn(N, generator=g) * 0.1
+    resid = torch.randn(M, N, generator=g) if with_resid else None
+    am, bm = ops.quant_mxfp8(a.to(dev)), ops.quant_mxfp8(b.to(dev))
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm_mxfp8(am, bm, out, bias=bias.to(dev), resid=None if resid is None else resid.to(dev), act=act)
+    da, db = am.to_float().double().cpu(), bm.to_float().double().cpu()
+    pre = da @ db.t() + bias.double()
+    want = O.gelu_erf(pre) if act else pre
+    if resid is not None:
+        want = want + resid.double()
+    bound = 2e-3 * (da.abs() @ db.abs().t()) + 1e-5
+    err = (out.double().cpu() - want).abs()
+    assert torch.isfinite(out).all()
+    assert bool((err <= bound).all()), f"worst excess {(err - bound).max().item():.3e} (err {err.max().item():.3e})"
+    # the first 1024 rows again as their own product (4 x 9 tiles: the 128 x 128 kernel): same operands, same instruction
+    sub = torch.empty(1024, N, device=dev)
+    am_s = ops.Mx8(am.q[:1024 * K], am.s[:1024 * (K // 32)], 1024, K)
+    ops.gemm_mxfp8(am_s, bm, sub, bias=bias.to(dev), resid=None if resid is None else resid[:1024].to(dev).contiguous(), act=act)
+    assert (sub - out[:1024]).abs().max().item() <= 2 * float(bound[:1024].max())
+
+
+def test_ring_product_hands_its_result_on_as_planes_and_mx_fp8(dev):
+    """out_planes / out_mx of the ring kernel: the split / the quantisation of the fp32 row it would have stored, byte for byte."""
+    from lr2ppo_amd import ops
+    g = torch.Generator().manual_seed(10)
+    M, N, K = 8100, 2048, 256
+    a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g) * 0.1
+    am, bm = ops.quant_mxfp8(a.to(dev)), ops.quant_mxfp8(b.to(dev))
+    out = torch.empty(M, N, device=dev)
+    mx = ops.Mx8.empty(M, N, dev)
+    ops.gemm_mxfp8(am, bm, out, bias=bias.to(dev), act=1, out_mx=mx)
+    want = ops.quant_mxfp8(out)
+    assert torch.equal(mx.s, want.s) and torch.equal(mx.q, want.q)
+    pl = ops.Planes.empty(M, N, dev)
+    ops.gemm_mxfp8(am, bm, None, bias=bias.to(dev), act=1, out_planes=pl)
+    assert torch.equal(pl.buf, ops.split_planes(out, ops.Planes.empty(M, N, dev)).buf)
+    only = ops.Mx8.empty(M, N, dev)
+    ops.gemm_mxfp8(am, bm, None, bias=bias.to(dev), act=1, out_mx=only)
+    assert torch.equal(only.s, want.s) and torch.equal(only.q, want.q)
+
+
+def test_ring_product_is_exact_on_small_integers(dev):
+    """Operands that e4m3 holds exactly (small integers, scales forced apart per row): every product and sum is exact, so the tile /
+    wave / quadrant / plane index maps and the scale routing of the ring kernel are checked bit for bit against integer arithmetic
+    (asymmetric B: a transposed output would not pass)."""
+    from lr2ppo_amd import ops
+    M, N, K = 8192, 2048, 256
+    g = torch.Generator().manual_seed(2)
+    a = torch.randint(-3, 4, (M, K), generator=g).float() * torch.exp2(torch.randint(-2, 3, (M, 1), generator=g).float())
+    b = torch.randint(-3, 4, (N, K), generator=g).float() * torch.exp2((torch.arange(N) % 5).float().view(-1, 1) - 2)
+    b[:, :32] *= 4.0                                      # the first K block of every B row on another scale than the rest
+    am, bm = ops.quant_mxfp8(a.to(dev)), ops.quant_mxfp8(b.to(dev))
+    assert torch.equal(am.to_float().cpu(), a) and torch.equal(bm.to_float().cpu(), b)
+    out = torch.empty(M, N, device=dev)
+    ops.gemm_mxfp8(am, bm, out)
+    assert torch.equal(out.cpu(), (a.double() @ b.double().t()).float())

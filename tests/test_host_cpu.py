@@ -342,3 +342,29 @@ def test_wgrad_tiling_picks_the_tn256_kernel_for_long_contractions():
         assert ops.choose_tiling(M, N, K, True, True) == want, (M, N, K)
     assert ops.choose_tiling(3072, 162816, 64, True, True)[0] != 256
     assert ops.choose_tiling(768, 3072, 2048, True, True)[0] != 256
+
+
+def test_row_split_plan_fills_whole_rounds_and_leaves_a_thin_tail(native):
+    """lr2_gemm_row_split_plan (round 4): rows of whole 256-tile rounds to the 256 x 256 kernel when the last round would be less
+    than half full -- the shapes of the heads / RoBERTa at 2 tags -- and no split otherwise; ops.use_gemm256 asks for block_m = 256
+    exactly where the plan (or a well-filled launch) exists.  Host arithmetic only."""
+    import ctypes
+    from lr2ppo_amd import ops
+    lib = native.lib()
+
+    def plan(M, N, K):
+        r, t = ctypes.c_int(-1), ctypes.c_int(-1)
+        assert lib.lr2_gemm_row_split_plan(M, N, K, ctypes.byref(r), ctypes.byref(t)) == 0
+        return r.value, t.value
+    assert plan(12544, 3072, 768) == (10752, 64)          # 588 tiles = 2.30 rounds: 42 tile rows (504 tiles) + 1792 rows
+    assert plan(25088, 768, 3072) == (21760, 64)          # 294 tiles = 1.15 rounds: 85 tile rows (255 tiles) + 3328 rows
+    assert plan(6272, 3072, 768) == (5376, 64)            # 300 tiles
+    for shape in ((12544, 2304, 768), (100864, 3072, 768), (12544, 768, 3072), (12544, 768, 768), (25088, 3072, 768)):
+        assert plan(*shape)[0] == 0, shape                # last round at least half full, or less than one round: one launch
+    assert plan(8448, 2048, 96)[0] == 0                   # the tail kernels step K by 64
+    assert lib.lr2_gemm_row_split_plan(0, 8, 8, None, None) != 0
+    for M, N, K in ((12544, 3072, 768), (6272, 3072, 768), (25088, 768, 3072)):
+        rows, _ = plan(M, N, K)
+        tn = (N + 255) // 256
+        assert rows % 256 == 0 and (rows // 256) * tn <= (((M + 255) // 256) * tn // 256) * 256
+        assert ops.use_gemm256(M, N, K)

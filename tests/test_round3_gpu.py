@@ -3,6 +3,7 @@ the composed path trains end to end -- loss -> head -> ViT / RoBERTa encoder sta
 autograd chain with pinned dropout masks, the explicit (no-autograd) fine-tune schedule equals the autograd route bit for bit,
 the rollout's shared input planes are ordered before the stream fork, long runs in the embedding backward, NDCG range flags."""
 import argparse
+import math
 import os
 
 import pytest
@@ -13,6 +14,7 @@ from oracle import lr2ppo_oracle as O
 pytestmark = pytest.mark.gpu
 
 REL = 2e-3          # the bar of the encoder-backward tests (test_round2_gpu.py: sum-of-squares within 2e-3, sampled values)
+FLIP_MAX, FAR_MAX = 2e-3, 4e-2      # test_finetune_pointwise_step_...: share of elements whose first AdamW step may flip / differ (see there)
 
 
 def _head_args(dev, **over):
@@ -309,7 +311,16 @@ def test_finetune_pointwise_step_trains_head_and_both_stacks(dev):
         # tolerance), below it is linear in g -- so the update as a whole agrees to about the gradient tolerance
         du_got, du_want = (got - w0).double(), (want - w0).double()
         rel = float((du_got - du_want).norm() / du_want.norm())
-        assert rel < 2e-2, (name, rel)
+        # ... and element by element: with zero moments an element's update is lr * 0.1 g / (sqrt(0.001) |g| + 1e-6), i.e. the full
+        # sign step lr / sqrt(0.001) * 0.1 for |g| >> 3e-5 and proportional to g below.  Two gradients that agree to 2e-3 of the
+        # tensor's scale can therefore differ by a whole step only where |g| is below that error -- a small, bounded share of the
+        # elements: a FLIP (opposite signs, both beyond half a step) and FAR (more than 5 % of a step apart) are counted, and the
+        # bounds are about twice what this build measures (printed with -s).
+        step = lr * 0.1 / math.sqrt(0.001)
+        flipped = float(((du_got * du_want < 0) & (du_got.abs() > 0.5 * step) & (du_want.abs() > 0.5 * step)).double().mean())
+        far = float(((du_got - du_want).abs() > 0.05 * step).double().mean())
+        print(f"{name}: update rel-L2 {rel:.2e}, flipped {flipped:.2e}, far {far:.2e}")
+        assert rel < 2e-2 and flipped < FLIP_MAX and far < FAR_MAX, (name, rel, flipped, far)
     losses = [l0, finetune_pointwise_step(args, fx, model, opt, sch, eopt, esch, frames.to(dev), ids.to(dev), seg.to(dev), tgts.to(dev))]
     fx.text.embedding.check_ids()
     assert abs(float(losses[0]) - float(loss_ref)) < 1e-3

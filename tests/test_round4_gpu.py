@@ -63,30 +63,36 @@ def test_row_split_product_matches_fp64_with_every_epilogue(dev, M, N, K):
     _close(out, (z_ref + bias.double()) * keep.double() / 0.9 + resid.double(), atol, 5e-5, "dropout + resid (single launch)")
 
 
-def test_row_split_is_what_runs_and_the_switch_turns_it_off(dev):
-    """The row split changes WHICH kernel computes the tail rows, so the two settings differ in the last bits there and nowhere
-    else: rows of the whole rounds are bit-identical with LR2_GEMM_ROWSPLIT=0, the tail rows agree to rounding (child processes:
-    the switch is read once per process)."""
-    code = r'''
-import sys, torch, hashlib
-sys.path.insert(0, %r)
-from lr2ppo_amd import ops
-dev = torch.device("cuda:0")
-M, N, K = 8448, 2048, 128
-g = torch.Generator().manual_seed(5)
-a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
-ap = ops.split_planes(a.to(dev), ops.Planes.empty(M, K, dev)); wp = ops.split_planes(w.to(dev), ops.Planes.empty(N, K, dev))
-out = torch.empty(M, N, device=dev)
-ops.gemm(ap, wp, out, M, N, K, block_m=256, splits=1)
-o = out.cpu()
-print(hashlib.sha1(o[:8192].numpy().tobytes()).hexdigest(), hashlib.sha1(o[8192:].numpy().tobytes()).hexdigest(), float(o[8192:].double().abs().sum()))
-''' % REPO
-    res = {}
-    for flag in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
-                           env=dict(os.environ, LR2_GEMM_ROWSPLIT=flag))
-        assert r.returncode == 0, r.stderr[-2000:]
-        res[flag] = r.stdout.split()
-    assert res["1"][0] == res["0"][0]                       # the whole rounds: the same kernel, the same bits
-    assert res["1"][1] != res["0"][1]                       # the tail: another kernel (the split really happened)
-    assert abs(float(res["1"][2]) - float(res["0"][2])) < 1e-4 * float(res["0"][2])
+def _counts():
+    import ctypes
+    from lr2ppo_amd import _native
+    c = (ctypes.c_uint64 * 3)()
+    assert _native.lib().lr2_gemm_launch_counts(c) == 0
+    return list(c)
+
+
+def test_row_split_is_what_runs(dev):
+    """lr2_gemm follows lr2_gemm_row_split_plan: one call = one launch of the 256 x 256 kernel (the plan's leading rows) + one of the
+    general family (the rest); with a fused dropout mask, or a shape whose last round is well filled, one launch of the 256 x 256
+    kernel alone.  The rows of the whole rounds carry the bits of the unsplit launch (same kernel, same tiles)."""
+    import ctypes
+    from lr2ppo_amd import _native, ops
+    M, N, K = 8448, 2048, 128
+    r, t = ctypes.c_int(), ctypes.c_int()
+    assert _native.lib().lr2_gemm_row_split_plan(M, N, K, ctypes.byref(r), ctypes.byref(t)) == 0
+    assert (r.value, t.value) == (8192, 64)
+    g = torch.Generator().manual_seed(5)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    ap, wp = _planes(ops, a, dev), _planes(ops, w, dev)
+    out, whole = torch.empty(M, N, device=dev), torch.empty(r.value, N, device=dev)
+    c0 = _counts()
+    ops.gemm(ap, wp, out, M, N, K, block_m=256, splits=1)
+    c1 = _counts()
+    assert [c1[i] - c0[i] for i in range(3)] == [1, 0, 1]
+    ops.gemm(ops.Planes(ap.buf, r.value, K, lo_off=ap.lo_off), wp, whole, r.value, N, K, block_m=256, splits=1)     # 256 tiles: one round
+    c2 = _counts()
+    assert [c2[i] - c1[i] for i in range(3)] == [1, 0, 0]
+    assert torch.equal(out[:r.value], whole)
+    ops.gemm(ap, wp, out, M, N, K, block_m=256, splits=1, drop=ops.Drop(0.1, 3, 1))
+    c3 = _counts()
+    assert [c3[i] - c2[i] for i in range(3)] == [1, 0, 0]

@@ -7,7 +7,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from lr2ppo_amd import ops  # noqa: E402
+from lr2ppo_amd import _native, ops  # noqa: E402
+
+if os.environ.get("LR2_AB_LIB"):            # a switch of THIS tool: another build of the same ABI, loaded explicitly
+    _native.use_library(os.environ["LR2_AB_LIB"])
 
 
 def main():
