@@ -354,7 +354,8 @@ int lr2_vit_assemble(const void* patch_proj, const void* cls, const void* pos, v
  *                    scales as written by lr2_quant_mxfp8.  N % 128 == 0, K % 128 == 0, any M.  out_q / out_scales (both or neither;
  *                    out may then be NULL): the result also / instead quantised to MX-FP8 [M, N] + [M, N / 32] by the same rule --
  *                    the A operand of the next product without an fp32 round trip.  out_hi / out_lo_off / ld_planes: the result also /
- *                    instead as bf16 hi / lo planes (the operand format of lr2_self_attn_fwd and of the split-bf16 products).
+ *                    instead as bf16 hi / lo planes (the operand format of lr2_self_attn_fwd and of the split-bf16 products);
+ *                    out_lo_off == 0 (ABI 18): ONE bf16 plane (round to nearest even), the operand format of lr2_self_attn_fwd_bf16.
  * replaces: nn.Linear forward (tencentpretrain/layers/position_ffn.py:12-15, multi_headed_attn.py:55-76) in that mode. */
 int lr2_quant_mxfp8(const void* x, int ldx, void* q, void* scales, int rows, int K, void* stream);
 /* LayerNorm (lr2_layernorm_fwd's semantics, modes 0 / 1) whose result leaves as MX-FP8 [rows, D] + [rows, D / 32] (and as fp32 when out is
@@ -364,6 +365,14 @@ int lr2_layernorm_fwd_mxfp8(const void* x, const void* gamma, const void* beta, 
 int lr2_gemm_mxfp8(const void* a_q, const void* a_scales, const void* b_q, const void* b_scales, void* out, int ld_out,
                    const void* bias, const void* resid, int ld_resid, int act, void* out_q, void* out_scales, void* out_hi,
                    uint64_t out_lo_off, int ld_planes, int M, int N, int K, void* stream);
+/* Round 4 (ABI 18).  Encoder self-attention of the MX-FP8 mode: q / k / v are ONE bf16 plane each (row stride ld elements; what
+ * lr2_gemm_mxfp8 writes with out_lo_off = 0 -- q, k, v = the three column blocks of one [rows, 3E] matrix), single-pass bf16 products,
+ * fp32 softmax, key mask -10000 * (seg <= 0) after the scale; the context rows leave as fp32 (o_f32 [batch * L, ld_o]) and / or as
+ * MX-FP8 (o_q [batch * L, ld_o] bytes + o_scales [batch * L, ld_o / 32]: the A operand of the output projection, no fp32 round trip, no
+ * quantise pass).  head_dim 64, L <= 288, inference only (no dropout).  NOT the parity path: lr2_self_attn_fwd stays the default.
+ * replaces: tencentpretrain/layers/multi_headed_attn.py:60-74 in that mode. */
+int lr2_self_attn_fwd_bf16(const void* q, const void* k, const void* v, int ld, const int64_t* seg, void* o_f32, void* o_q,
+                           void* o_scales, int ld_o, int batch, int heads, int L, int head_dim, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "liblr2ppo_hip.so")
-SOURCES = ["gemm.hip", "gemm256.hip", "gemm256_mx.hip", "norm.hip", "attn.hip", "selfattn.hip", "misc.hip", "fp8.hip"]
+SOURCES = ["gemm.hip", "gemm256.hip", "gemm256_mx.hip", "norm.hip", "attn.hip", "selfattn.hip", "selfattn_mx.hip", "misc.hip", "fp8.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "fp8_common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
 
 ABI_VERSION = 18     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
@@ -133,6 +133,7 @@ SIGNATURES = {
     "lr2_quant_mxfp8": [_P, _I, _P, _P, _I, _I, _P],
     "lr2_layernorm_fwd_mxfp8": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "lr2_gemm_mxfp8": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _U64, _I, _I, _I, _I, _P],
+    "lr2_self_attn_fwd_bf16": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "lr2_text_embed": [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.c_int64, _I, _P, _P],
     "lr2_patchify_planes": [_P, _I, _P, _U64, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P],
     "lr2_ndcg": [_P, _P, _P, _P, _P, _I, _P, _I, _P],

@@ -139,6 +139,10 @@ __device__ __forceinline__ void split4(float4 v, u32x2_t& hv, u32x2_t& lv) {
   lv = u32x2_t{l01, l23};
 }
 // store 4 consecutive elements of a planes tensor (hi plane at p, lo plane lo_off elements later)
+// four fp32 -> four bf16 (round to nearest even), one 8-byte store: a SINGLE bf16 plane (the MX-FP8 mode's attention operands)
+__device__ __forceinline__ void store_bf16x4(bf16_t* p, float4 v) {
+  *reinterpret_cast<u32x2_t*>(p) = u32x2_t{cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w)};
+}
 __device__ __forceinline__ void store_planes4(bf16_t* p, size_t lo_off, float4 v) {
   u32x2_t hv, lv;
   split4(v, hv, lv);

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mxfp8_lds_kernel(Mx8Params p) {
           v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
         if (p.out) *reinterpret_cast<float4*>(p.out + (size_t)m * p.ld_out + n) = v;
-        if (p.out_hi) store_planes4(p.out_hi + (size_t)m * p.ld_planes + n, p.out_lo_off, v);
+        if (p.out_hi) { if (p.out_lo_off) store_planes4(p.out_hi + (size_t)m * p.ld_planes + n, p.out_lo_off, v); else store_bf16x4(p.out_hi + (size_t)m * p.ld_planes + n, v); }
       }
       if (p.out_q) {
         // a row's 32-column MX block = 8 consecutive lanes x 4 columns (the wave tile's 64 columns are two blocks per row):

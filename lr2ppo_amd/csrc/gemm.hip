@@ -609,7 +609,8 @@ extern "C" int lr2_gemm_row_split_plan(int M, int N, int K, int* rows_256, int* 
   const int tn256 = (N + 255) / 256, tiles256 = ((M + 255) / 256) * tn256;
   const int full = tiles256 / 256, rem = tiles256 - full * 256;
   const int M1 = ((full * 256) / tn256) * 256;          // rows of the tile rows that fit `full` rounds
-  if (!rs_env || full < 1 || rem <= 0 || 2 * rem >= 256 || (K % 64) != 0 || M1 <= 0 || M1 >= M) return 0;
+  // (up to 4 whole rounds: behind 18 rounds -- the encoders at 512 frames -- a thin last round is 2 % of the launch, not worth a seam)
+  if (!rs_env || full < 1 || full > 4 || rem <= 0 || 2 * rem >= 256 || (K % 64) != 0 || M1 <= 0 || M1 >= M) return 0;
   *rows_256 = M1;
   // tail tiles: 64 rows when 128-row tiles would not fill the 512 resident slots, or would leave a thin last round
   const int M2 = M - M1, t128 = ((M2 + 127) / 128) * ((N + 127) / 128), last = t128 % 512;

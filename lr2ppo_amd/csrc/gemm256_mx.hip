@@ -238,7 +238,7 @@ __device__ __forceinline__ void epilogue_slab(const Mx8Params& p, f32x4_t (&acc)
     if (p.resid) { x.x += rr[pass].x; x.y += rr[pass].y; x.z += rr[pass].z; x.w += rr[pass].w; }
     if (ok) {
       if (p.out) lr2gemm::st4(p.out + (size_t)m * p.ld_out + n, x);
-      if (p.out_hi) store_planes4(p.out_hi + (size_t)m * p.ld_planes + n, p.out_lo_off, x);
+      if (p.out_hi) { if (p.out_lo_off) store_planes4(p.out_hi + (size_t)m * p.ld_planes + n, p.out_lo_off, x); else store_bf16x4(p.out_hi + (size_t)m * p.ld_planes + n, x); }
     }
     if (p.out_q) mx_quant_store(p, x, m, n, lane, ok);
   }

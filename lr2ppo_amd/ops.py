@@ -273,7 +273,7 @@ def _use_gemm256(M: int, N: int, K: int, passes: int) -> bool:
     # round 4 (tools/dbg/rowsplit_ab.py): more than one round with a last round LESS than half full -- lr2_gemm then sends the rows of
     # the whole rounds to the 256 x 256 kernel and the remaining rows to the 128- / 64-row kernels (row split: two launches, no
     # reduction): M = 12544, N = 3072, K = 768 (588 tiles) 166 us against 199 (NN on 128-row tiles) / 184 (three rounds of 256 x 256)
-    if tiles > 256 and 0 < tiles % 256 < 128 and K % 64 == 0 and os.environ.get("LR2_GEMM_ROWSPLIT", "1") != "0":
+    if 256 < tiles < 5 * 256 and 0 < tiles % 256 < 128 and K % 64 == 0 and os.environ.get("LR2_GEMM_ROWSPLIT", "1") != "0":
         return True
     # one partial round, long contraction (M = 12544, N = 768, K = 3072: 147 tiles): each CU runs one tile at the 256 x 256 kernel's
     # main-loop rate and the epilogue is amortised over 96 K steps -- 182 us against 197 (64-row tiles) / 212 (128-row), round 3;
@@ -734,13 +734,19 @@ def layernorm_fwd_mxfp8(x, gamma, beta, dst: Mx8, out: Optional[torch.Tensor] = 
 
 
 def gemm_mxfp8(a: Mx8, b: Mx8, out: Optional[torch.Tensor], *, bias=None, resid=None, act: int = 0, out_mx: Optional[Mx8] = None,
-               out_planes: Optional[Planes] = None):
+               out_planes: Optional[Planes] = None, out_bf16: Optional[torch.Tensor] = None):
     """out[M, N] fp32 = a . b^T (+ bias) (act 1: GELU) (+ resid) with a [M, K], b [N, K] in MX-FP8 (lr2_gemm_mxfp8).
-    out_mx: the result also (out given) or only (out None) as MX-FP8 -- the next product's A operand."""
+    out_mx: the result also (out given) or only (out None) as MX-FP8 -- the next product's A operand.
+    out_bf16: the result as ONE bf16 plane (an int16 / bfloat16 tensor of M * N elements): the operands of self_attn_fwd_bf16."""
     _chk_f32(out, bias, resid)
     M, N, K = a.rows, b.rows, a.cols
+    if out_bf16 is not None:
+        if out_planes is not None or out_bf16.element_size() != 2 or not out_bf16.is_cuda or out_bf16.numel() < M * N:
+            raise ValueError("gemm_mxfp8: out_bf16 is a 2-byte HIP tensor of M * N elements, and excludes out_planes")
+        out_planes = Planes.__new__(Planes)       # a single plane: lo_off = 0 (see include/lr2ppo_hip.h)
+        out_planes.buf, out_planes.rows, out_planes.cols, out_planes.lo_off, out_planes.transposed = out_bf16, M, N, 0, False
     if b.cols != K or (out is None and out_mx is None and out_planes is None):
-        raise ValueError("gemm_mxfp8: a [M, K], b [N, K], out [M, N] and / or out_mx / out_planes")
+        raise ValueError("gemm_mxfp8: a [M, K], b [N, K], out [M, N] and / or out_mx / out_planes / out_bf16")
     if out_planes is not None and (out_planes.rows != M or out_planes.cols != N):
         raise ValueError("gemm_mxfp8: out_planes must be [M, N]")
     if out is not None and (out.dim() != 2 or out.shape[0] != M or out.shape[1] != N or out.stride(1) != 1):
@@ -757,6 +763,29 @@ def gemm_mxfp8(a: Mx8, b: Mx8, out: Optional[torch.Tensor], *, bias=None, resid=
                                              out_planes.lo_off if out_planes is not None else 0,
                                              out_planes.cols if out_planes is not None else 0, M, N, K, _stream()), "lr2_gemm_mxfp8")
     return out if out is not None else (out_mx if out_mx is not None else out_planes)
+
+
+def self_attn_fwd_bf16(qkv: torch.Tensor, seg, *, batch, heads, L, head_dim, scale, out: Optional[torch.Tensor] = None,
+                       out_mx: Optional[Mx8] = None):
+    """Encoder self-attention of the MX-FP8 mode (lr2_self_attn_fwd_bf16).  qkv: ONE bf16 plane [batch * L, 3E] = [Q | K | V] (a 2-byte
+    HIP tensor: what gemm_mxfp8(out_bf16=...) writes); the context as fp32 `out` [batch * L, E] and / or as MX-FP8 `out_mx`."""
+    E = heads * head_dim
+    if qkv.element_size() != 2 or not qkv.is_cuda or qkv.numel() < batch * L * 3 * E:
+        raise TypeError("self_attn_fwd_bf16: qkv is a 2-byte HIP tensor [batch * L, 3 * heads * head_dim]")
+    if seg.dtype != torch.int64:
+        raise TypeError("seg must be int64")
+    _chk_f32(out)
+    if out is None and out_mx is None:
+        raise ValueError("self_attn_fwd_bf16: out and / or out_mx")
+    if out_mx is not None and (out_mx.rows != batch * L or out_mx.cols != E):
+        raise ValueError("self_attn_fwd_bf16: out_mx must be [batch * L, heads * head_dim]")
+    base = qkv.data_ptr()
+    with _Timed(f"selfattn_bf16_B{batch}_H{heads}_L{L}", 4.0 * batch * heads * L * L * head_dim, 7.0 * batch * L * E):
+        _nat.check(_nat.lib().lr2_self_attn_fwd_bf16(base, base + 2 * E, base + 4 * E, 3 * E, seg.data_ptr(), _ptr(out),
+                                                     out_mx.q.data_ptr() if out_mx is not None else None,
+                                                     out_mx.s.data_ptr() if out_mx is not None else None, E, batch, heads, L, head_dim,
+                                                     scale, _stream()), "lr2_self_attn_fwd_bf16")
+    return out if out is not None else out_mx
 
 
 def text_embed(src, seg, word, pos, seg_table, out, *, rows, L, D, err: Optional[torch.Tensor] = None):

@@ -13,6 +13,7 @@ hand-written backward (`_EncoderFn`): MFMA attention backward with recomputed pr
 backward, dgrad / wgrad GEMMs with fused GELU' and residual epilogues, dropout at the reference's three sites per layer
 (attention probabilities, dropout_1, dropout_2) from the counter-based mask stream of lr2ppo_amd.runtime."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -256,6 +257,8 @@ class TransformerEncoder(nn.Module):
         h, h2, xn = ws.mat("h", M, E), ws.mat("h2", M, E), ws.mat("fp8_xn", M, E)
         o32 = ws.mat("fp8_o", M, E)
         qkv_p = ws.planes("qkv_p", M, 3 * E)
+        fast_attn = hd == 64 and L <= 288 and os.environ.get("LR2_FP8_ATTN", "1") != "0"     # (longer sequences: the 3-pass kernels)
+        qkv_b = qkv_p.buf[:M * 3 * E]
         if getattr(self, "_fp8_act", None) is None or self._fp8_act[0].rows != M:
             self._fp8_act = (ops.Mx8.empty(M, E, dev), ops.Mx8.empty(M, F, dev))
         x_q, ff_q = self._fp8_act
@@ -271,9 +274,14 @@ class TransformerEncoder(nn.Module):
                 kv_p = ws.planes("kv_p", M, 2 * E)
                 ops.gemm_mxfp8(x_q, w["wkv"], None, bias=w["bqkv"][E:], out_planes=kv_p)
                 return self._last_layer_first_token(ws, layer, self._weight_planes(dev)[li], h, None, seg, B, L, E, F, kv_p=kv_p)
-            ops.gemm_mxfp8(x_q, w["wqkv"], None, bias=w["bqkv"], out_planes=qkv_p)     # the attention kernels take bf16 hi / lo planes
-            ops.self_attn_fwd(qkv_p, seg, o32, batch=B, heads=H, L=L, head_dim=hd, scale=scale)
-            ops.quant_mxfp8(o32, x_q)
+            if fast_attn:
+                # Q | K | V as ONE bf16 plane, single-pass attention, context straight to MX-FP8 (csrc/selfattn_mx.hip)
+                ops.gemm_mxfp8(x_q, w["wqkv"], None, bias=w["bqkv"], out_bf16=qkv_b)
+                ops.self_attn_fwd_bf16(qkv_b, seg, batch=B, heads=H, L=L, head_dim=hd, scale=scale, out_mx=x_q)
+            else:
+                ops.gemm_mxfp8(x_q, w["wqkv"], None, bias=w["bqkv"], out_planes=qkv_p)     # the 3-pass attention kernels take bf16 hi / lo planes
+                ops.self_attn_fwd(qkv_p, seg, o32, batch=B, heads=H, L=L, head_dim=hd, scale=scale)
+                ops.quant_mxfp8(o32, x_q)
             ops.gemm_mxfp8(x_q, w["wo"], h2, bias=att.final_linear.bias.data, resid=h)
             if pre:                                                   # layers/transformer.py:63-73
                 ops.layernorm_fwd_mxfp8(h2, ln2.gamma.data, ln2.beta.data, x_q, rows=M, D=E, eps=ln2.eps, mode=1)

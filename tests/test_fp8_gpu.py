@@ -204,3 +204,52 @@ def test_ring_product_is_exact_on_small_integers(dev):
     out = torch.empty(M, N, device=dev)
     ops.gemm_mxfp8(am, bm, out)
     assert torch.equal(out.cpu(), (a.double() @ b.double().t()).float())
+
+
+# ---- the MX-FP8 mode's attention (csrc/selfattn_mx.hip): one bf16 plane per operand, single-pass products, MX-FP8 context ------------
+@pytest.mark.parametrize("batch,heads,L", [(2, 16, 257), (3, 12, 197), (2, 4, 64), (1, 2, 288), (2, 3, 100), (1, 1, 17), (2, 2, 225)])
+def test_bf16_attention_matches_fp64_on_its_own_operands(dev, batch, heads, L):
+    """lr2_self_attn_fwd_bf16 against the fp64 formula evaluated on the SAME bf16-rounded Q, K, V (so the only differences are the
+    bf16 rounding of the un-normalised probabilities, 2^-9 relative each, and fp32 accumulation): key mask on the last sequence, every
+    key-tile count (4 / 8 / 14 / 18 tiles, ragged last tile), ViT-L/14's 257 and ViT-B/16's 197 tokens; the MX-FP8 output equals
+    lr2_quant_mxfp8 of the fp32 output byte for byte."""
+    from lr2ppo_amd import ops
+    g = torch.Generator().manual_seed(L + heads)
+    E = heads * 64
+    qkv = torch.cat([torch.randn(batch * L, E, generator=g) * 0.5, torch.randn(batch * L, E, generator=g) * 0.5,
+                     torch.randn(batch * L, E, generator=g)], dim=1).to(torch.bfloat16)
+    seg = torch.ones(batch, L, dtype=torch.long)
+    seg[-1, (2 * L) // 3:] = 0
+    mask = (1.0 - (seg > 0).double()).view(batch, 1, 1, L) * -10000.0
+    qh, kh, vh = (t.double().reshape(batch, L, heads, 64).transpose(1, 2) for t in qkv.split(E, dim=1))
+    sc = qh @ kh.transpose(-2, -1) / 8.0 + mask
+    ref = (torch.softmax(sc, dim=-1) @ vh).transpose(1, 2).reshape(batch * L, E)
+    out = torch.full((batch * L, E), float("nan"), device=dev)
+    mx = ops.Mx8.empty(batch * L, E, dev)
+    ops.self_attn_fwd_bf16(qkv.to(dev), seg.to(dev).view(-1), batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, out=out, out_mx=mx)
+    assert torch.isfinite(out).all()
+    err = (out.double().cpu() - ref).abs().max().item()
+    assert err < 6e-3 * float(vh.abs().max()), err
+    assert (out.double().cpu() - ref).norm() / ref.norm() < 2e-3
+    want = ops.quant_mxfp8(out)
+    assert torch.equal(mx.s, want.s) and torch.equal(mx.q, want.q)
+    only = ops.Mx8.empty(batch * L, E, dev)
+    ops.self_attn_fwd_bf16(qkv.to(dev), seg.to(dev).view(-1), batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, out_mx=only)
+    assert torch.equal(only.s, want.s) and torch.equal(only.q, want.q)
+    with pytest.raises(Exception):
+        ops.self_attn_fwd_bf16(qkv.to(dev), seg.to(dev).view(-1), batch=batch, heads=heads, L=300, head_dim=64, scale=0.125, out=out)
+
+
+def test_product_can_leave_as_one_bf16_plane(dev):
+    """gemm_mxfp8(out_bf16=...): the round-to-nearest bf16 of the fp32 row it would have stored, on both product kernels."""
+    from lr2ppo_amd import ops
+    g = torch.Generator().manual_seed(12)
+    for M, N, K in ((333, 512, 256), (8100, 2048, 256)):
+        a, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
+        bias = torch.randn(N, generator=g) * 0.1
+        am, bm = ops.quant_mxfp8(a.to(dev)), ops.quant_mxfp8(b.to(dev))
+        out = torch.empty(M, N, device=dev)
+        ops.gemm_mxfp8(am, bm, out, bias=bias.to(dev))
+        ob = torch.empty(M * N, dtype=torch.bfloat16, device=dev)
+        ops.gemm_mxfp8(am, bm, None, bias=bias.to(dev), out_bf16=ob)
+        assert torch.equal(ob.view(M, N), out.to(torch.bfloat16))

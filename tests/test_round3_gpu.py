@@ -14,7 +14,7 @@ from oracle import lr2ppo_oracle as O
 pytestmark = pytest.mark.gpu
 
 REL = 2e-3          # the bar of the encoder-backward tests (test_round2_gpu.py: sum-of-squares within 2e-3, sampled values)
-FLIP_MAX, FAR_MAX = 2e-3, 4e-2      # test_finetune_pointwise_step_...: share of elements whose first AdamW step may flip / differ (see there)
+FLIP_MAX, FAR_MAX = 1e-4, 1e-3      # test_finetune_pointwise_step_...: share of elements whose first AdamW step may flip / differ (measured: 0 and 0; rel-L2 of the update 3e-5 .. 2e-4)
 
 
 def _head_args(dev, **over):
@@ -320,7 +320,7 @@ def test_finetune_pointwise_step_trains_head_and_both_stacks(dev):
         flipped = float(((du_got * du_want < 0) & (du_got.abs() > 0.5 * step) & (du_want.abs() > 0.5 * step)).double().mean())
         far = float(((du_got - du_want).abs() > 0.05 * step).double().mean())
         print(f"{name}: update rel-L2 {rel:.2e}, flipped {flipped:.2e}, far {far:.2e}")
-        assert rel < 2e-2 and flipped < FLIP_MAX and far < FAR_MAX, (name, rel, flipped, far)
+        assert rel < 2e-3 and flipped < FLIP_MAX and far < FAR_MAX, (name, rel, flipped, far)
     losses = [l0, finetune_pointwise_step(args, fx, model, opt, sch, eopt, esch, frames.to(dev), ids.to(dev), seg.to(dev), tgts.to(dev))]
     fx.text.embedding.check_ids()
     assert abs(float(losses[0]) - float(loss_ref)) < 1e-3
