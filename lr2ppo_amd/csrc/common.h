@@ -115,6 +115,19 @@ static inline uint32_t dropout_threshold(float p) {
   return (uint32_t)t;
 }
 
+// max over aligned groups of 4 / 8 consecutive lanes, result in every lane of the group, on the VALU's DPP path (quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror).  __shfl_xor compiles to ds_bpermute_b32: an LDS round trip (~130 cycles) and a dozen index
+// instructions per step -- three per 4-column group in the MX-FP8 epilogues made them 18 us of a 35-us K = 1024 tile (round 4).
+__device__ __forceinline__ float group4_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  return v;
+}
+__device__ __forceinline__ float group8_max(float v) {
+  v = group4_max(v);
+  return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

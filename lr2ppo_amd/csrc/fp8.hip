@@ -33,8 +33,7 @@ __global__ __launch_bounds__(256) void quant_mxfp8_kernel(const float* __restric
     const float4 b = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + 8 * g + 4);
     float amax = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))),
                        fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));         // the block's 32 elements = 4 consecutive lanes (k8 is a multiple of 4)
+    amax = group4_max(amax);         // the block's 32 elements = 4 consecutive lanes (k8 is a multiple of 4)
     // shared exponent: floor(log2(amax)) - emax(e4m3 = 8), as a biased E8M0 byte; amax = 0 (or denormal): the smallest scale
     const int ex = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127;          // floor(log2(amax)) of a normal float
     int e = ex - 8;
@@ -281,9 +280,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mxfp8_lds_kernel(Mx8Params p) {
           v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
         float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-        amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+        amax = group8_max(amax);
         int e = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127 - 8;
         if (amax < 1.17549435e-38f) e = -127;
         if (e < -127) e = -127;

@@ -43,6 +43,8 @@ constexpr int STAGE = 4 * PART;                // parts A0, B0, B1, A1
 constexpr int RING = 2 * STAGE;                // 128 KiB
 constexpr int SC_STAGE = 2048;                 // A scales [256 rows][4 B], then B scales [256][4 B]
 constexpr int LDS_BYTES = RING + 2 * SC_STAGE;
+constexpr int SC16_STAGE = 8192;               // SC16: A scales [256 rows][16 B] (4 K steps each), then B scales [256][16 B]
+constexpr int LDS_BYTES16 = RING + 2 * SC16_STAGE;
 constexpr int SLOT_A0 = 0, SLOT_B0 = 1, SLOT_B1 = 2, SLOT_A1 = 3;
 constexpr uint32_t OOB = 0xFFFFFF00u;          // beyond any descriptor this library builds
 
@@ -66,7 +68,8 @@ struct Ctx {
   uint32_t voff_a[2], voff_b[2];     // per-lane source byte offsets of this wave's piece of part A(h) / B(h) at K step 0
   uint32_t voff_s;                   // per-lane source byte offset of this lane's scale row at K step 0
   uint32_t rd_a[2], rd_b[2];         // per-lane LDS read bases (fragments) for stage 0 / 1
-  uint32_t rd_sa, rd_sb;             // per-lane LDS read bases (scales), stage 0
+  uint32_t rd_sa, rd_sb;             // per-lane LDS read bases (scales), stage 0 (SC16: + the step's offset, see k_step)
+  int ks;                            // scale bytes per row (K / 32)
   char* smem;
   int wave, nt;
 };
@@ -108,6 +111,26 @@ __device__ __forceinline__ void read_b_half(uint32_t base, v8i_t (&b)[2]) {
   b[1] = v8i_t{(int)l1[0], (int)l1[1], (int)l1[2], (int)l1[3], (int)h1[0], (int)h1[1], (int)h1[2], (int)h1[3]};
 }
 // scales of accumulator half AH / BH for stage S: A rows wr*128 + AH*64 + 16 i + r16, B rows wc*64 + BH*32 + 16 j + r16
+// SC16 form: the scale bytes of FOUR K steps per row and DMA (16 B per lane): a 4-byte gather per lane and step touched one cache
+// line per row and step -- as many L2 -> L1 bytes as the operands themselves, 0.56 of 2.21 us per K step (tools/dbg/mx_ablate.py)
+__device__ __forceinline__ void issue_scales16(const Ctx& c, int quad, int stage) {
+  const uint32_t off = (uint32_t)quad * 16u;
+  const uint32_t v = (off < (uint32_t)c.ks && c.voff_s != OOB) ? c.voff_s + off : OOB;
+  char* dst = c.smem + RING + stage * SC16_STAGE + c.wave * 1024;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(c.sc, LDS_PTR(dst), 16, v, 0, 0, 0);
+}
+template <int AH>
+__device__ __forceinline__ void read_sa16(uint32_t base, int (&sa)[4]) {
+  sa[0] = lds_read_u8<(AH * 64 + 0) * 16>(base);
+  sa[1] = lds_read_u8<(AH * 64 + 16) * 16>(base);
+  sa[2] = lds_read_u8<(AH * 64 + 32) * 16>(base);
+  sa[3] = lds_read_u8<(AH * 64 + 48) * 16>(base);
+}
+template <int BH>
+__device__ __forceinline__ void read_sb16(uint32_t base, int (&sb)[2]) {
+  sb[0] = lds_read_u8<(BH * 32 + 0) * 16>(base);
+  sb[1] = lds_read_u8<(BH * 32 + 16) * 16>(base);
+}
 template <int S, int AH>
 __device__ __forceinline__ void read_sa(uint32_t base, int (&sa)[4]) {
   sa[0] = lds_read_u8<S * SC_STAGE + (AH * 64 + 0) * 4>(base);
@@ -131,52 +154,79 @@ __device__ __forceinline__ void end_load_section() {
 }
 
 // 8 instructions of one accumulator quadrant (K = 128 each)
-template <int AH, int BH>
+template <int AH, int BH, int ABL = 0>
 __device__ __forceinline__ void mfma_section(f32x4_t (&acc)[8][4], const v8i_t (&a)[4], const v8i_t (&b)[2], const int (&sa)[4],
                                              const int (&sb)[2]) {
   __builtin_amdgcn_s_setprio(1);
+  if constexpr (ABL & 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(a[i]), "v"(sa[i]));
+    asm volatile("" ::"v"(b[0]), "v"(b[1]), "v"(sb[0]), "v"(sb[1]));
+  } else {
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       acc[AH * 4 + i][BH * 2 + j] =
           __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[i], b[j], acc[AH * 4 + i][BH * 2 + j], 0, 0, 0, sa[i], 0, sb[j]);
+  }
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int S>
+// ABL (diagnostics, LR2_MX_ABLATE, never in a timed product run): 1 = no scale traffic (unit scales), 2 = no operand DMA,
+// 4 = no matrix instructions, 8 = no epilogue
+template <int S, int ABL, bool SC16>
 __device__ __forceinline__ void k_step(const Ctx& c, int t, f32x4_t (&acc)[8][4]) {
   v8i_t a[4], b[2];
-  int sa[4], sb0[2], sb1[2];
+  int sa[4] = {127, 127, 127, 127}, sb0[2] = {127, 127}, sb1[2] = {127, 127};
+  constexpr bool SC = !(ABL & 1);
+  // SC16: the step's scales sit in stage (t >> 2) & 1 at byte 4 (t & 3) of the lane's row
+  const uint32_t soff = SC16 ? (uint32_t)(((t >> 2) & 1) * SC16_STAGE + (t & 3) * 4) : 0u;
+  const uint32_t rsa = c.rd_sa + soff, rsb = c.rd_sb + soff;
+  // the waits: SC16 issues a scale DMA in one step of four only, so the counts are those of the operand parts alone (an extra DMA in
+  // flight makes a counted wait stricter, never laxer); the 4-byte form issues one per step and counts it
+  constexpr int W0 = (ABL & 2) ? 0 : (SC && !SC16) ? 14 : 12, W2 = (ABL & 2) ? 0 : (SC && !SC16) ? 13 : 12, W3 = (ABL & 2) ? 0 : (SC && !SC16) ? 7 : 6;
   // phase 0: quadrant (A0, B0)
-  issue_part<SLOT_B0, false, 0>(c, t + 1, S ^ 1);
+  if (!(ABL & 2)) issue_part<SLOT_B0, false, 0>(c, t + 1, S ^ 1);
   read_a_half<SLOT_A0>(c.rd_a[S], a);
   read_b_half<SLOT_B0>(c.rd_b[S], b);
-  read_sa<S, 0>(c.rd_sa, sa);
-  read_sb<S, 0>(c.rd_sb, sb0);
-  end_load_section<14>();
-  mfma_section<0, 0>(acc, a, b, sa, sb0);
+  if constexpr (SC && SC16) {
+    read_sa16<0>(rsa, sa);
+    read_sb16<0>(rsb, sb0);
+  } else if constexpr (SC) {
+    read_sa<S, 0>(c.rd_sa, sa);
+    read_sb<S, 0>(c.rd_sb, sb0);
+  }
+  end_load_section<W0>();
+  mfma_section<0, 0, ABL>(acc, a, b, sa, sb0);
   // phase 1: (A0, B1)
-  issue_part<SLOT_A0, true, 0>(c, t + 2, S);
+  if (!(ABL & 2)) issue_part<SLOT_A0, true, 0>(c, t + 2, S);
   read_b_half<SLOT_B1>(c.rd_b[S], b);
-  read_sb<S, 1>(c.rd_sb, sb1);
-  end_load_section<14>();
-  mfma_section<0, 1>(acc, a, b, sa, sb1);
+  if constexpr (SC && SC16) read_sb16<1>(rsb, sb1);
+  else if constexpr (SC) read_sb<S, 1>(c.rd_sb, sb1);
+  end_load_section<W0>();
+  mfma_section<0, 1, ABL>(acc, a, b, sa, sb1);
   // phase 2: (A1, B1)
-  issue_part<SLOT_B1, false, 1>(c, t + 2, S);
+  if (!(ABL & 2)) issue_part<SLOT_B1, false, 1>(c, t + 2, S);
   read_a_half<SLOT_A1>(c.rd_a[S], a);
-  read_sa<S, 1>(c.rd_sa, sa);
-  end_load_section<13>();
-  mfma_section<1, 1>(acc, a, b, sa, sb1);
-  // phase 3: (A1, B0); every scale read of step t was retired one barrier ago by both groups: its slot takes step t + 2
-  issue_part<SLOT_A1, true, 1>(c, t + 2, S);
-  issue_scales(c, t + 2, S);
+  if constexpr (SC && SC16) read_sa16<1>(rsa, sa);
+  else if constexpr (SC) read_sa<S, 1>(c.rd_sa, sa);
+  end_load_section<W2>();
+  mfma_section<1, 1, ABL>(acc, a, b, sa, sb1);
+  // phase 3: (A1, B0); every scale read of step t was retired one barrier ago by both groups.  4-byte form: the step's slot takes
+  // step t + 2.  SC16: at the first step of a quad the OTHER stage (last read in step t - 1) takes the next quad.
+  if (!(ABL & 2)) issue_part<SLOT_A1, true, 1>(c, t + 2, S);
+  if constexpr (SC && SC16) {
+    if ((t & 3) == 0) issue_scales16(c, (t >> 2) + 1, ((t >> 2) + 1) & 1);
+  } else if constexpr (SC) {
+    issue_scales(c, t + 2, S);
+  }
   read_b_half<SLOT_B0>(c.rd_b[S], b);
-  end_load_section<7>();
-  mfma_section<1, 0>(acc, a, b, sa, sb0);
+  end_load_section<W3>();
+  mfma_section<1, 0, ABL>(acc, a, b, sa, sb0);
 }
 
 // ---- epilogue: one 32-row slab of the wave tile (accumulator tile rows 2 HALF, 2 HALF + 1) --------------------------------------
@@ -188,9 +238,7 @@ __device__ __forceinline__ float4 mx_finish(const Mx8Params& p, float4 v, float4
 // the row's 32-column MX block = 8 consecutive lanes x 4 columns: quantise as lr2_quant_mxfp8 would the stored row
 __device__ __forceinline__ void mx_quant_store(const Mx8Params& p, float4 v, int m, int n, int lane, bool ok) {
   float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-  amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+  amax = group8_max(amax);
   int e = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127 - 8;
   if (amax < 1.17549435e-38f) e = -127;
   if (e < -127) e = -127;
@@ -206,12 +254,67 @@ __device__ __forceinline__ void mx_quant_store(const Mx8Params& p, float4 v, int
   }
 }
 
+// Straight-line forms of a slab that lies inside the matrix, chosen ONCE per slab (wave-uniform) -- the encoder's four products:
+//   FORM 0: (+ bias) -> ONE bf16 plane (QKV)          FORM 1: -> bf16 hi / lo planes          FORM 2: + residual -> fp32 (output
+//   projection, FFN-2)   FORM 3 / 4: (GELU for 4) -> MX-FP8 (FFN-1).
+// The general body below decides everything per pass: a dozen wave-uniform branches, exec-masked stores, a residual select that made
+// the compiler wait (vmcnt: loads AND stores, in order) for stores two passes back, 64-bit address arithmetic per store -- 16 us per
+// K = 1024 tile against 17 us of main loop.  Same operations in the same order per element as the general body: same bytes.
+template <int HALF, int FORM>
+__device__ __forceinline__ void epilogue_slab_fast(const Mx8Params& p, f32x4_t (&acc)[8][4], float* slab, int mw, int nw, int lane, float4 b4) {
+  constexpr int NP = 8, RPP = 4, LDW = 68;
+  const int row0 = lane >> 4, col = (lane & 15) * 4, n = nw + col;
+  const int mbase = mw + 32 * HALF + row0;
+  float4 rr[NP];
+  if constexpr (FORM == 2) {
+    const float* r0 = p.resid + (size_t)mbase * p.ld_resid + n;
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) rr[pass] = lr2gemm::ld4(r0 + (size_t)(pass * RPP) * p.ld_resid);
+  }
+  lr2gemm::epilogue_to_slab<64, 8, 4, HALF>(acc, slab, lane);
+  float4 v[NP];
+  lr2gemm::slab_read_all<64, NP, 0>(lds_addr(slab) + (uint32_t)((row0 * LDW + col) * 4), v);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    const int m = mbase + pass * RPP;
+    float4 x = v[pass];
+    x.x += b4.x; x.y += b4.y; x.z += b4.z; x.w += b4.w;
+    if constexpr (FORM == 4) { x.x = gelu_erf(x.x); x.y = gelu_erf(x.y); x.z = gelu_erf(x.z); x.w = gelu_erf(x.w); }
+    if constexpr (FORM == 2) {
+      x.x += rr[pass].x; x.y += rr[pass].y; x.z += rr[pass].z; x.w += rr[pass].w;
+      lr2gemm::st4(p.out + (size_t)m * p.ld_out + n, x);
+    } else if constexpr (FORM == 0) {
+      store_bf16x4(p.out_hi + (size_t)m * p.ld_planes + n, x);
+    } else if constexpr (FORM == 1) {
+      store_planes4(p.out_hi + (size_t)m * p.ld_planes + n, p.out_lo_off, x);
+    } else {
+      mx_quant_store(p, x, m, n, lane, true);
+    }
+  }
+}
+
 template <int HALF>
 __device__ __forceinline__ void epilogue_slab(const Mx8Params& p, f32x4_t (&acc)[8][4], float* slab, int mw, int nw, int lane, float4 b4) {
   constexpr int NP = 8, RPP = 4, LDW = 68;
   const int row0 = lane >> 4, col = (lane & 15) * 4, n = nw + col;
   const int mbase = mw + 32 * HALF + row0;
   const bool inside = mw + 32 * HALF + 32 <= p.M;            // wave-uniform
+  if (inside && p.act <= 1) {
+    const bool f32 = p.out != nullptr, pl = p.out_hi != nullptr, mx = p.out_q != nullptr, rs = p.resid != nullptr;
+    if (pl && !f32 && !mx && !rs && p.act == 0) {
+      if (p.out_lo_off) epilogue_slab_fast<HALF, 1>(p, acc, slab, mw, nw, lane, b4);
+      else epilogue_slab_fast<HALF, 0>(p, acc, slab, mw, nw, lane, b4);
+      return;
+    }
+    if (f32 && rs && !pl && !mx && p.act == 0) { epilogue_slab_fast<HALF, 2>(p, acc, slab, mw, nw, lane, b4); return; }
+    if (mx && !f32 && !pl && !rs) {
+      if (p.act == 1) epilogue_slab_fast<HALF, 4>(p, acc, slab, mw, nw, lane, b4);
+      else epilogue_slab_fast<HALF, 3>(p, acc, slab, mw, nw, lane, b4);
+      return;
+    }
+  }
   float4 rr[NP];
   if (p.resid) {                                             // every residual request of the slab before its first store
     if (inside) {
@@ -244,6 +347,7 @@ __device__ __forceinline__ void epilogue_slab(const Mx8Params& p, f32x4_t (&acc)
   }
 }
 
+template <int ABL, bool SC16>
 __global__ __launch_bounds__(512, 2) void gemm256_mx_kernel(Mx8Params p, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -290,8 +394,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_mx_kernel(Mx8Params p, int til
       c.rd_a[s] = sm + s * STAGE + wr * 4096 + lane_off;     // A part: local row wr*64 + i*16 + r16
       c.rd_b[s] = sm + s * STAGE + wc * 2048 + lane_off;     // B part: local row wc*32 + j*16 + r16
     }
-    c.rd_sa = sm + RING + (uint32_t)((wr * 128 + r16) * 4 + q);
-    c.rd_sb = sm + RING + 1024u + (uint32_t)((wc * 64 + r16) * 4 + q);
+    c.rd_sa = sm + RING + (SC16 ? (uint32_t)((wr * 128 + r16) * 16 + q) : (uint32_t)((wr * 128 + r16) * 4 + q));
+    c.rd_sb = sm + RING + (SC16 ? 4096u + (uint32_t)((wc * 64 + r16) * 16 + q) : 1024u + (uint32_t)((wc * 64 + r16) * 4 + q));
+    c.ks = ks;
   }
 
   f32x4_t acc[8][4];
@@ -300,24 +405,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_mx_kernel(Mx8Params p, int til
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // prologue: K steps 0 and 1 except B0(1), in the steady-state issue order (... A1, S, B0, A0, B1, A1, S ...)
+  // prologue: K steps 0 and 1 except B0(1), in the steady-state issue order (... A1, S, B0, A0, B1, A1, S ...); SC16: the first
+  // quad of scales first (the oldest request: every later counted wait covers it)
+  if constexpr (SC16) issue_scales16(c, 0, 0);
   issue_part<SLOT_A0, true, 0>(c, 0, 0);
   issue_part<SLOT_B1, false, 1>(c, 0, 0);
   issue_part<SLOT_A1, true, 1>(c, 0, 0);
-  issue_scales(c, 0, 0);
+  if constexpr (!SC16) issue_scales(c, 0, 0);
   issue_part<SLOT_B0, false, 0>(c, 0, 0);
   issue_part<SLOT_A0, true, 0>(c, 1, 1);
   issue_part<SLOT_B1, false, 1>(c, 1, 1);
   issue_part<SLOT_A1, true, 1>(c, 1, 1);
-  issue_scales(c, 1, 1);
-  end_load_section<7>();                        // everything of K step 0 has landed, everyone's
+  if constexpr (!SC16) issue_scales(c, 1, 1);
+  end_load_section<SC16 ? 6 : 7>();             // everything of K step 0 has landed, everyone's
   if (wr == 1) {                                // waves 4-7 run one section behind waves 0-3
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
   for (int t = 0; t < c.nt; t += 2) {
-    k_step<0>(c, t, acc);
-    if (t + 1 < c.nt) k_step<1>(c, t + 1, acc);
+    k_step<0, ABL, SC16>(c, t, acc);
+    if (t + 1 < c.nt) k_step<1, ABL, SC16>(c, t + 1, acc);
   }
   if (wr == 0) {                                // same number of barriers for every wave
     __builtin_amdgcn_s_barrier();
@@ -328,6 +435,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_mx_kernel(Mx8Params p, int til
   __builtin_amdgcn_sched_barrier(0);
 
   const int mw = m0 + wr * 128, nw = n0 + wc * 64;
+  if constexpr (ABL == 8) {                     // diagnostics: no epilogue at all (the accumulators are kept alive)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   if (nw + 64 > p.N || mw >= p.M) return;       // N % 128 == 0 <=> a wave's 64 columns are all inside or all outside
   float* slab = reinterpret_cast<float*>(smem) + wave * (32 * (64 + 4));
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -345,10 +459,29 @@ int launch_gemm256_mx(const Mx8Params& p, hipStream_t stream) {
   using namespace lr2mx256;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   static bool attr_set = false;
+  static int abl = 0, sc16_env = 1;
   if (!attr_set) {
-    if (lr2_allow_dynamic_lds(gemm256_mx_kernel, LDS_BYTES, "gemm256_mx")) return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(gemm256_mx_kernel<0, false>, LDS_BYTES, "gemm256_mx")) return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(gemm256_mx_kernel<0, true>, LDS_BYTES16, "gemm256_mx")) return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(gemm256_mx_kernel<1, false>, LDS_BYTES, "gemm256_mx")) return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(gemm256_mx_kernel<2, false>, LDS_BYTES, "gemm256_mx")) return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(gemm256_mx_kernel<4, false>, LDS_BYTES, "gemm256_mx")) return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(gemm256_mx_kernel<8, false>, LDS_BYTES, "gemm256_mx")) return LR2_ERR_LAUNCH;
+    const char* e = getenv("LR2_MX_ABLATE");      // diagnostics only (wrong results): see k_step
+    abl = e ? atoi(e) : 0;
+    const char* e16 = getenv("LR2_MX_SC16");      // 0: one 4-byte scale gather per K step everywhere (A/B)
+    sc16_env = e16 ? atoi(e16) : 1;
     attr_set = true;
   }
-  LR2_LAUNCH(gemm256_mx_kernel, dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES, stream, p, tiles_m, tiles_n);
+  const dim3 grid(tiles_m * tiles_n);
+  // whole 16-byte scale chunks per row (K / 32 a multiple of 16): the SC16 form; else the 4-byte form
+  // (from K = 2048: at K = 1024 -- 8 steps -- the row gather in the prologue costs more than the seven later gathers it saves)
+  const bool sc16 = sc16_env && (p.K % 512) == 0 && p.K >= 2048;
+  if (abl == 1) LR2_LAUNCH((gemm256_mx_kernel<1, false>), grid, dim3(512), LDS_BYTES, stream, p, tiles_m, tiles_n);
+  else if (abl == 2) LR2_LAUNCH((gemm256_mx_kernel<2, false>), grid, dim3(512), LDS_BYTES, stream, p, tiles_m, tiles_n);
+  else if (abl == 4) LR2_LAUNCH((gemm256_mx_kernel<4, false>), grid, dim3(512), LDS_BYTES, stream, p, tiles_m, tiles_n);
+  else if (abl == 8) LR2_LAUNCH((gemm256_mx_kernel<8, false>), grid, dim3(512), LDS_BYTES, stream, p, tiles_m, tiles_n);
+  else if (sc16) LR2_LAUNCH((gemm256_mx_kernel<0, true>), grid, dim3(512), LDS_BYTES16, stream, p, tiles_m, tiles_n);
+  else LR2_LAUNCH((gemm256_mx_kernel<0, false>), grid, dim3(512), LDS_BYTES, stream, p, tiles_m, tiles_n);
   return lr2_launch_status(__func__);
 }

@@ -70,9 +70,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
         // MX-FP8 (csrc/fp8.hip's rule): a 32-column block = 8 consecutive lanes x 4 columns; D % 32 == 0, so a block's lanes are
         // all inside the row or all outside
         float amax = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
-        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-        amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+        amax = group8_max(amax);
         int ex = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127 - 8;
         if (amax < 1.17549435e-38f) ex = -127;
         if (ex < -127) ex = -127;

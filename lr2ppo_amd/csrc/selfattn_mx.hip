@@ -175,9 +175,7 @@ __global__ __launch_bounds__(64 * NW) void self_attn_bf16_mx_kernel(const bf16_t
       if (Oq) {
         // the row's 32-column MX block = 8 consecutive lanes x 4 columns (the head's 64 columns are two blocks): as lr2_quant_mxfp8
         float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-        amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+        amax = group8_max(amax);
         int e = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127 - 8;
         if (amax < 1.17549435e-38f) e = -127;
         if (e < -127) e = -127;

@@ -135,9 +135,11 @@ def test_layernorm_can_leave_as_mx_fp8(dev, mode):
 
 # ---- the 256 x 256 LDS-DMA ring (csrc/gemm256_mx.hip): products whose one-workgroup-per-CU rounds are well filled ------------------
 @pytest.mark.parametrize("M,N,K,act,with_resid", [(8192, 2048, 128, 0, False), (8000, 2048, 256, 1, True), (16384, 1024, 384, 0, True),
-                                                   (7937, 2176, 1024, 1, False)])
+                                                   (7937, 2176, 1024, 1, False), (8192, 2048, 512, 0, False), (8100, 2048, 1536, 1, True),
+                                                   (8192, 2048, 2560, 0, False)])
 def test_ring_product_matches_the_dequantised_operands(dev, M, N, K, act, with_resid):
-    """>= 256 tiles of 256 x 256 -> lr2_gemm_mxfp8 takes the ring kernel: every K-step parity (1, 2, 3, 8 steps), ragged M (a last
+    """>= 256 tiles of 256 x 256 -> lr2_gemm_mxfp8 takes the ring kernel: both scale-staging forms (K % 512 == 0: the scales of four
+    K steps per 16-byte DMA -- 1, 2, 3 and 5 such chunks per row; else one 4-byte gather per step), every K-step parity, ragged M (a last
     tile row of 64 / 1 rows), N a multiple of 128 but not of 256 (a half-empty last tile column), fused bias / GELU / residual --
     against the fp64 product of the dequantised operands (bound of the instruction's adder tree) and against the 128 x 128 kernel
     (LR2_FP8_256=0 is read once per process, so the comparison value comes from a slice that stays on the small kernel)."""
@@ -194,16 +196,18 @@ def test_ring_product_is_exact_on_small_integers(dev):
     wave / quadrant / plane index maps and the scale routing of the ring kernel are checked bit for bit against integer arithmetic
     (asymmetric B: a transposed output would not pass)."""
     from lr2ppo_amd import ops
-    M, N, K = 8192, 2048, 256
-    g = torch.Generator().manual_seed(2)
-    a = torch.randint(-3, 4, (M, K), generator=g).float() * torch.exp2(torch.randint(-2, 3, (M, 1), generator=g).float())
-    b = torch.randint(-3, 4, (N, K), generator=g).float() * torch.exp2((torch.arange(N) % 5).float().view(-1, 1) - 2)
-    b[:, :32] *= 4.0                                      # the first K block of every B row on another scale than the rest
-    am, bm = ops.quant_mxfp8(a.to(dev)), ops.quant_mxfp8(b.to(dev))
-    assert torch.equal(am.to_float().cpu(), a) and torch.equal(bm.to_float().cpu(), b)
-    out = torch.empty(M, N, device=dev)
-    ops.gemm_mxfp8(am, bm, out)
-    assert torch.equal(out.cpu(), (a.double() @ b.double().t()).float())
+    for M, N, K in ((8192, 2048, 256), (8192, 2048, 1024)):            # 4-byte scale gathers / 16-byte scale chunks (two per row)
+        g = torch.Generator().manual_seed(2)
+        a = torch.randint(-3, 4, (M, K), generator=g).float() * torch.exp2(torch.randint(-2, 3, (M, 1), generator=g).float())
+        b = torch.randint(-3, 4, (N, K), generator=g).float() * torch.exp2((torch.arange(N) % 5).float().view(-1, 1) - 2)
+        for blk in range(K // 32):                        # every 32-element K block of every row on its own scale
+            a[:, 32 * blk:32 * blk + 32] *= 2.0 ** (blk % 3)
+            b[:, 32 * blk:32 * blk + 32] *= 2.0 ** ((blk * 5) % 4)
+        am, bm = ops.quant_mxfp8(a.to(dev)), ops.quant_mxfp8(b.to(dev))
+        assert torch.equal(am.to_float().cpu(), a) and torch.equal(bm.to_float().cpu(), b)
+        out = torch.empty(M, N, device=dev)
+        ops.gemm_mxfp8(am, bm, out)
+        assert torch.equal(out.cpu(), (a.double() @ b.double().t()).float()), (M, N, K)
 
 
 # ---- the MX-FP8 mode's attention (csrc/selfattn_mx.hip): one bf16 plane per operand, single-pass products, MX-FP8 context ------------
