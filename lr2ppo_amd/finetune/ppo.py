@@ -912,11 +912,17 @@ class GraphedPPOStep:
 
     Call 1 runs eagerly (it sizes the workspaces), call 2 captures and replays, later calls replay.  Inputs are copied into
     static buffers (pass the buffers themselves -- .text / .img / .tgts -- to skip the copies).  The returned metrics tensor is
-    static too: read it before the next call.  Single rank only: a captured step holds no collectives."""
+    static too: read it before the next call.  Data parallel (round 4): with the RCCL backend the step's collectives -- the factor
+    all-gathers, the tail all-reduces, the 3-float RankLoss statistics, the packed metric all-reduce -- are captured with it (RCCL
+    enqueues device kernels on its own stream, forked from and joined to the capture by events; checked with one rank and the
+    exchange forced: tests/workers/rccl_graph_worker.py); every rank must capture and replay in lock step.  Other backends stage
+    through the host and cannot be captured."""
 
     def __init__(self, args, model, reward_model, optimizer, critic_optim):
-        if _DataParallel().active:
-            raise NotImplementedError("GraphedPPOStep: single rank only (the data-parallel step interleaves RCCL collectives)")
+        dp = _DataParallel()
+        if dp.active and dp.backend != "nccl":
+            raise NotImplementedError("GraphedPPOStep: the data-parallel step can be captured with the RCCL ('nccl') backend only "
+                                      f"(backend {dp.backend!r} stages its collectives through the host)")
         for o in (optimizer, critic_optim):
             if not hasattr(o, "use_device_lr"):
                 raise TypeError("GraphedPPOStep needs lr2ppo_amd's AdamW (device-resident learning rates)")

@@ -20,3 +20,14 @@ def test_rccl_world1_forced_exchange_is_bit_identical_to_the_plain_step(dev):
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "RCCL_WORLD1_OK" in out.stdout, out.stdout[-3000:] + out.stderr[-4000:]
     assert out.stdout.count("RCCL_WORLD1_EXCHANGE_BITEQUAL") == 4
+
+
+def test_graphed_step_captures_its_rccl_collectives(dev):
+    """ppo.GraphedPPOStep under data parallelism (round 4): rollout + update WITH the factor all-gathers, tail all-reduces, the
+    RankLoss statistics and metric all-reduces captured in one HIP graph -- one RCCL rank, exchange forced, three steps (eager,
+    capture + replay, replay; the schedulers move) bit-identical to the eager data-parallel steps.  A fresh child with its own short
+    time limit: a capture that RCCL cannot serve must fail here, not hang the suite."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "workers", "rccl_graph_worker.py")], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL_GRAPH_BITEQUAL" in out.stdout, out.stdout[-3000:] + out.stderr[-4000:]
