@@ -273,6 +273,26 @@ def test_integration_md_config5_call_runs_as_written(dev):
         fx8.forward_train(frames_u8, token_ids, seg)
 
 
+def test_fp8_mode_on_the_default_towers_stays_near_the_split_bf16_features(dev):
+    """precision="mxfp8" is a mode of ANY tower pair: ViT-B/16 + RoBERTa-base (hidden 768: K = 768 products take the 4-byte scale
+    gathers, 197 / 196 tokens the 14-tile attention), two layers each, against the same extractor in split-bf16 -- finite, a few per
+    cent away, the pooled row from the pruned last layer."""
+    from lr2ppo_amd.finetune.features import TEXT_CONFIG, VIT_CONFIG, FeatureExtractor, encoder_args, synthetic_raw_batch
+    torch.manual_seed(5)
+    fx = FeatureExtractor(encoder_args(VIT_CONFIG, layers_num=2), encoder_args(TEXT_CONFIG, layers_num=2))
+    fx.init_normal()
+    fx = fx.to(dev).eval()
+    assert fx.visual_projection is None
+    frames, ids, seg, _ = synthetic_raw_batch(4, 2, device=dev, generator=torch.Generator(device=dev).manual_seed(6))
+    t0, i0 = fx.extract(frames, ids, seg)
+    fx.precision = "mxfp8"
+    t1, i1 = fx.extract(frames, ids, seg)
+    assert t1.shape == t0.shape and i1.shape == i0.shape and torch.isfinite(t1).all() and torch.isfinite(i1).all()
+    rt, ri = _rel(t1, t0), _rel(i1, i0)
+    print(f"\nViT-B/16 + RoBERTa-base, 2 layers each, mxfp8 vs split-bf16: text {rt:.3e}, image {ri:.3e}")
+    assert 1e-4 < rt < 0.15 and 1e-4 < ri < 0.15
+
+
 def _ndcg_at(scores, gold, k=3):
     from lr2ppo_amd import ops
     n, t = scores.shape
