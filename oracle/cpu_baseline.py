@@ -11,6 +11,7 @@ import time
 import torch
 
 from . import lr2ppo_oracle as O
+from .cpu_threads import fit_torch_threads
 
 
 def _adamw_inplace(params, grads, state, lr, names, beta1=0.9, beta2=0.999, eps=1e-6):
@@ -70,6 +71,7 @@ class PpoCpu:
 def time_ppo_steps(bs: int = 32, tags: int = 2, steps: int = 1, warmup_bs: int = 2, seed: int = 7):
     """-> dict: median seconds per PPO step at batch `bs` over `steps` measured steps, after one untimed warm-up step at
     batch `warmup_bs` (same code path, allocates the 2 x 1.045 B-element Adam state)."""
+    fit_torch_threads()                 # one thread per usable core (cgroup quota), reported as `threads`
     m = PpoCpu(tags, seed)
     m.step(warmup_bs)
     runs = [m.step(bs) for _ in range(max(1, steps))]
@@ -113,6 +115,7 @@ class FeaturesCpu:
 def time_feature_extraction(bs: int = 32, tags: int = 2, n_img: int = 16, seed: int = 7):
     """-> seconds of ONE dual-encoder forward at the PPO step's shapes (bs x n_img frames, bs x tags sequences) after a small
     untimed warm-up call."""
+    fit_torch_threads()
     fx = FeaturesCpu()
     g = torch.Generator().manual_seed(seed)
 

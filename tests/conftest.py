@@ -10,6 +10,12 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLD = os.path.join(REPO, "tests", "golden")
 
+# one torch thread per USABLE core (cgroup quota): the CPU oracle is the checker of most GPU tests, and an oversubscribed quota makes
+# it 2.2 x slower (oracle/cpu_threads.py)
+from oracle.cpu_threads import fit_torch_threads  # noqa: E402
+
+fit_torch_threads()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -368,10 +368,9 @@ def test_fp8_features_score_and_ndcg_drift_on_256_items(dev, monkeypatch):
 @pytest.mark.parametrize("stage, extra", [
     ("reward_pair_dataloader", ["--max_steps", "2", "--report_steps", "2", "--fp8_features"]),
     ("ppo", ["--max_cycles", "1", "--max_timesteps", "1", "--update_timesteps", "2", "--epochs_num", "2", "--fp8_features"]),
-    ("ppo", ["--max_cycles", "1", "--max_timesteps", "1", "--update_timesteps", "2", "--epochs_num", "2"]),
 ])
 def test_stage2_and_stage3_launchers_run_config5_from_raw_inputs(dev, tmp_path, stage, extra):
-    """`python -m lr2ppo_amd.finetune.{reward_pair_dataloader,ppo} --raw_inputs --image_tower vit_large_14_224 [--fp8_features]`:
+    """`python -m lr2ppo_amd.finetune.{reward_pair_dataloader,ppo} --raw_inputs --image_tower vit_large_14_224 --fp8_features`:
     the two launchers BASELINE configs[4] names, with the ViT-L/14 tower (1 layer here) + projection and RoBERTa (1 layer) frozen in
     front of the head, on synthetic raw items; training steps, validation and the checkpoint all happen."""
     import json

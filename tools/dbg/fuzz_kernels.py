@@ -6,6 +6,9 @@ import numpy as np
 import torch
 from lr2ppo_amd import ops
 from oracle import lr2ppo_oracle as O
+from oracle.cpu_threads import fit_torch_threads  # noqa: E402
+
+fit_torch_threads()          # one torch thread per usable core (cgroup quota): the fp64 references run on the host
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=150)

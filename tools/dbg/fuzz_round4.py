@@ -16,6 +16,9 @@ import torch  # noqa: E402
 
 from lr2ppo_amd import _native, ops  # noqa: E402
 from oracle import lr2ppo_oracle as O  # noqa: E402
+from oracle.cpu_threads import fit_torch_threads  # noqa: E402
+
+fit_torch_threads()          # one torch thread per usable core (cgroup quota): the fp64 references run on the host
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=40)
