@@ -21,3 +21,23 @@ def test_two_rank_update_keeps_replicas_identical(dev, fuse):
     # the exchanged gradient equals the mean of the two ranks' independently computed gradients (distinct data per rank),
     # also through the fused out_layer.fc1 update; RankLoss statistics are global
     assert "DP_GRADIENT_IS_RANK_MEAN_OK" in out.stdout and "GLOBAL_RANK_LOSS_OK" in out.stdout, out.stdout[-2000:]
+
+
+def test_bench_gpus_2_starts_two_ranks_and_reports_them(dev):
+    """`python bench.py --gpus 2` with no launcher in the environment (the driver's scaling command): the parent starts two ranks
+    through torch.distributed.run, both run the head-only and the composed (`value`) loops with the data-parallel exchange active,
+    and the relayed line reports n_gpus = 2 and two ranks seen by the all-reduce probe.  Two ranks share this box's one GPU, so the
+    backend is gloo (LR2_BENCH_BACKEND: RCCL refuses two ranks on one device); one-stream schedule, as world > 1 defaults to."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(LR2_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extras",
+                        "--no-cpu-baseline", "--no-graph", "--no-profile"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["backend"] == "gloo" and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and d["head_only_steps_per_sec"] > 0
