@@ -408,6 +408,10 @@ def main():
         out["roofline"]["top_ms_per_step_note"] = ("GEMM / attention / LayerNorm / AdamW signatures of one instrumented warm-up step "
                                                    "of the value loop, one stream (exclusive durations)")
         pm = _pmc(key)
+        if pm and "hbm_bytes" in pm:
+            out["roofline"]["traffic"] = pm["hbm_bytes"]
+            out["roofline"]["traffic_unit"] = "HBM bytes/launch (2*FETCH_SIZE + WRITE_SIZE, separate PMC passes over the encoder forward, profiles/pmc_traffic.json)"
+            out["roofline"]["algorithmic_bytes"] = int(rec["bytes"])
         if pm and "mfma_busy" in pm:
             out["roofline"]["mfma_busy_pmc"] = pm["mfma_busy"]
             out["roofline"]["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) for this signature, profiles/pmc_traffic.json"

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
   const int wr = wave >> 2, wc = wave & 3;
 
   int tm, tn;
-  tile_coords(g.tiles_m, g.tiles_n, blockIdx.x, tm, tn);
+  tile_coords(g.tiles_m, g.tiles_n, blockIdx.x, tm, tn, g.strip_n > 0 ? g.strip_n : 8);
   const int m0 = tm * BM, n0 = tn * BN;
 
   Ctx c;
@@ -533,6 +533,8 @@ int launch_gemm256_nt(const GemmParams& p_in, hipStream_t stream) {
     if (lr2_allow_dynamic_lds(gemm256_nt_kernel<1>, LDS_BYTES, "gemm256")) return LR2_ERR_LAUNCH;
     attr_set = true;
   }
+  const char* se = getenv("LR2_GEMM_STRIP");          // read per call: strip width of the tile order (A/B inside one process)
+  p.strip_n = se ? atoi(se) : 0;
   const char* ve = getenv("LR2_GEMM256_VARIANT");     // read per call: tools A/B the variants inside one process
   const int variant = ve ? atoi(ve) : 0;
   if (variant == 1) LR2_LAUNCH(gemm256_nt_kernel<1>, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS_BYTES, stream, p);

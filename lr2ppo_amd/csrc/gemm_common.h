@@ -24,6 +24,7 @@ struct GemmParams {
   int dma_stages;               // LDS images per planes operand: 2 = double buffered (1 workgroup/CU at BM=128), 1 = single
   int waves8;                   // planes x planes, 128 x 128 tiles: 8-wave workgroups (wave tile 64 x 32)
   int ablate;                   // diagnostics only (LR2_GEMM_ABLATE): 2 no global loads, 4 no LDS fill
+  int strip_n;                  // tiles per strip along N of the XCD-aware tile order (0 = 8; LR2_GEMM_STRIP: an A/B switch of the 256 x 256 NT kernel)
   Epilogue epi;
 };
 
@@ -45,9 +46,9 @@ __device__ __forceinline__ int xcd_chunk_index(int T, int bid) {
   const int q = T >> 3, r = T & 7, xcd = bid & 7, local = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
 }
-__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int bid, int& tm, int& tn) {
+__device__ __forceinline__ void tile_coords(int tiles_m, int tiles_n, int bid, int& tm, int& tn, int strip = 8) {
   const int i = xcd_chunk_index(tiles_m * tiles_n, bid);
-  const int SN = tiles_n < 8 ? tiles_n : 8;
+  const int SN = tiles_n < strip ? tiles_n : strip;
   const int full = (tiles_n / SN) * tiles_m * SN;  // tiles inside full-width strips
   if (i < full) {
     const int strip = i / (tiles_m * SN), rem = i % (tiles_m * SN);

@@ -46,6 +46,17 @@ if os.path.exists(_mf):
         rec["mfma_busy"] = round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 1024.0), 4)
         rec["effective_clock_ghz"] = round(gui / (r["total_ms"] * 1e-3) / 1e9, 3)
         rec["pmc_launches"] = r["launches"]
+# HBM bytes of the value loop's GEMM signatures: FETCH_SIZE / WRITE_SIZE passes over the dual-encoder forward (same correction)
+_ef, _ew = os.path.join(d, f"{tag}_encoder_pmc_fetch.json"), os.path.join(d, f"{tag}_encoder_pmc_write.json")
+if os.path.exists(_ef) and os.path.exists(_ew):
+    EW = {key(r): r for r in json.load(open(_ew))}
+    for r in json.load(open(_ef)):
+        if not r.get("bench_signature") or key(r) not in EW:
+            continue
+        fetch = r["counters_per_launch"].get("FETCH_SIZE", 0.0) * 1024
+        write = EW[key(r)]["counters_per_launch"].get("WRITE_SIZE", 0.0) * 1024
+        rec = by_label.setdefault(r["bench_signature"], {})
+        rec.update(read_bytes=int(2 * fetch), write_bytes=int(write), hbm_bytes=int(2 * fetch + write), traffic_launches=r["launches"])
 print(json.dumps({
     "_method": "tools/profile_round.sh " + tag + ": rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) on "
                "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-online --no-profile` (head-only PPO steps), summarised per dispatch signature by "
@@ -53,5 +64,7 @@ print(json.dumps({
                "is.  kernel_trace_* come from the `--serial-streams` kernel-trace pass of the SAME gpurun call (same box, 13 PPO steps on one "
                "HIP stream: exclusive per-launch durations).  mfma_busy / effective_clock_ghz: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 "
                "x 1024 SIMDs) and (GRBM_GUI_ACTIVE / 8) / kernel time from the encoder PMC pass of the same call "
-               "(`tools/encoder_bench.py --ppo-shapes --iters 1` under --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES).",
+               "(`tools/encoder_bench.py --ppo-shapes --iters 1` under --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES); "
+               "read_bytes / write_bytes / hbm_bytes of the encoder's GEMM signatures: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over the "
+               "same encoder command.",
     "by_bench_label": by_label, "by_dispatch_signature": by_sig}, indent=1))

@@ -44,6 +44,13 @@ echo "== encoder forward: MFMA counters"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $O/enc_pmc -- python3 $R/tools/encoder_bench.py --ppo-shapes --iters 1 > /dev/null 2> $O/enc_pmc.err || exit 1
 $S pmc $O/enc_pmc --title "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python3 tools/encoder_bench.py --ppo-shapes --iters 1 ($TAG)" --md $O/${TAG}_encoder_pmc_mfma.md --json $O/${TAG}_encoder_pmc_mfma.json || exit 1
 rm -rf $O/enc_pmc
+echo "== encoder forward: FETCH_SIZE / WRITE_SIZE passes (HBM bytes per launch of the value loop's GEMM signatures: roofline.traffic)"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/enc_fetch -- python3 $R/tools/encoder_bench.py --ppo-shapes --iters 1 > /dev/null 2> $O/enc_fetch.err || exit 1
+$S pmc $O/enc_fetch --title "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 tools/encoder_bench.py --ppo-shapes --iters 1 ($TAG)" --md $O/${TAG}_encoder_pmc_fetch.md --json $O/${TAG}_encoder_pmc_fetch.json || exit 1
+rm -rf $O/enc_fetch
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/enc_write -- python3 $R/tools/encoder_bench.py --ppo-shapes --iters 1 > /dev/null 2> $O/enc_write.err || exit 1
+$S pmc $O/enc_write --title "rocprofv3 --kernel-trace --pmc WRITE_SIZE -- python3 tools/encoder_bench.py --ppo-shapes --iters 1 ($TAG)" --md $O/${TAG}_encoder_pmc_write.md --json $O/${TAG}_encoder_pmc_write.json || exit 1
+rm -rf $O/enc_write
 ls -la $O
 echo "== encoder forward + backward: kernel trace"
 bash $R/tools/prof_enc_train.sh $TAG > $O/enc_train.log 2>&1 || exit 1
