@@ -13,11 +13,16 @@
 // contraction index permuted (slot (g, j) <-> key 4g + j for j < 4, 16 + 4g + j - 4 otherwise); the V fragments are read
 // with the same permutation by two ds_read_b64_tr_b16 (rows 4g .. 4g+3 and 16 + 4g .. 16 + 4g + 3 of the key block).
 // P never touches LDS and no shuffle is needed between the two GEMMs.
+#include <stdlib.h>
+
 #include "common.h"
 #include "lr2ppo_hip.h"
 
 namespace {
 
+#ifndef LR2_SA_ABLATE
+#define LR2_SA_ABLATE 0         // diagnostics (tools/dbg/attn_ablate.py builds variants of this file): bit 1 no K / V global loads, 2 no
+#endif                          // sub-tile work, 4 no softmax arithmetic, 8 no lo split of P, 16 no P V product, 32 no S product, 64 no store
 constexpr int HD = 64;          // head dim
 constexpr int ROW_B = HD * 2;   // bytes of one K / V row in one LDS plane
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
@@ -65,27 +70,49 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* plane, int row_a, int ro
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-// One 16-query sub-tile against the K / V planes resident in LDS: S^T = K Q^T (MFMA), fp32 softmax in the log2 domain,
-// O = P V (MFMA), rows stored through the wave's LDS slab.  qh / ql: the sub-tile's query fragments.
-template <int NT>
-__device__ __forceinline__ void attn_subtile_fwd(const char* sK, const char* sV, const float* sMask, float* slab,
-                                                 const bf16x8_t (&qh)[2], const bf16x8_t (&ql)[2], int sub, int lane, int L, int b,
-                                                 int h, int heads, size_t row0, int col0, float scale, float* __restrict__ lse,
-                                                 const DropP& dr, float* __restrict__ O, bf16_t* __restrict__ Oh, size_t o_lo_off,
-                                                 int ld_o) {
+// LDS fragment addresses as (per-lane base register) + (compile-time offset): the XOR swizzles above depend on the row only through
+// bits that the tile index does not touch, so ONE base per (k-step) for K and one per head-column group for V serve every tile; the
+// bases are made opaque to the optimiser (else it re-derives one address per read -- 70 live registers where 6 do).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+  asm volatile("" : "+v"(a));
+  return a;
+}
+__device__ __forceinline__ bf16x8_t lds_ld16(uint32_t a) {
+  return *(__attribute__((address_space(3))) const bf16x8_t*)(uintptr_t)a;
+}
+__device__ __forceinline__ bf16x8_t lds_tr_pair(uint32_t a, uint32_t b) {
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)a);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)b);
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// One 16-query sub-tile against the K / V planes resident in LDS, in two phases that touch different planes:
+//   phase A (K, mask):  S^T = K Q^T (MFMA), fp32 softmax in the log2 domain -> the un-normalised probabilities as bf16 hi / lo
+//                       fragments of the P V product + 1 / sum;
+//   phase B (V):        O = (P~ V) / sum (MFMA), rows stored through the wave's LDS slab.
+// qh / ql: the sub-tile's query fragments.
+template <int NT, bool DROP = true>
+__device__ __forceinline__ void attn_phase_a(const char* sK, const float* sMask, const bf16x8_t (&qh)[2], const bf16x8_t (&ql)[2],
+                                             int sub, int lane, int L, int b, int h, int heads, float scale, float* __restrict__ lse,
+                                             const DropP& dr, bf16x8_t (&ph)[NT / 2], bf16x8_t (&pl)[NT / 2], float& inv) {
   constexpr int PLANE = 16 * NT * ROW_B;
   const int qn = lane & 15, g = lane >> 4;
   const int q_row = sub * 16 + qn;
   // ---- S^T tiles: acc[t][r] = S[query qn][key 16t + 4g + r] ----
+  const uint32_t kb[2] = {lds_addr(sK + k_off(qn, g)), lds_addr(sK + k_off(qn, g + 4))};
   f32x4_t s[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (LR2_SA_ABLATE & 32) acc = f32x4_t{__builtin_bit_cast(float, (int)qh[0][0]), 0.f, (float)t, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int r = 16 * t + qn;          // A fragment: key row 16t + (l & 15), hd 8g + 32ks ..
-      const bf16x8_t kh = *reinterpret_cast<const bf16x8_t*>(sK + k_off(r, g + 4 * ks));
-      const bf16x8_t kl = *reinterpret_cast<const bf16x8_t*>(sK + PLANE + k_off(r, g + 4 * ks));
+    for (int ks = 0; ks < ((LR2_SA_ABLATE & 32) ? 0 : 2); ++ks) {
+      // A fragment: key row 16t + (l & 15), hd 8g + 32ks ..: k_off(16t + qn, g + 4ks) = 2048 t + k_off(qn, g + 4ks)
+      const bf16x8_t kh = lds_ld16(kb[ks] + 2048 * t);
+      const bf16x8_t kl = lds_ld16(kb[ks] + 2048 * t + PLANE);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], acc, 0, 0, 0);
@@ -108,6 +135,7 @@ __device__ __forceinline__ void attn_subtile_fwd(const char* sK, const char* sV,
   mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
   float sum = 0.f;
+  if (!(LR2_SA_ABLATE & 4)) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -118,16 +146,13 @@ __device__ __forceinline__ void attn_subtile_fwd(const char* sK, const char* sV,
   }
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
-  const float inv = 1.0f / sum;
+  } else sum = 1.0f + mx * 1e-30f;
+  inv = 1.0f / sum;
   if (lse && g == 0 && q_row < L) lse[((size_t)b * heads + h) * L + q_row] = mx * LN2 + logf(sum);
   const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_row < L ? q_row : 0)) * mask_pitch(L);
 
-  // ---- O = (P~ V) / sum over 32-key blocks, P~ = the un-normalised exponentials in (0, 1]: fragments straight from the
-  // accumulators (permuted contraction index); the 1 / sum goes onto the 16 output values instead of the NT * 4 probabilities
-  f32x4_t o[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+  // ---- P~ = the un-normalised exponentials in (0, 1], as the A fragments of P V: straight from the accumulators (permuted
+  // contraction index: slot (g, j) <-> key 4g + j for j < 4, 16 + 4g + j - 4 otherwise, of each 32-key block) ----
 #pragma unroll
   for (int u = 0; u < NT / 2; ++u) {
     float p[8];
@@ -136,7 +161,7 @@ __device__ __forceinline__ void attn_subtile_fwd(const char* sK, const char* sV,
       p[r] = s[2 * u][r];
       p[4 + r] = s[2 * u + 1][r];
     }
-    if (dr.thr) {
+    if (DROP && dr.thr) {
       drop_mul4(dr, drow + 32 * u + 4 * g, p[0], p[1], p[2], p[3]);
       drop_mul4(dr, drow + 32 * u + 16 + 4 * g, p[4], p[5], p[6], p[7]);
     }
@@ -146,21 +171,90 @@ __device__ __forceinline__ void attn_subtile_fwd(const char* sK, const char* sV,
     const uint32_t l23 = cvt_pk_bf16(p[2] - __uint_as_float(h23 << 16), p[3] - __uint_as_float(h23 & 0xffff0000u));
     const uint32_t l45 = cvt_pk_bf16(p[4] - __uint_as_float(h45 << 16), p[5] - __uint_as_float(h45 & 0xffff0000u));
     const uint32_t l67 = cvt_pk_bf16(p[6] - __uint_as_float(h67 << 16), p[7] - __uint_as_float(h67 & 0xffff0000u));
-    const bf16x8_t ph = __builtin_bit_cast(bf16x8_t, (u32x4_t{h01, h23, h45, h67}));
-    const bf16x8_t pl = __builtin_bit_cast(bf16x8_t, (u32x4_t{l01, l23, l45, l67}));
-    // transposed V reads: lane (tq, tp) of a 16-lane group supplies row base + tq, hd 16n + 4tp .. +3
-    const int ra = 32 * u + 4 * g + tq, rb = ra + 16;
+    ph[u] = __builtin_bit_cast(bf16x8_t, (u32x4_t{h01, h23, h45, h67}));
+    pl[u] = (LR2_SA_ABLATE & 8) ? ph[u] : __builtin_bit_cast(bf16x8_t, (u32x4_t{l01, l23, l45, l67}));
+  }
+}
+
+// HALF_SLAB: the wave's LDS slab holds 16 rows x 32 columns (the 16-wave persistent kernel: 13-14 slabs beside the K / V planes);
+// the output then leaves in two halves of 32 head columns.  Same values either way.
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// after_pv(): called between the last P V product and the output's way through the slab (the persistent kernel requests the next
+// pair's query fragments there: the probability registers are dead by then).
+template <int NT, bool HALF_SLAB = false, typename Hook = NoHook>
+__device__ __forceinline__ void attn_phase_b(const char* sV, float* slab, const bf16x8_t (&ph)[NT / 2], const bf16x8_t (&pl)[NT / 2],
+                                             float inv, int sub, int lane, int L, size_t row0, int col0, float* __restrict__ O,
+                                             bf16_t* __restrict__ Oh, size_t o_lo_off, int ld_o, Hook after_pv = Hook()) {
+  constexpr int PLANE = 16 * NT * ROW_B;
+  const int qn = lane & 15, g = lane >> 4;
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+  // transposed V reads: lane (tq, tp) of a 16-lane group supplies row 32u + 4g + tq (and that row + 16), hd 16n + 4tp .. +3:
+  // v_off(32u + 4g + tq (+ 16), unit) = 4096 u (+ 2048) + v_off(4g + tq, unit)
+  uint32_t vb[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) vb[n] = lds_addr(sV + v_off(4 * g + tq, 2 * n + (tp >> 1)) + 8 * (tp & 1));
+  if constexpr (HALF_SLAB) {
+    // 32 head columns at a time: 8 accumulator registers + the V fragments of two column groups beside the probabilities (a
+    // 128-register wave); each half leaves through the 16 x 32 slab as soon as it is complete
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      f32x4_t o[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int u = 0; u < NT / 2; ++u) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const uint32_t a = vb[2 * half + n] + 4096 * u;
+          const bf16x8_t vh = lds_tr_pair(a, a + 2048);
+          const bf16x8_t vl = lds_tr_pair(a + PLANE, a + 2048 + PLANE);
+          o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[u], vh, o[n], 0, 0, 0);
+          o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[u], vl, o[n], 0, 0, 0);
+          o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[u], vh, o[n], 0, 0, 0);
+        }
+      }
+      if (half == 1) after_pv();
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(4 * g + r) * (32 + 4) + 16 * n + qn] = o[n][r] * __shfl(inv, 4 * g + r, 64);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int r = pass * 8 + (lane >> 3), c = (lane & 7) * 4;
+        const int qr = sub * 16 + r;
+        if (qr < L) {
+          const float4 v = *reinterpret_cast<const float4*>(slab + r * (32 + 4) + c);
+          const size_t off = (row0 + qr) * (size_t)ld_o + col0 + 32 * half + c;
+          if (O) *reinterpret_cast<float4*>(O + off) = v;
+          if (Oh) store_planes4(Oh + off, o_lo_off, v);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+  // ---- O = (P~ V) / sum over 32-key blocks; the 1 / sum goes onto the 16 output values instead of the NT * 4 probabilities
+  f32x4_t o[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < NT / 2; ++u) {
+    if (LR2_SA_ABLATE & 16) {
+      o[u & 3][0] += __builtin_bit_cast(float, (int)ph[u][0]) + __builtin_bit_cast(float, (int)pl[u][1]);
+      continue;
+    }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-      const int unit = 2 * n + (tp >> 1), half8 = 8 * (tp & 1);
-      const bf16x8_t vh = tr_pair(sV, ra, rb, unit, half8);
-      const bf16x8_t vl = tr_pair(sV + PLANE, ra, rb, unit, half8);
-      o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl, vh, o[n], 0, 0, 0);
-      o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vl, o[n], 0, 0, 0);
-      o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph, vh, o[n], 0, 0, 0);
+      const bf16x8_t vh = lds_tr_pair(vb[n] + 4096 * u, vb[n] + 4096 * u + 2048);
+      const bf16x8_t vl = lds_tr_pair(vb[n] + 4096 * u + PLANE, vb[n] + 4096 * u + 2048 + PLANE);
+      o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[u], vh, o[n], 0, 0, 0);
+      o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[u], vl, o[n], 0, 0, 0);
+      o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[u], vh, o[n], 0, 0, 0);
     }
   }
 
+  after_pv();
   // ---- o[n][r] = O[query 4g + r][hd 16n + (l & 15)] -> LDS slab -> 16-B row-contiguous stores ----
   float inv_q[4];                         // 1 / sum of query 4g + r (lane 4g + r holds it: its own query is l & 15)
 #pragma unroll
@@ -174,7 +268,7 @@ __device__ __forceinline__ void attn_subtile_fwd(const char* sK, const char* sV,
   for (int pass = 0; pass < 4; ++pass) {
     const int r = pass * 4 + (lane >> 4), c = (lane & 15) * 4;
     const int qr = sub * 16 + r;
-    if (qr < L) {
+    if (qr < L && (!(LR2_SA_ABLATE & 64) || slab[r] == 12345.f)) {
       const float4 v = *reinterpret_cast<const float4*>(slab + r * (HD + 4) + c);
       const size_t off = (row0 + qr) * (size_t)ld_o + col0 + c;
       if (O) *reinterpret_cast<float4*>(O + off) = v;
@@ -182,6 +276,18 @@ __device__ __forceinline__ void attn_subtile_fwd(const char* sK, const char* sV,
     }
   }
   __builtin_amdgcn_wave_barrier();
+}
+
+template <int NT>
+__device__ __forceinline__ void attn_subtile_fwd(const char* sK, const char* sV, const float* sMask, float* slab,
+                                                 const bf16x8_t (&qh)[2], const bf16x8_t (&ql)[2], int sub, int lane, int L, int b,
+                                                 int h, int heads, size_t row0, int col0, float scale, float* __restrict__ lse,
+                                                 const DropP& dr, float* __restrict__ O, bf16_t* __restrict__ Oh, size_t o_lo_off,
+                                                 int ld_o) {
+  bf16x8_t ph[NT / 2], pl[NT / 2];
+  float inv;
+  attn_phase_a<NT>(sK, sMask, qh, ql, sub, lane, L, b, h, heads, scale, lse, dr, ph, pl, inv);
+  attn_phase_b<NT>(sV, slab, ph, pl, inv, sub, lane, L, row0, col0, O, Oh, o_lo_off, ld_o);
 }
 
 template <int NT, int NW>   // NT = key tiles of 16 (even), LP = 16 * NT padded keys; NW = waves per workgroup
@@ -237,7 +343,7 @@ __global__ __launch_bounds__(64 * NW) void self_attn_mfma_kernel(const bf16_t* _
       const int r = i >> 3, u = i & 7;
       kh[it] = u32x4_t{0, 0, 0, 0};
       kl[it] = kh[it]; vh[it] = kh[it]; vl[it] = kh[it];
-      if (i < LP * 8 && r < L) {
+      if (i < LP * 8 && r < L && !(LR2_SA_ABLATE & 1)) {
         const size_t o = (row0 + r) * (size_t)ld + col0 + u * 8;
         kh[it] = *reinterpret_cast<const u32x4_t*>(Kh + o);
         kl[it] = *reinterpret_cast<const u32x4_t*>(Kh + o + lo_off);
@@ -263,7 +369,7 @@ __global__ __launch_bounds__(64 * NW) void self_attn_mfma_kernel(const bf16_t* _
 
   __syncthreads();
   // K / V stay resident; each wave walks over 16-query sub-tiles (blockIdx.x strides them when the grid splits the queries)
-  for (int sub = sub_first; sub < n_sub; sub += sub_step) {
+  for (int sub = sub_first; sub < ((LR2_SA_ABLATE & 2) ? 0 : n_sub); sub += sub_step) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) { qh[ks] = qh_next[ks]; ql[ks] = ql_next[ks]; }
   load_q(sub + sub_step, qh_next, ql_next);     // next sub-tile's queries travel while this one is computed
@@ -271,6 +377,179 @@ __global__ __launch_bounds__(64 * NW) void self_attn_mfma_kernel(const bf16_t* _
   attn_subtile_fwd<NT>(sK, sV, sMask, sOut + wave * 16 * (HD + 4), qh, ql, sub, lane, L, b, h, heads, row0, col0, scale, lse, dr,
                        O, Oh, o_lo_off, ld_o);
   }  // sub-tile loop
+}
+
+// ---- persistent forward: one workgroup per CU walks over (sequence, head) pairs, K / V travel by LDS-DMA under the compute ----
+// The one-pair kernel above spends a quarter of its time waiting for its K / V planes (112 KiB per workgroup, one workgroup per CU:
+// nothing else runs meanwhile), every workgroup pays its launch and the drain of its last stores, and its phases (staging, S,
+// softmax, P V, stores) barely overlap: two waves per SIMD in the same phase (tools/dbg/attn_ablate.py).  Here
+//   * a workgroup is 16 waves at <= 128 VGPRs: wave w < n_sub owns the 16-query sub-tile w of every pair (n_sub <= 14: L <= 224), waves
+//     14 and 15 only move data -- three to four waves per SIMD in different places instead of two in the same one;
+//   * a pair is two phases that touch different planes -- A: S = Q K^T + softmax (K, mask), the probabilities kept as bf16 fragments in
+//     registers; B: O = P V (V) -- so that during phase A of pair i the V planes of pair i are loaded (V is free since the end of pair
+//     i - 1) and during phase B of pair i the K planes, the key mask and the query fragments of pair i + 1 (K is free after phase A);
+//   * the two mover waves issue every LDS-DMA piece and are the only ones that wait for memory (s_waitcnt vmcnt(0) before the phase
+//     barrier); the compute waves' stores stay in flight across pairs.
+// Two barriers per pair: after A (every K read retired -> K free; V landed) and after B (every V read retired; K, mask landed).
+// Same arithmetic, same bits as self_attn_mfma_kernel (both call attn_phase_a / attn_phase_b).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sa_rsrc(const void* p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  void* q = (void*)(((uint64_t)hi << 32) | (uint64_t)lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+// Rows 8j .. 8j + 7 (j = j0, j0 + jstep, ...) of one head's K or V, both planes, into the LDS image: LDS-DMA writes lane-linearly
+// (lane l -> byte 16 l of the 1-KiB piece = row l >> 3, slot l & 7), so the swizzle of k_off / v_off is applied to the SOURCE unit;
+// rows >= L are out-of-range requests (the descriptor's range check writes zeros).
+template <int NT, bool IS_V>
+__device__ __forceinline__ void dma_head_rows(const __amdgpu_buffer_rsrc_t& hi, const __amdgpu_buffer_rsrc_t& lo, char* dst, int lane,
+                                              int j0, int jstep, uint32_t pair_off, uint32_t row_bytes, int L) {
+  constexpr int LP = 16 * NT, PLANE = LP * ROW_B;
+  const int rl = lane >> 3, sl = lane & 7;
+  for (int j = j0; j < LP / 8; j += jstep) {
+    const int r = 8 * j + rl;
+    const int u = IS_V ? (sl ^ (((r >> 1) & 3) << 1)) : (sl ^ ((r >> 1) & 7));
+    const uint32_t v = r < L ? pair_off + (uint32_t)r * row_bytes + (uint32_t)u * 16u : 0xFFFFFF00u;
+    char* d = dst + j * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(hi, LDS_PTR(d), 16, v, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(lo, LDS_PTR(d + PLANE), 16, v, 0, 0, 0);
+  }
+}
+
+// every LDS access of this wave retired, then meet the workgroup (no vmcnt wait: stores and DMA stay in flight)
+__device__ __forceinline__ void phase_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+constexpr int PS_WAVES = 16, PS_MOVERS = 2, PS_MAX_SUB = PS_WAVES - PS_MOVERS;
+
+template <int NT, bool DROP>
+__global__ __launch_bounds__(64 * PS_WAVES) void self_attn_persist_kernel(const bf16_t* __restrict__ Qh, const bf16_t* __restrict__ Kh,
+                                                                          const bf16_t* __restrict__ Vh, size_t lo_off, int ld,
+                                                                          const int64_t* __restrict__ seg, float* __restrict__ O,
+                                                                          bf16_t* __restrict__ Oh, size_t o_lo_off, int ld_o, int heads,
+                                                                          int L, float scale, float* __restrict__ lse, DropP dr,
+                                                                          int n_pairs, uint32_t kv_bytes) {
+  constexpr int LP = 16 * NT;
+  constexpr int PLANE = LP * ROW_B;
+  constexpr int MK = (LP + 64 * PS_MOVERS - 1) / (64 * PS_MOVERS);     // mask values per mover thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;                    // [hi | lo]
+  char* sV = smem + 2 * PLANE;        // [hi | lo]
+  float* sMask = reinterpret_cast<float*>(smem + 4 * PLANE);          // [2][LP]: pair number it reads half it & 1
+  float* sOut = sMask + 2 * LP;                                      // [PS_MAX_SUB waves][16][32 + 4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool mover = wave >= PS_MAX_SUB;
+  const int mtid = tid - 64 * PS_MAX_SUB;                             // thread number among the movers
+  const int qn = lane & 15, g = lane >> 4;
+  const int n_sub = (L + 15) >> 4;
+  const bool computes = wave < n_sub;
+  float* slab = sOut + (mover ? 0 : wave) * 16 * (32 + 4);
+  const uint32_t row_bytes = (uint32_t)ld * 2u;
+
+  int p = blockIdx.x;
+  if (p >= n_pairs) return;
+  int b = p / heads, h = p - b * heads;
+  size_t row0 = (size_t)b * L;
+  int col0 = h * HD;
+
+  if (mover) {
+    // ---- the two mover waves ----
+    const __amdgpu_buffer_rsrc_t k_hi = sa_rsrc(Kh, kv_bytes), k_lo = sa_rsrc(Kh + lo_off, kv_bytes);
+    const __amdgpu_buffer_rsrc_t v_hi = sa_rsrc(Vh, kv_bytes), v_lo = sa_rsrc(Vh + lo_off, kv_bytes);
+    const int j0 = wave - PS_MAX_SUB;
+    dma_head_rows<NT, false>(k_hi, k_lo, sK, lane, j0, PS_MOVERS, (uint32_t)((row0 * ld + col0) * 2), row_bytes, L);
+    // additive key mask, pre-multiplied by log2(e) (see self_attn_mfma_kernel)
+    for (int j = mtid; j < LP; j += 64 * PS_MOVERS) sMask[j] = j < L ? ((seg[row0 + j] > 0) ? 0.f : -10000.0f * LOG2E) : -INFINITY;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    phase_barrier();
+    for (int it = 0;; ++it) {
+      // phase A of pair p: its V planes travel
+      dma_head_rows<NT, true>(v_hi, v_lo, sV, lane, j0, PS_MOVERS, (uint32_t)((row0 * ld + col0) * 2), row_bytes, L);
+      const int pn = p + gridDim.x;
+      const bool more = pn < n_pairs;
+      const int bn = pn / heads, hn = pn - bn * heads;
+      const size_t row0n = (size_t)bn * L;
+      float mk[MK];
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < MK; ++i) {
+          const int j = mtid + i * 64 * PS_MOVERS;
+          mk[i] = j < L ? ((seg[row0n + j] > 0) ? 0.f : -10000.0f * LOG2E) : -INFINITY;
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // V of this pair has landed
+      phase_barrier();
+      if (!more) break;
+      // phase B of pair p: K and the mask of the next pair travel
+      dma_head_rows<NT, false>(k_hi, k_lo, sK, lane, j0, PS_MOVERS, (uint32_t)((row0n * ld + hn * HD) * 2), row_bytes, L);
+      float* mnext = sMask + ((it + 1) & 1) * LP;
+#pragma unroll
+      for (int i = 0; i < MK; ++i) {
+        const int j = mtid + i * 64 * PS_MOVERS;
+        if (j < LP) mnext[j] = mk[i];
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // K of the next pair has landed
+      phase_barrier();
+      p = pn; row0 = row0n; col0 = hn * HD;
+    }
+    return;
+  }
+
+  if (!computes) {
+    // ---- waves n_sub .. 13: nothing to compute, they only keep the barriers company ----
+    phase_barrier();
+    for (;;) {
+      phase_barrier();
+      p += gridDim.x;
+      if (p >= n_pairs) break;
+      phase_barrier();
+    }
+    return;
+  }
+
+  // ---- compute waves ----
+  const int sub = wave;
+  // query fragments of this wave's sub-tile of the pair whose first row is row0_ (B operand of S^T = K Q^T)
+  auto load_q = [&](size_t row0_, int col0_, bf16x8_t (&fh)[2], bf16x8_t (&fl)[2]) {
+    const int q_row_ = sub * 16 + qn;
+    const bool ok = q_row_ < L;
+    const size_t o = (row0_ + (ok ? q_row_ : 0)) * (size_t)ld + col0_ + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4_t a = {0, 0, 0, 0}, c = a;
+      if (ok) {
+        a = *reinterpret_cast<const u32x4_t*>(Qh + o + 32 * ks);
+        c = *reinterpret_cast<const u32x4_t*>(Qh + o + 32 * ks + lo_off);
+      }
+      fh[ks] = __builtin_bit_cast(bf16x8_t, a);
+      fl[ks] = __builtin_bit_cast(bf16x8_t, c);
+    }
+  };
+  bf16x8_t qh[2], ql[2];
+  load_q(row0, col0, qh, ql);
+  phase_barrier();
+  for (int it = 0;; ++it) {
+    const float* mask = sMask + (it & 1) * LP;
+    bf16x8_t ph[NT / 2], pl[NT / 2];
+    float inv = 0.f;
+    attn_phase_a<NT, DROP>(sK, mask, qh, ql, sub, lane, L, b, h, heads, scale, lse, dr, ph, pl, inv);
+    phase_barrier();
+    const int pn = p + gridDim.x;
+    const bool more = pn < n_pairs;
+    const int bn = pn / heads, hn = pn - bn * heads;
+    const size_t row0n = (size_t)bn * L;
+    // the next pair's queries are requested once the probability registers are dead; they travel under the output's stores and the
+    // wait at the barrier
+    auto next_q = [&]() { if (more) load_q(row0n, hn * HD, qh, ql); };
+    attn_phase_b<NT, true>(sV, slab, ph, pl, inv, sub, lane, L, row0, col0, O, Oh, o_lo_off, ld_o, next_q);
+    if (!more) break;
+    phase_barrier();
+    p = pn; b = bn; h = hn; row0 = row0n; col0 = hn * HD;
+  }
 }
 
 // ---- forward for sequences longer than one LDS-resident key block (L > 256: ViT-L/14's 257 tokens, RoBERTa's 514) ----
@@ -1099,10 +1378,42 @@ struct AttnArgs {
 
 // Forward: 8 waves per workgroup (2 per SIMD) hide the LDS-read latency of the dependent tile chains; the 256-key
 // variant keeps 4 (its K/V planes + 8 output slabs would not fit the 160 KiB of LDS).
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+  }
+  return n;
+}
+
+// The persistent form: at least one pair per CU, every operand offset a 32-bit byte count (LR2_ATTN_PERSIST=0: an A/B switch, read
+// once per process).
+template <int NT>
+int launch_fwd_persist(const AttnArgs& a, float* o, bf16_t* oh, size_t o_lo_off, int ld_o, float* lse, uint32_t kv_bytes) {
+  constexpr int LP = 16 * NT;
+  const size_t lds = (size_t)4 * LP * ROW_B + (size_t)2 * LP * 4 + (size_t)PS_MAX_SUB * 16 * (32 + 4) * 4;
+  static bool done = false;
+  if (allow_lds_once(self_attn_persist_kernel<NT, false>, lds, done, "self_attn_fwd(persistent)")) return LR2_ERR_LAUNCH;
+  const int n_pairs = a.batch * a.heads;
+  const int grid = n_pairs < cu_count() ? n_pairs : cu_count();
+  LR2_LAUNCH((self_attn_persist_kernel<NT, false>), dim3(grid), dim3(64 * PS_WAVES), lds, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, a.seg, o, oh,
+             o_lo_off, ld_o, a.heads, a.L, a.scale, lse, a.dr, n_pairs, kv_bytes);
+  return lr2_launch_status("lr2_self_attn_fwd(persistent)");
+}
+
 template <int NT>
 int launch_fwd(const AttnArgs& a, float* o, bf16_t* oh, size_t o_lo_off, int ld_o, float* lse) {
   constexpr int LP = 16 * NT;
   constexpr int NW = NT <= 14 ? 8 : 4;
+  if constexpr (NT <= 14) {
+    static const bool persist_on = !(getenv("LR2_ATTN_PERSIST") && atoi(getenv("LR2_ATTN_PERSIST")) == 0);
+    // bytes a K / V descriptor spans from its first element: the last row's head columns end (rows - 1) * ld + heads * 64 elements on
+    const uint64_t span = ((uint64_t)a.batch * a.L - 1) * (uint64_t)a.ld * 2u + (uint64_t)a.heads * HD * 2u;
+    if (persist_on && a.dr.thr == 0 && a.batch * a.heads >= cu_count() && (a.L + 15) / 16 <= PS_MAX_SUB && span < 0xFFFFFF00ull)
+      return launch_fwd_persist<NT>(a, o, oh, o_lo_off, ld_o, lse, (uint32_t)span);
+  }
   const size_t lds = (size_t)4 * LP * ROW_B + (size_t)LP * 4 + (size_t)NW * 16 * (HD + 4) * 4;
   static bool done = false;
   if (allow_lds_once(self_attn_mfma_kernel<NT, NW>, lds, done, "self_attn_fwd")) return LR2_ERR_LAUNCH;
