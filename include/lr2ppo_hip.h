@@ -24,7 +24,7 @@ extern "C" {
 #define LR2_ERR_SHAPE (-2)  /* shape not supported by the kernel's tiling */
 #define LR2_ERR_LAUNCH (-3) /* HIP launch failure */
 
-#define LR2_ABI_VERSION 18
+#define LR2_ABI_VERSION 19
 int lr2_abi_version(void);
 /* Fills name[0..len) with the HIP device name and returns the CU count (or <0). */
 int lr2_device_info(char* name, int len);
@@ -210,15 +210,27 @@ int lr2_first_token_attn(const void* q, int ld_q, const void* k_hi, const void* 
 
 /* Backward of lr2_self_attn_fwd: from Q, K, V planes and dO planes (same layout rules) to dQ, dK, dV planes
  * (dq_hi / dk_hi / dv_hi: hi planes, element (row, h*64 + d) at ptr[row*ld_d + h*64 + d], lo plane d_lo_off elements behind --
- * three column blocks of one dQKV matrix are the intended target).  Two kernels: dQ per 64 queries (also writes the
- * per-query log-sum-exp and sum_k dP*P into lse_ws / dsum_ws, fp32 [batch*heads*L] each), then dK, dV per 64 keys.
- * Probabilities are recomputed; pass the forward's drop_p / seed / site to replay its mask.  L > 256: both kernels walk the
- * other dimension in blocks of 128 rows; the dQ kernel sweeps the keys twice (running max / sum / sum of exp * dP first).
+ * three column blocks of one dQKV matrix are the intended target).  Two kernels: dQ per 16-query sub-tile, then dK, dV per 16-key
+ * sub-tile; pass the forward's drop_p / seed / site to replay its mask.
+ *   o_hi == NULL: everything is recomputed from Q, K, V -- the dQ kernel writes the per-query log-sum-exp and sum_k dP*P into lse_ws /
+ *     dsum_ws (fp32 [batch*heads*L] each, scratch).  L > 256: both kernels walk the other dimension in blocks of 128 rows; the dQ
+ *     kernel sweeps the keys twice (running max / sum / sum of exp * dP first).
+ *   o_hi != NULL (ABI 19): the forward's output planes (element (row, h*64 + d) at o_hi[row*ld_o + h*64 + d], lo plane o_lo_off elements
+ *     behind) and, in lse_ws, the log-sum-exp lr2_self_attn_fwd wrote (an INPUT then): P = exp(S - lse) and D = sum_d dO O need no
+ *     pass over the keys, both kernels stream over 32-row blocks and -- with at least one (sequence, head) pair per CU, L <= 224 -- run
+ *     as persistent 16-wave workgroups whose K / V (Q / dO) planes are refilled by LDS-DMA under the compute (lr2_self_attn_plan
+ *     says which form a shape takes).  Shapes the persistent form does not cover fall back to the recomputing kernels, which
+ *     OVERWRITE lse_ws with their own (equal up to rounding) values.
  * replaces: autograd of tencentpretrain/layers/multi_headed_attn.py:61-74. */
 int lr2_self_attn_bwd(const void* q_hi, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld, const void* do_hi,
                       uint64_t do_lo_off, int ld_do, const int64_t* seg, void* dq_hi, void* dk_hi, void* dv_hi,
-                      uint64_t d_lo_off, int ld_d, void* lse_ws, void* dsum_ws, float drop_p, uint64_t drop_seed,
-                      uint32_t drop_site, int batch, int heads, int L, int head_dim, float scale, void* stream);
+                      uint64_t d_lo_off, int ld_d, const void* o_hi, uint64_t o_lo_off, int ld_o, void* lse_ws, void* dsum_ws,
+                      float drop_p, uint64_t drop_seed, uint32_t drop_site, int batch, int heads, int L, int head_dim, float scale,
+                      void* stream);
+/* (ABI 19) Which form of the attention kernels a call of this shape runs on this device: *fwd_persistent / *bwd_persistent = 1 when
+ * lr2_self_attn_fwd / lr2_self_attn_bwd (given o_hi) take the persistent kernels (a pure function of the shape, the CU count and the
+ * LR2_ATTN_PERSIST switch; either pointer may be NULL).  No reference counterpart: a test hook of this library's own scheduling. */
+int lr2_self_attn_plan(int batch, int heads, int L, int ld, int ld_do, int* fwd_persistent, int* bwd_persistent);
 
 /* y[r] = dot(x[row(r)], w) + b for r < rows, row(r) = r*row_step + row_off.
  * replaces: self.head = nn.Linear(768, 1) and the last-position select (finetune/ppo.py:228-232,293-295). */

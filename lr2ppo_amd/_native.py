@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(CSRC, "liblr2ppo_hip.so")
 SOURCES = ["gemm.hip", "gemm256.hip", "gemm256_mx.hip", "norm.hip", "attn.hip", "selfattn.hip", "selfattn_mx.hip", "misc.hip", "fp8.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "fp8_common.h"), os.path.join(INCLUDE, "lr2ppo_hip.h")]
 
-ABI_VERSION = 18     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
+ABI_VERSION = 19     # == LR2_ABI_VERSION of include/lr2ppo_hip.h (tests assert the two agree)
 
 _lock = threading.Lock()
 _lib = None
@@ -114,8 +114,9 @@ SIGNATURES = {
     "lr2_xattn_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _U64, _U64, _I, _I, _I, _I, _I, _F, _P],
     "lr2_self_attn_fwd": [_P, _P, _P, _U64, _I, _P, _P, _P, _U64, _I, _P, _F, _U64, _U32, _I, _I, _I, _I, _F, _P],
     "lr2_first_token_attn": [_P, _I, _P, _P, _U64, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P],
-    "lr2_self_attn_bwd": [_P, _P, _P, _U64, _I, _P, _U64, _I, _P, _P, _P, _P, _U64, _I, _P, _P, _F, _U64, _U32, _I, _I, _I,
-                          _I, _F, _P],
+    "lr2_self_attn_bwd": [_P, _P, _P, _U64, _I, _P, _U64, _I, _P, _P, _P, _P, _U64, _I, _P, _U64, _I, _P, _P, _F, _U64, _U32, _I,
+                          _I, _I, _I, _F, _P],
+    "lr2_self_attn_plan": [_I, _I, _I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "lr2_head_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "lr2_head_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "lr2_add_period_rows": [_P, _P, _P, _I, _I, _I, _P],

@@ -223,7 +223,7 @@ __device__ __forceinline__ void attn_phase_b(const char* sV, float* slab, const 
       for (int pass = 0; pass < 2; ++pass) {
         const int r = pass * 8 + (lane >> 3), c = (lane & 7) * 4;
         const int qr = sub * 16 + r;
-        if (qr < L) {
+        if (qr < L && (!(LR2_SA_ABLATE & 64) || slab[r] == 12345.f)) {
           const float4 v = *reinterpret_cast<const float4*>(slab + r * (32 + 4) + c);
           const size_t off = (row0 + qr) * (size_t)ld_o + col0 + 32 * half + c;
           if (O) *reinterpret_cast<float4*>(O + off) = v;
@@ -408,7 +408,7 @@ __device__ __forceinline__ void dma_head_rows(const __amdgpu_buffer_rsrc_t& hi, 
                                               int j0, int jstep, uint32_t pair_off, uint32_t row_bytes, int L) {
   constexpr int LP = 16 * NT, PLANE = LP * ROW_B;
   const int rl = lane >> 3, sl = lane & 7;
-  for (int j = j0; j < LP / 8; j += jstep) {
+  for (int j = j0; j < ((LR2_SA_ABLATE & 1) ? 0 : LP / 8); j += jstep) {
     const int r = 8 * j + rl;
     const int u = IS_V ? (sl ^ (((r >> 1) & 3) << 1)) : (sl ^ ((r >> 1) & 7));
     const uint32_t v = r < L ? pair_off + (uint32_t)r * row_bytes + (uint32_t)u * 16u : 0xFFFFFF00u;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_persist_kernel(const 
     const float* mask = sMask + (it & 1) * LP;
     bf16x8_t ph[NT / 2], pl[NT / 2];
     float inv = 0.f;
-    attn_phase_a<NT, DROP>(sK, mask, qh, ql, sub, lane, L, b, h, heads, scale, lse, dr, ph, pl, inv);
+    if (!(LR2_SA_ABLATE & 2)) attn_phase_a<NT, DROP>(sK, mask, qh, ql, sub, lane, L, b, h, heads, scale, lse, dr, ph, pl, inv);
     phase_barrier();
     const int pn = p + gridDim.x;
     const bool more = pn < n_pairs;
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_persist_kernel(const 
     // the next pair's queries are requested once the probability registers are dead; they travel under the output's stores and the
     // wait at the barrier
     auto next_q = [&]() { if (more) load_q(row0n, hn * HD, qh, ql); };
-    attn_phase_b<NT, true>(sV, slab, ph, pl, inv, sub, lane, L, row0, col0, O, Oh, o_lo_off, ld_o, next_q);
+    if (!(LR2_SA_ABLATE & 2)) attn_phase_b<NT, true>(sV, slab, ph, pl, inv, sub, lane, L, row0, col0, O, Oh, o_lo_off, ld_o, next_q);
     if (!more) break;
     phase_barrier();
     p = pn; b = bn; h = hn; row0 = row0n; col0 = hn * HD;
@@ -1088,6 +1088,467 @@ __global__ __launch_bounds__(64 * NW) void self_attn_bwd_dkv_kernel(const bf16_t
   }  // sub-tile loop
 }
 
+// ---- persistent backward (round 4): the forward's log-sum-exp and output are inputs, nothing is recomputed twice ----
+// With lse[q] from the forward, P = exp(S - lse) needs no row maximum / row sum, and D[q] = sum_k dP P = sum_d dO[q, d] O[q, d] needs
+// no pass over the keys: both kernels STREAM over 32-row blocks of the resident operand -- one S / dP tile pair in registers at a time
+// (the one-pair kernels above hold 14 S tiles and 14 dP tiles of a sub-tile) -- which fits 16-wave workgroups at <= 128 VGPRs:
+//   * wave w < n_sub owns sub-tile w (16 queries in the dQ kernel, 16 keys in the dK / dV kernel) of every pair; waves 14, 15 move data;
+//   * the resident planes (K, V / Q, dO: both in the d_off layout) are refilled IN HALVES while the other half is being used: a row
+//     block is dead once every wave has passed it, so after block H1 - 1 (barrier "mid") the movers load rows [0, 32 H1) of the NEXT
+//     pair and after the last block (barrier "end") the rest; a mover waits for its pieces (s_waitcnt vmcnt(0)) before the NEXT barrier,
+//     i.e. half a pair later; no compute wave waits for memory except for its own 16-row fragments, requested before the stores.
+// Arithmetic: dQ kernel  S^T = K Q^T, dPd^T = V dO^T, P = exp(S scale + mask - lse), dS = P (dPd o M - D) scale, dQ = dS K
+//             dKV kernel S = Q K^T, dPd = dO V^T, Pd = P o M, dS as above, dV = Pd^T dO, dK = dS^T Q          (M = keep / (1 - p))
+// replaces: autograd of tencentpretrain/layers/multi_headed_attn.py:61-74 (as the one-pair kernels do).
+// LDS image of a plane that is read BOTH as row fragments (ds_read_b128: 16 rows x one 16-B unit) and transposed (ds_read_b64_tr_b16:
+// 8 rows x 32 B per half-wave): unit u of row r at u ^ x(r), x = 2 ((r >> 1) & 3) + ((r >> 3) & 1).  x is a bijection of the 8 row
+// pairs of a 16-row tile (fragment reads: 16 distinct 16-B slots = all 64 banks once) and x >> 1 takes 4 distinct values on the 4 row
+// pairs of each 8-row group (transposed reads: 8 distinct 32-B bank groups); k_off's x = (r >> 1) & 7 gives the second only two ways.
+__device__ __forceinline__ int d_swz(int r) { return 2 * ((r >> 1) & 3) + ((r >> 3) & 1); }
+__device__ __forceinline__ int d_off(int r, int u) { return r * ROW_B + ((u ^ d_swz(r)) << 4); }
+
+template <int NT>
+__device__ __forceinline__ void dma_rows_k(const __amdgpu_buffer_rsrc_t& hi, const __amdgpu_buffer_rsrc_t& lo, char* dst, int lane,
+                                           int j_begin, int j_end, int jstep, uint32_t pair_off, uint32_t row_bytes, int L) {
+  constexpr int LP = 16 * NT, PLANE = LP * ROW_B;
+  const int rl = lane >> 3, sl = lane & 7;
+  for (int j = j_begin; j < j_end; j += jstep) {
+    const int r = 8 * j + rl;
+    const int u = sl ^ d_swz(r);
+    const uint32_t v = r < L ? pair_off + (uint32_t)r * row_bytes + (uint32_t)u * 16u : 0xFFFFFF00u;
+    char* d = dst + j * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(hi, LDS_PTR(d), 16, v, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(lo, LDS_PTR(d + PLANE), 16, v, 0, 0, 0);
+  }
+}
+
+// eight bf16 (one fragment) -> fp32 sum of hi + lo products with another fragment pair: sum_i (ah + al)_i (bh + bl)_i
+__device__ __forceinline__ float frag_dot(bf16x8_t ah, bf16x8_t al, bf16x8_t bh, bf16x8_t bl) {
+  const u32x4_t a = __builtin_bit_cast(u32x4_t, ah), c = __builtin_bit_cast(u32x4_t, al);
+  const u32x4_t b = __builtin_bit_cast(u32x4_t, bh), d = __builtin_bit_cast(u32x4_t, bl);
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = __uint_as_float(a[i] << 16) + __uint_as_float(c[i] << 16);
+    const float x1 = __uint_as_float(a[i] & 0xffff0000u) + __uint_as_float(c[i] & 0xffff0000u);
+    const float y0 = __uint_as_float(b[i] << 16) + __uint_as_float(d[i] << 16);
+    const float y1 = __uint_as_float(b[i] & 0xffff0000u) + __uint_as_float(d[i] & 0xffff0000u);
+    acc = __builtin_fmaf(x0, y0, acc);
+    acc = __builtin_fmaf(x1, y1, acc);
+  }
+  return acc;
+}
+
+// 16 x 64 accumulator tile -> planes rows through a 16 x 32 slab, 32 columns at a time
+__device__ __forceinline__ void store_tile_planes_half(const f32x4_t (&o)[4], float* slab, int lane, int row_first, int rows_valid,
+                                                       bf16_t* dst_hi, size_t lo_off, size_t row_stride, size_t base) {
+  const int qn = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(4 * g + r) * (32 + 4) + 16 * n + qn] = o[2 * half + n][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = pass * 8 + (lane >> 3), c = (lane & 7) * 4;
+      if (row_first + r < rows_valid) {
+        const float4 v = *reinterpret_cast<const float4*>(slab + r * (32 + 4) + c);
+        store_planes4(dst_hi + base + (size_t)(row_first + r) * row_stride + 32 * half + c, lo_off, v);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+struct BwdArgs {
+  const bf16_t *q, *k, *v;      // hi planes (lo plane lo_off elements behind), row stride ld
+  size_t lo_off;
+  int ld;
+  const bf16_t* go;             // dO hi plane
+  size_t do_lo_off;
+  int ld_do;
+  const bf16_t* o;              // forward output hi plane
+  size_t o_lo_off;
+  int ld_o;
+  const int64_t* seg;
+  bf16_t *dq, *dk, *dv;
+  size_t d_lo_off;
+  int ld_d;
+  const float* lse;             // [batch, heads, L] from the forward
+  float* dsum;                  // [batch, heads, L]: written by the dQ kernel, read by the dK / dV kernel
+  int heads, L, n_pairs;
+  float scale;
+  DropP dr;
+  uint32_t qkv_bytes, do_bytes; // descriptor spans from q / k / v and from go
+};
+
+// rows [0, 32 * H1) are the first half of the resident planes
+template <int NT>
+struct Halves {
+  static constexpr int NB = NT / 2, H1 = (NB + 1) / 2, J_MID = 4 * H1, J_END = 2 * NT;
+};
+
+template <int NT, bool DROP>
+__global__ __launch_bounds__(64 * PS_WAVES) void self_attn_bwd_dq_persist_kernel(BwdArgs A) {
+  constexpr int LP = 16 * NT, PLANE = LP * ROW_B, NB = Halves<NT>::NB, H1 = Halves<NT>::H1;
+  constexpr int MK = (LP + 64 * PS_MOVERS - 1) / (64 * PS_MOVERS);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + 2 * PLANE;        // same layout: V is an A operand here (rows = keys, contraction over hd)
+  float* sMask = reinterpret_cast<float*>(smem + 4 * PLANE);          // [LP], pre-multiplied by log2(e)
+  float* sOut = sMask + LP;                                          // [PS_MAX_SUB waves][16][32 + 4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int heads = A.heads, L = A.L, n_pairs = A.n_pairs;
+  const int n_sub = (L + 15) >> 4;
+  int p = blockIdx.x;
+  if (p >= n_pairs) return;
+
+  if (wave >= PS_MAX_SUB) {
+    // ---- movers ----
+    const __amdgpu_buffer_rsrc_t k_hi = sa_rsrc(A.k, A.qkv_bytes), k_lo = sa_rsrc(A.k + A.lo_off, A.qkv_bytes);
+    const __amdgpu_buffer_rsrc_t v_hi = sa_rsrc(A.v, A.qkv_bytes), v_lo = sa_rsrc(A.v + A.lo_off, A.qkv_bytes);
+    const int j0 = wave - PS_MAX_SUB, mtid = tid - 64 * PS_MAX_SUB;
+    const uint32_t row_bytes = (uint32_t)A.ld * 2u;
+    auto pair_off = [&](int pp) { const int b = pp / heads, h = pp - b * heads; return (uint32_t)(((size_t)b * L * A.ld + h * HD) * 2); };
+    auto mask_of = [&](int pp, int j) -> float {
+      const int b = pp / heads;
+      return j < L ? ((A.seg[(size_t)b * L + j] > 0) ? 0.f : -10000.0f * LOG2E) : -INFINITY;
+    };
+    dma_rows_k<NT>(k_hi, k_lo, sK, lane, j0, Halves<NT>::J_END, PS_MOVERS, pair_off(p), row_bytes, L);
+    dma_rows_k<NT>(v_hi, v_lo, sV, lane, j0, Halves<NT>::J_END, PS_MOVERS, pair_off(p), row_bytes, L);
+    for (int j = mtid; j < LP; j += 64 * PS_MOVERS) sMask[j] = mask_of(p, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    phase_barrier();
+    for (;;) {
+      const int pn = p + gridDim.x;
+      const bool more = pn < n_pairs;
+      phase_barrier();                                   // mid: rows [0, 32 H1) of this pair are dead
+      if (more) {
+        dma_rows_k<NT>(k_hi, k_lo, sK, lane, j0, Halves<NT>::J_MID, PS_MOVERS, pair_off(pn), row_bytes, L);
+        dma_rows_k<NT>(v_hi, v_lo, sV, lane, j0, Halves<NT>::J_MID, PS_MOVERS, pair_off(pn), row_bytes, L);
+        float mk[MK];
+#pragma unroll
+        for (int i = 0; i < MK; ++i) mk[i] = mask_of(pn, mtid + i * 64 * PS_MOVERS);
+#pragma unroll
+        for (int i = 0; i < MK; ++i) {
+          const int j = mtid + i * 64 * PS_MOVERS;
+          if (j < 32 * H1) sMask[j] = mk[i];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      phase_barrier();                                   // end: the rest is dead
+      if (!more) break;
+      dma_rows_k<NT>(k_hi, k_lo, sK, lane, Halves<NT>::J_MID + j0, Halves<NT>::J_END, PS_MOVERS, pair_off(pn), row_bytes, L);
+      dma_rows_k<NT>(v_hi, v_lo, sV, lane, Halves<NT>::J_MID + j0, Halves<NT>::J_END, PS_MOVERS, pair_off(pn), row_bytes, L);
+      {
+        float mk[MK];
+#pragma unroll
+        for (int i = 0; i < MK; ++i) mk[i] = mask_of(pn, mtid + i * 64 * PS_MOVERS);
+#pragma unroll
+        for (int i = 0; i < MK; ++i) {
+          const int j = mtid + i * 64 * PS_MOVERS;
+          if (j >= 32 * H1 && j < LP) sMask[j] = mk[i];
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      p = pn;
+    }
+    return;
+  }
+  if (wave >= n_sub) {
+    // ---- nothing to compute: keep the barriers company ----
+    phase_barrier();
+    for (;;) {
+      phase_barrier();
+      phase_barrier();
+      p += gridDim.x;
+      if (p >= n_pairs) break;
+    }
+    return;
+  }
+
+  // ---- compute waves: sub-tile `wave` = 16 queries of every pair ----
+  const int sub = wave;
+  const int qn = lane & 15, g = lane >> 4;
+  const int q_row = sub * 16 + qn;
+  const bool q_ok = q_row < L;
+  float* slab = sOut + wave * 16 * (32 + 4);
+  const float scale = A.scale, scale2 = A.scale * LOG2E;
+  const uint32_t kb[2] = {lds_addr(sK + d_off(qn, g)), lds_addr(sK + d_off(qn, g + 4))};
+  const uint32_t vbk[2] = {lds_addr(sV + d_off(qn, g)), lds_addr(sV + d_off(qn, g + 4))};
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+  uint32_t ktb[4];                                        // transposed reads of K: rows 32u + 4g + tq (+ 16)
+#pragma unroll
+  for (int n = 0; n < 4; ++n) ktb[n] = lds_addr(sK + d_off(4 * g + tq, 2 * n + (tp >> 1)) + 8 * (tp & 1));
+
+  bf16x8_t qh[2], ql[2], gh[2], gl[2];
+  float dD = 0.f, lse2 = 0.f;
+  // this wave's rows of pair pp: Q and dO fragments, D = sum_d dO O, lse
+  auto fetch = [&](int pp) {
+    const int b = pp / heads, h = pp - b * heads;
+    const size_t row = (size_t)b * L + (q_ok ? q_row : 0);
+    bf16x8_t oh[2], ol[2];
+    load_frags(A.q, A.lo_off, row * (size_t)A.ld + h * HD + 8 * g, q_ok, qh, ql);
+    load_frags(A.go, A.do_lo_off, row * (size_t)A.ld_do + h * HD + 8 * g, q_ok, gh, gl);
+    load_frags(A.o, A.o_lo_off, row * (size_t)A.ld_o + h * HD + 8 * g, q_ok, oh, ol);
+    const size_t si = ((size_t)b * heads + h) * L + (q_ok ? q_row : 0);
+    lse2 = q_ok ? A.lse[si] * LOG2E : 0.f;
+    float d = frag_dot(gh[0], gl[0], oh[0], ol[0]) + frag_dot(gh[1], gl[1], oh[1], ol[1]);
+    d += __shfl_xor(d, 16, 64);
+    d += __shfl_xor(d, 32, 64);
+    dD = d;
+    if (g == 0 && q_ok) A.dsum[si] = d;
+  };
+  fetch(p);
+  phase_barrier();
+  for (;;) {
+    const int b = p / heads, h = p - b * heads;
+    const size_t row0 = (size_t)b * L;
+    const uint64_t drow = (((uint64_t)b * heads + h) * L + (uint64_t)(q_ok ? q_row : 0)) * mask_pitch(L);
+    f32x4_t o[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      if (u == H1) phase_barrier();                      // mid
+      float e[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * u + half;
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, d = a;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          a = mfma3(lds_ld16(kb[ks] + 2048 * t), lds_ld16(kb[ks] + 2048 * t + PLANE), qh[ks], ql[ks], a);
+          d = mfma3(lds_ld16(vbk[ks] + 2048 * t), lds_ld16(vbk[ks] + 2048 * t + PLANE), gh[ks], gl[ks], d);
+        }
+        const float4 mk = *reinterpret_cast<const float4*>(sMask + 16 * t + 4 * g);
+        const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+        if (DROP && A.dr.thr) d = drop_mul4v(A.dr, drow + 16 * t + 4 * g, d);      // dP = dPd o M
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(a[r], scale2, mkv[r] - lse2));
+          e[4 * half + r] = pr * (d[r] - dD) * scale;
+        }
+      }
+      bf16x8_t eh, el;
+      split8(e, eh, el);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const uint32_t ad = ktb[n] + 4096 * u;
+        o[n] = mfma3(eh, el, lds_tr_pair(ad, ad + 2048), lds_tr_pair(ad + PLANE, ad + 2048 + PLANE), o[n]);
+      }
+    }
+    const int pn = p + gridDim.x;
+    const bool more = pn < n_pairs;
+    if (more) fetch(pn);                                 // the next pair's rows travel under the stores and the barrier
+    store_tile_planes_half(o, slab, lane, sub * 16, L, A.dq, A.d_lo_off, (size_t)A.ld_d, row0 * (size_t)A.ld_d + h * HD);
+    phase_barrier();                                     // end
+    if (!more) break;
+    p = pn;
+  }
+}
+
+template <int NT, bool DROP>
+__global__ __launch_bounds__(64 * PS_WAVES) void self_attn_bwd_dkv_persist_kernel(BwdArgs A) {
+  constexpr int LP = 16 * NT, PLANE = LP * ROW_B, NB = Halves<NT>::NB, H1 = Halves<NT>::H1;
+  constexpr int MK = (LP + 64 * PS_MOVERS - 1) / (64 * PS_MOVERS);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQ = smem;                    // d_off layout: fragment reads (rows = queries) + transposed reads
+  char* sG = smem + 2 * PLANE;        // dO
+  float* sLse = reinterpret_cast<float*>(smem + 4 * PLANE);   // [LP] lse * log2(e); +inf for padded queries (P = 0)
+  float* sD = sLse + LP;                                      // [LP]
+  float* sOut = sD + LP;                                      // [PS_MAX_SUB waves][16][32 + 4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int heads = A.heads, L = A.L, n_pairs = A.n_pairs;
+  const int n_sub = (L + 15) >> 4;
+  int p = blockIdx.x;
+  if (p >= n_pairs) return;
+
+  if (wave >= PS_MAX_SUB) {
+    // ---- movers ----
+    const __amdgpu_buffer_rsrc_t q_hi = sa_rsrc(A.q, A.qkv_bytes), q_lo = sa_rsrc(A.q + A.lo_off, A.qkv_bytes);
+    const __amdgpu_buffer_rsrc_t g_hi = sa_rsrc(A.go, A.do_bytes), g_lo = sa_rsrc(A.go + A.do_lo_off, A.do_bytes);
+    const int j0 = wave - PS_MAX_SUB, mtid = tid - 64 * PS_MAX_SUB;
+    const uint32_t q_row_bytes = (uint32_t)A.ld * 2u, g_row_bytes = (uint32_t)A.ld_do * 2u;
+    auto q_off = [&](int pp) { const int b = pp / heads, h = pp - b * heads; return (uint32_t)(((size_t)b * L * A.ld + h * HD) * 2); };
+    auto g_off = [&](int pp) { const int b = pp / heads, h = pp - b * heads; return (uint32_t)(((size_t)b * L * A.ld_do + h * HD) * 2); };
+    dma_rows_k<NT>(q_hi, q_lo, sQ, lane, j0, Halves<NT>::J_END, PS_MOVERS, q_off(p), q_row_bytes, L);
+    dma_rows_k<NT>(g_hi, g_lo, sG, lane, j0, Halves<NT>::J_END, PS_MOVERS, g_off(p), g_row_bytes, L);
+    for (int j = mtid; j < LP; j += 64 * PS_MOVERS) {
+      const size_t si = (size_t)p * L + j;
+      sLse[j] = j < L ? A.lse[si] * LOG2E : INFINITY;
+      sD[j] = j < L ? A.dsum[si] : 0.f;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    phase_barrier();
+    for (;;) {
+      const int pn = p + gridDim.x;
+      const bool more = pn < n_pairs;
+      phase_barrier();                                   // mid
+      if (more) {
+        dma_rows_k<NT>(q_hi, q_lo, sQ, lane, j0, Halves<NT>::J_MID, PS_MOVERS, q_off(pn), q_row_bytes, L);
+        dma_rows_k<NT>(g_hi, g_lo, sG, lane, j0, Halves<NT>::J_MID, PS_MOVERS, g_off(pn), g_row_bytes, L);
+        float l2[MK], dd[MK];
+#pragma unroll
+        for (int i = 0; i < MK; ++i) {
+          const int j = mtid + i * 64 * PS_MOVERS;
+          const size_t si = (size_t)pn * L + (j < L ? j : 0);
+          l2[i] = j < L ? A.lse[si] * LOG2E : INFINITY;
+          dd[i] = j < L ? A.dsum[si] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MK; ++i) {
+          const int j = mtid + i * 64 * PS_MOVERS;
+          if (j < 32 * H1) { sLse[j] = l2[i]; sD[j] = dd[i]; }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      phase_barrier();                                   // end
+      if (!more) break;
+      dma_rows_k<NT>(q_hi, q_lo, sQ, lane, Halves<NT>::J_MID + j0, Halves<NT>::J_END, PS_MOVERS, q_off(pn), q_row_bytes, L);
+      dma_rows_k<NT>(g_hi, g_lo, sG, lane, Halves<NT>::J_MID + j0, Halves<NT>::J_END, PS_MOVERS, g_off(pn), g_row_bytes, L);
+      {
+        float l2[MK], dd[MK];
+#pragma unroll
+        for (int i = 0; i < MK; ++i) {
+          const int j = mtid + i * 64 * PS_MOVERS;
+          const size_t si = (size_t)pn * L + (j < L ? j : 0);
+          l2[i] = j < L ? A.lse[si] * LOG2E : INFINITY;
+          dd[i] = j < L ? A.dsum[si] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MK; ++i) {
+          const int j = mtid + i * 64 * PS_MOVERS;
+          if (j >= 32 * H1 && j < LP) { sLse[j] = l2[i]; sD[j] = dd[i]; }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      p = pn;
+    }
+    return;
+  }
+  if (wave >= n_sub) {
+    phase_barrier();
+    for (;;) {
+      phase_barrier();
+      phase_barrier();
+      p += gridDim.x;
+      if (p >= n_pairs) break;
+    }
+    return;
+  }
+
+  // ---- compute waves: sub-tile `wave` = 16 keys of every pair ----
+  const int sub = wave;
+  const int kn = lane & 15, g = lane >> 4;
+  const int key = sub * 16 + kn;
+  const bool k_ok = key < L;
+  float* slab = sOut + wave * 16 * (32 + 4);
+  const float scale = A.scale, scale2 = A.scale * LOG2E;
+  const uint32_t qb[2] = {lds_addr(sQ + d_off(kn, g)), lds_addr(sQ + d_off(kn, g + 4))};
+  const uint32_t gb[2] = {lds_addr(sG + d_off(kn, g)), lds_addr(sG + d_off(kn, g + 4))};
+  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+  uint32_t qtb[4], gtb[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    qtb[n] = lds_addr(sQ + d_off(4 * g + tq, 2 * n + (tp >> 1)) + 8 * (tp & 1));
+    gtb[n] = lds_addr(sG + d_off(4 * g + tq, 2 * n + (tp >> 1)) + 8 * (tp & 1));
+  }
+  bf16x8_t kh[2], kl[2], vh[2], vl[2];
+  float kmask2 = 0.f;
+  auto fetch = [&](int pp) {
+    const int b = pp / heads, h = pp - b * heads;
+    const size_t row = (size_t)b * L + (k_ok ? key : 0);
+    load_frags(A.k, A.lo_off, row * (size_t)A.ld + h * HD + 8 * g, k_ok, kh, kl);
+    load_frags(A.v, A.lo_off, row * (size_t)A.ld + h * HD + 8 * g, k_ok, vh, vl);
+    kmask2 = k_ok ? ((A.seg[row] > 0) ? 0.f : -10000.0f * LOG2E) : -INFINITY;
+  };
+  fetch(p);
+  phase_barrier();
+  for (;;) {
+    const int b = p / heads, h = p - b * heads;
+    const size_t row0 = (size_t)b * L;
+    // mask element of (query q, this lane's key): (((b heads + h) L + q) pitch + key
+    const uint64_t pitch = mask_pitch(L);
+    const uint64_t drow_k = ((uint64_t)b * heads + h) * (uint64_t)L * pitch + (uint64_t)(k_ok ? key : 0);
+    f32x4_t dv[4], dk[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) dv[n] = dk[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // one 32-query block: rolled loops (an unrolled pair lets the scheduler hoist seven blocks' worth of hashes and fragments)
+    auto block = [&](int u) {
+      const uint32_t uo = 4096u * (uint32_t)u;
+      // the block's 8 dropout decisions as one bit mask, taken before the fragments are live
+      uint32_t keep = 0xffu;
+      if (DROP && A.dr.thr) {
+        keep = 0;
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+          const int q = 32 * u + 16 * (e8 >> 2) + 4 * g + (e8 & 3);
+          keep |= (uint32_t)dropout_keep(A.dr.key, drow_k + (uint64_t)(q < L ? q : 0) * pitch, A.dr.thr) << e8;
+        }
+        asm volatile("" : "+v"(keep));
+      }
+      float pd[8], ds[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, d = a;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const uint32_t aq = qb[ks] + uo + 2048 * half, ag = gb[ks] + uo + 2048 * half;
+          a = mfma3(lds_ld16(aq), lds_ld16(aq + PLANE), kh[ks], kl[ks], a);   // S[query 32u + 16 half + 4g + r][key kn]
+          d = mfma3(lds_ld16(ag), lds_ld16(ag + PLANE), vh[ks], vl[ks], d);   // dPd
+        }
+        const float4 ls = *reinterpret_cast<const float4*>(sLse + 32 * u + 16 * half + 4 * g);
+        const float4 dd = *reinterpret_cast<const float4*>(sD + 32 * u + 16 * half + 4 * g);
+        const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, ddv[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(a[r], scale2, kmask2 - lsv[r]));
+          const float m = (DROP && A.dr.thr) ? (((keep >> (4 * half + r)) & 1u) ? A.dr.inv_keep : 0.0f) : 1.0f;
+          pd[4 * half + r] = pr * m;
+          ds[4 * half + r] = pr * (d[r] * m - ddv[r]) * scale;
+        }
+      }
+      {
+        bf16x8_t ph, pl;
+        split8(pd, ph, pl);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const uint32_t ag = gtb[n] + uo;
+          dv[n] = mfma3(ph, pl, lds_tr_pair(ag, ag + 2048), lds_tr_pair(ag + PLANE, ag + 2048 + PLANE), dv[n]);
+        }
+      }
+      {
+        bf16x8_t eh, el;
+        split8(ds, eh, el);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const uint32_t aq = qtb[n] + uo;
+          dk[n] = mfma3(eh, el, lds_tr_pair(aq, aq + 2048), lds_tr_pair(aq + PLANE, aq + 2048 + PLANE), dk[n]);
+        }
+      }
+    };
+#pragma unroll 1
+    for (int u = 0; u < H1; ++u) block(u);
+    phase_barrier();                                     // mid
+#pragma unroll 1
+    for (int u = H1; u < NB; ++u) block(u);
+    const int pn = p + gridDim.x;
+    const bool more = pn < n_pairs;
+    if (more) fetch(pn);
+    const size_t base = row0 * (size_t)A.ld_d + h * HD;
+    store_tile_planes_half(dk, slab, lane, sub * 16, L, A.dk, A.d_lo_off, (size_t)A.ld_d, base);
+    store_tile_planes_half(dv, slab, lane, sub * 16, L, A.dv, A.d_lo_off, (size_t)A.ld_d, base);
+    phase_barrier();                                     // end
+    if (!more) break;
+    p = pn;
+  }
+}
+
 // ---- backward for sequences beyond one LDS-resident block (L > 256): the same two kernels with a block loop ---------------
 // dQ: the keys are walked in blocks of LPB = 16*NT, TWICE.  Sweep 1 keeps, per query, the running maximum m, the sum
 // l = sum_k exp(s_k - m) and a = sum_k exp(s_k - m) dP_k (rescaled like the forward's accumulator when m grows), which give
@@ -1378,6 +1839,7 @@ struct AttnArgs {
 
 // Forward: 8 waves per workgroup (2 per SIMD) hide the LDS-read latency of the dependent tile chains; the 256-key
 // variant keeps 4 (its K/V planes + 8 output slabs would not fit the 160 KiB of LDS).
+static bool attn_persist_enabled();
 static int cu_count() {
   static int n = 0;
   if (n == 0) {
@@ -1395,11 +1857,17 @@ int launch_fwd_persist(const AttnArgs& a, float* o, bf16_t* oh, size_t o_lo_off,
   constexpr int LP = 16 * NT;
   const size_t lds = (size_t)4 * LP * ROW_B + (size_t)2 * LP * 4 + (size_t)PS_MAX_SUB * 16 * (32 + 4) * 4;
   static bool done = false;
+  static bool done_drop = false;
   if (allow_lds_once(self_attn_persist_kernel<NT, false>, lds, done, "self_attn_fwd(persistent)")) return LR2_ERR_LAUNCH;
+  if (allow_lds_once(self_attn_persist_kernel<NT, true>, lds, done_drop, "self_attn_fwd(persistent, dropout)")) return LR2_ERR_LAUNCH;
   const int n_pairs = a.batch * a.heads;
   const int grid = n_pairs < cu_count() ? n_pairs : cu_count();
-  LR2_LAUNCH((self_attn_persist_kernel<NT, false>), dim3(grid), dim3(64 * PS_WAVES), lds, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, a.seg, o, oh,
-             o_lo_off, ld_o, a.heads, a.L, a.scale, lse, a.dr, n_pairs, kv_bytes);
+  if (a.dr.thr)
+    LR2_LAUNCH((self_attn_persist_kernel<NT, true>), dim3(grid), dim3(64 * PS_WAVES), lds, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, a.seg, o,
+               oh, o_lo_off, ld_o, a.heads, a.L, a.scale, lse, a.dr, n_pairs, kv_bytes);
+  else
+    LR2_LAUNCH((self_attn_persist_kernel<NT, false>), dim3(grid), dim3(64 * PS_WAVES), lds, a.stream, a.q, a.k, a.v, a.lo_off, a.ld, a.seg, o,
+               oh, o_lo_off, ld_o, a.heads, a.L, a.scale, lse, a.dr, n_pairs, kv_bytes);
   return lr2_launch_status("lr2_self_attn_fwd(persistent)");
 }
 
@@ -1408,10 +1876,10 @@ int launch_fwd(const AttnArgs& a, float* o, bf16_t* oh, size_t o_lo_off, int ld_
   constexpr int LP = 16 * NT;
   constexpr int NW = NT <= 14 ? 8 : 4;
   if constexpr (NT <= 14) {
-    static const bool persist_on = !(getenv("LR2_ATTN_PERSIST") && atoi(getenv("LR2_ATTN_PERSIST")) == 0);
+    const bool persist_on = attn_persist_enabled();
     // bytes a K / V descriptor spans from its first element: the last row's head columns end (rows - 1) * ld + heads * 64 elements on
     const uint64_t span = ((uint64_t)a.batch * a.L - 1) * (uint64_t)a.ld * 2u + (uint64_t)a.heads * HD * 2u;
-    if (persist_on && a.dr.thr == 0 && a.batch * a.heads >= cu_count() && (a.L + 15) / 16 <= PS_MAX_SUB && span < 0xFFFFFF00ull)
+    if (persist_on && a.batch * a.heads >= cu_count() && (a.L + 15) / 16 <= PS_MAX_SUB && span < 0xFFFFFF00ull)
       return launch_fwd_persist<NT>(a, o, oh, o_lo_off, ld_o, lse, (uint32_t)span);
   }
   const size_t lds = (size_t)4 * LP * ROW_B + (size_t)LP * 4 + (size_t)NW * 16 * (HD + 4) * 4;
@@ -1453,6 +1921,51 @@ static int fwd_blocked_dispatch(const AttnArgs& a, float* o, bf16_t* oh, size_t 
   // 14 key tiles: 3 query sub-tiles per wave always (the 4-slot variant needs 11 VGPRs more than the 256 of two waves per SIMD)
   return launch_fwd_blocked<14, 3>(a, o, oh, o_lo_off, ld_o, lse, (a.L + 16 * 14 - 1) / (16 * 14));
 #undef BLK
+}
+
+// The backward's persistent form needs the forward's output and log-sum-exp (o != nullptr: lse is then an INPUT), at least one pair per
+// CU, 32-bit byte offsets into every operand.  (LR2_ATTN_PERSIST=0: the A/B switch of the forward applies here too.)
+static bool attn_persist_enabled() {
+  static const bool on = !(getenv("LR2_ATTN_PERSIST") && atoi(getenv("LR2_ATTN_PERSIST")) == 0);
+  return on;
+}
+static bool bwd_persist_ok(int batch, int heads, int L, int ld, int ld_do, bool has_o) {
+  const uint64_t span = ((uint64_t)batch * L - 1) * (uint64_t)ld * 2u + (uint64_t)heads * HD * 2u;
+  const uint64_t span_do = ((uint64_t)batch * L - 1) * (uint64_t)ld_do * 2u + (uint64_t)heads * HD * 2u;
+  return attn_persist_enabled() && has_o && L <= 16 * PS_MAX_SUB && batch * heads >= cu_count() && span < 0xFFFFFF00ull &&
+         span_do < 0xFFFFFF00ull;
+}
+
+template <int NT>
+int launch_bwd_persist(const AttnArgs& a, const bf16_t* go, size_t do_lo_off, int ld_do, const bf16_t* o, size_t o_lo_off, int ld_o,
+                       bf16_t* dq, bf16_t* dk, bf16_t* dv, size_t d_lo_off, int ld_d, const float* lse, float* dsum) {
+  constexpr int LP = 16 * NT;
+  const size_t lds1 = (size_t)4 * LP * ROW_B + (size_t)LP * 4 + (size_t)PS_MAX_SUB * 16 * (32 + 4) * 4;
+  const size_t lds2 = (size_t)4 * LP * ROW_B + (size_t)LP * 8 + (size_t)PS_MAX_SUB * 16 * (32 + 4) * 4;
+  static bool d1 = false, d2 = false, d3 = false, d4 = false;
+  if (allow_lds_once(self_attn_bwd_dq_persist_kernel<NT, false>, lds1, d1, "self_attn_bwd_dq(persistent)")) return LR2_ERR_LAUNCH;
+  if (allow_lds_once(self_attn_bwd_dq_persist_kernel<NT, true>, lds1, d2, "self_attn_bwd_dq(persistent, dropout)")) return LR2_ERR_LAUNCH;
+  if (allow_lds_once(self_attn_bwd_dkv_persist_kernel<NT, false>, lds2, d3, "self_attn_bwd_dkv(persistent)")) return LR2_ERR_LAUNCH;
+  if (allow_lds_once(self_attn_bwd_dkv_persist_kernel<NT, true>, lds2, d4, "self_attn_bwd_dkv(persistent, dropout)")) return LR2_ERR_LAUNCH;
+  BwdArgs A{};
+  A.q = a.q; A.k = a.k; A.v = a.v; A.lo_off = a.lo_off; A.ld = a.ld;
+  A.go = go; A.do_lo_off = do_lo_off; A.ld_do = ld_do;
+  A.o = o; A.o_lo_off = o_lo_off; A.ld_o = ld_o;
+  A.seg = a.seg; A.dq = dq; A.dk = dk; A.dv = dv; A.d_lo_off = d_lo_off; A.ld_d = ld_d;
+  A.lse = lse; A.dsum = dsum; A.heads = a.heads; A.L = a.L; A.n_pairs = a.batch * a.heads; A.scale = a.scale; A.dr = a.dr;
+  A.qkv_bytes = (uint32_t)(((uint64_t)a.batch * a.L - 1) * (uint64_t)a.ld * 2u + (uint64_t)a.heads * HD * 2u);
+  A.do_bytes = (uint32_t)(((uint64_t)a.batch * a.L - 1) * (uint64_t)ld_do * 2u + (uint64_t)a.heads * HD * 2u);
+  const int grid = A.n_pairs < cu_count() ? A.n_pairs : cu_count();
+  if (a.dr.thr) {
+    LR2_LAUNCH((self_attn_bwd_dq_persist_kernel<NT, true>), dim3(grid), dim3(64 * PS_WAVES), lds1, a.stream, A);
+    if (lr2_launch_status("lr2_self_attn_bwd(dq, persistent)")) return LR2_ERR_LAUNCH;
+    LR2_LAUNCH((self_attn_bwd_dkv_persist_kernel<NT, true>), dim3(grid), dim3(64 * PS_WAVES), lds2, a.stream, A);
+  } else {
+    LR2_LAUNCH((self_attn_bwd_dq_persist_kernel<NT, false>), dim3(grid), dim3(64 * PS_WAVES), lds1, a.stream, A);
+    if (lr2_launch_status("lr2_self_attn_bwd(dq, persistent)")) return LR2_ERR_LAUNCH;
+    LR2_LAUNCH((self_attn_bwd_dkv_persist_kernel<NT, false>), dim3(grid), dim3(64 * PS_WAVES), lds2, a.stream, A);
+  }
+  return lr2_launch_status("lr2_self_attn_bwd(dkv, persistent)");
 }
 
 template <int NT>
@@ -1613,24 +2126,46 @@ extern "C" int lr2_self_attn_fwd(const void* q_hi, const void* k_hi, const void*
 
 extern "C" int lr2_self_attn_bwd(const void* q_hi, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld,
                                  const void* do_hi, uint64_t do_lo_off, int ld_do, const int64_t* seg, void* dq_hi, void* dk_hi,
-                                 void* dv_hi, uint64_t d_lo_off, int ld_d, void* lse_ws, void* dsum_ws, float drop_p,
-                                 uint64_t drop_seed, uint32_t drop_site, int batch, int heads, int L, int head_dim, float scale,
-                                 void* stream) {
+                                 void* dv_hi, uint64_t d_lo_off, int ld_d, const void* o_hi, uint64_t o_lo_off, int ld_o,
+                                 void* lse_ws, void* dsum_ws, float drop_p, uint64_t drop_seed, uint32_t drop_site, int batch,
+                                 int heads, int L, int head_dim, float scale, void* stream) {
   if (!q_hi || !k_hi || !v_hi || !do_hi || !seg || !dq_hi || !dk_hi || !dv_hi || !lse_ws || !dsum_ws || batch <= 0 || heads <= 0)
     return LR2_ERR_ARG;
   if (head_dim != HD || L < 1 || ld % 8 || ld_do % 8 || ld_d % 8 || lo_off % 8 || do_lo_off % 8 || d_lo_off % 8)
     return LR2_ERR_SHAPE;
+  if (o_hi && (ld_o % 8 || o_lo_off % 8)) return LR2_ERR_SHAPE;
   if (drop_p < 0.f || drop_p >= 1.f) return LR2_ERR_ARG;
   const AttnArgs a{(const bf16_t*)q_hi, (const bf16_t*)k_hi, (const bf16_t*)v_hi, (size_t)lo_off, ld, seg, batch, heads, L,
                    scale, make_drop(drop_p, drop_seed, drop_site), (hipStream_t)stream};
   if (L > 256)
     return launch_bwd_blocked(a, (const bf16_t*)do_hi, (size_t)do_lo_off, ld_do, (bf16_t*)dq_hi, (bf16_t*)dk_hi, (bf16_t*)dv_hi,
                               (size_t)d_lo_off, ld_d, (float*)lse_ws, (float*)dsum_ws);
+  if (bwd_persist_ok(batch, heads, L, ld, ld_do, o_hi != nullptr)) {
+#define CALLP(NT)                                                                                                                      \
+  launch_bwd_persist<NT>(a, (const bf16_t*)do_hi, (size_t)do_lo_off, ld_do, (const bf16_t*)o_hi, (size_t)o_lo_off, ld_o, (bf16_t*)dq_hi, \
+                         (bf16_t*)dk_hi, (bf16_t*)dv_hi, (size_t)d_lo_off, ld_d, (const float*)lse_ws, (float*)dsum_ws)
+    if (L <= 64) return CALLP(4);
+    if (L <= 128) return CALLP(8);
+    return CALLP(14);
+#undef CALLP
+  }
 #define CALL(NT)                                                                                                           \
   launch_bwd<NT>(a, (const bf16_t*)do_hi, (size_t)do_lo_off, ld_do, (bf16_t*)dq_hi, (bf16_t*)dk_hi, (bf16_t*)dv_hi,        \
                  (size_t)d_lo_off, ld_d, (float*)lse_ws, (float*)dsum_ws)
   LR2_SA_DISPATCH(L, CALL)
 #undef CALL
+}
+
+// Which form of the attention kernels a call of this shape runs (a pure function of the shape, the device's CU count and
+// LR2_ATTN_PERSIST): *fwd_persistent / *bwd_persistent = 1 when lr2_self_attn_fwd / lr2_self_attn_bwd (the latter given o_hi) take the
+// persistent kernels.  Tests assert on it; ld / ld_do as in the calls.
+extern "C" int lr2_self_attn_plan(int batch, int heads, int L, int ld, int ld_do, int* fwd_persistent, int* bwd_persistent) {
+  if (batch <= 0 || heads <= 0 || L < 1) return LR2_ERR_ARG;
+  const uint64_t span = ((uint64_t)batch * L - 1) * (uint64_t)ld * 2u + (uint64_t)heads * HD * 2u;
+  if (fwd_persistent)
+    *fwd_persistent = attn_persist_enabled() && L <= 16 * PS_MAX_SUB && batch * heads >= cu_count() && span < 0xFFFFFF00ull;
+  if (bwd_persistent) *bwd_persistent = bwd_persist_ok(batch, heads, L, ld, ld_do, true);
+  return 0;
 }
 
 extern "C" int lr2_first_token_attn(const void* q, int ld_q, const void* k_hi, const void* v_hi, uint64_t lo_off, int ld,

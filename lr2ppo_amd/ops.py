@@ -538,10 +538,12 @@ def first_token_attn(q: torch.Tensor, kv: "Planes", seg, o: torch.Tensor, *, bat
 
 
 def self_attn_bwd(qkv: "Planes", do: "Planes", seg, dqkv: "Planes", lse_ws, dsum_ws, *, batch, heads, L, head_dim, scale,
-                  drop: Optional[Drop] = None):
-    """dQKV (Planes [batch*L, 3E]) from QKV and dO (Planes [batch*L, E]); lse_ws / dsum_ws: fp32 [batch*heads*L] scratch."""
+                  drop: Optional[Drop] = None, o: Optional["Planes"] = None):
+    """dQKV (Planes [batch*L, 3E]) from QKV and dO (Planes [batch*L, E]); lse_ws / dsum_ws: fp32 [batch*heads*L].  Without `o` both are
+    scratch (everything is recomputed).  With `o` = the forward's output planes [batch*L, E], lse_ws must hold the log-sum-exp
+    self_attn_fwd(..., lse=lse_ws) wrote for the same inputs: the streaming / persistent kernels (lr2_self_attn_bwd, ABI 19)."""
     E = heads * head_dim
-    for name, t, cols in (("qkv", qkv, 3 * E), ("do", do, E), ("dqkv", dqkv, 3 * E)):
+    for name, t, cols in (("qkv", qkv, 3 * E), ("do", do, E), ("dqkv", dqkv, 3 * E)) + ((("o", o, E),) if o is not None else ()):
         if not isinstance(t, Planes) or t.cols != cols or t.rows != batch * L:
             raise TypeError(f"self_attn_bwd: {name} must be a Planes matrix [batch*L, {cols}]")
     if seg.dtype != torch.int64:
@@ -554,9 +556,21 @@ def self_attn_bwd(qkv: "Planes", do: "Planes", seg, dqkv: "Planes", lse_ws, dsum
     p, seed, site = (drop.p, drop.seed, drop.site) if drop is not None else (0.0, 0, 0)
     with _Timed(f"selfattnbwd_B{batch}_H{heads}_L{L}", 14.0 * batch * heads * L * L * head_dim, 32.0 * batch * L * E):
         _nat.check(_nat.lib().lr2_self_attn_bwd(q, k, v, qkv.lo_off, qkv.cols, do.data_ptr(), do.lo_off, do.cols, seg.data_ptr(),
-                                                dq, dk, dv, dqkv.lo_off, dqkv.cols, lse_ws.data_ptr(), dsum_ws.data_ptr(), p,
-                                                seed, site, batch, heads, L, head_dim, scale, _stream()), "lr2_self_attn_bwd")
+                                                dq, dk, dv, dqkv.lo_off, dqkv.cols, o.data_ptr() if o is not None else None,
+                                                o.lo_off if o is not None else 0, o.cols if o is not None else 0,
+                                                lse_ws.data_ptr(), dsum_ws.data_ptr(), p, seed, site, batch, heads, L, head_dim, scale,
+                                                _stream()), "lr2_self_attn_bwd")
     return dqkv
+
+
+def self_attn_plan(batch: int, heads: int, L: int, ld: Optional[int] = None, ld_do: Optional[int] = None):
+    """(forward persistent?, backward persistent?) for a call of this shape (lr2_self_attn_plan): which form of the kernels runs."""
+    import ctypes
+    E = heads * 64
+    f, b = ctypes.c_int(), ctypes.c_int()
+    _nat.check(_nat.lib().lr2_self_attn_plan(batch, heads, L, 3 * E if ld is None else ld, E if ld_do is None else ld_do,
+                                             ctypes.byref(f), ctypes.byref(b)), "lr2_self_attn_plan")
+    return bool(f.value), bool(b.value)
 
 
 def gather_rows(src, index, dst, *, B, t_in, t_out, row_elems, src_bstride=None, src_tstride=None):

@@ -363,7 +363,7 @@ class TransformerEncoder(nn.Module):
         pre = self.layernorm_positioning == "pre"
         # everything the backward needs lives in one allocation per forward: per layer 32 (pre-LN) / 40 (post-LN) x M x E bytes
         # of hidden-width tensors, 8 x M x F of feed-forward ones, 4 row statistics; + the final LayerNorm's statistics
-        per_layer = (32 if pre else 40) * M * E + 8 * M * F + 16 * M + 16 * 256
+        per_layer = (32 if pre else 40) * M * E + 8 * M * F + 16 * M + 4 * B * H * L + 20 * 256
         arena = engine.Arena(dev, self.layers_num * per_layer + 4 * M * E + 8 * M + 8 * 256)
         mat, vec, pl = arena.mat, arena.vec, arena.planes
         scale = 1.0 / math.sqrt(float(hd))
@@ -386,7 +386,8 @@ class TransformerEncoder(nn.Module):
                 x_p = h_p
             qkv_p, o_p, t1 = pl(M, 3 * E), pl(M, E), mat(M, E)
             engine.linear_fwd(ws, x_p, w["wqkv" if big_qkv else "wqkv_t"], w["bqkv"], None, M, 3 * E, E, out_planes=qkv_p)
-            ops.self_attn_fwd(qkv_p, seg, o_p, batch=B, heads=H, L=L, head_dim=hd, scale=scale, drop=drop(s0))
+            S["lse"] = vec(B * H * L)                                    # the attention's log-sum-exp: an input of its backward
+            ops.self_attn_fwd(qkv_p, seg, o_p, batch=B, heads=H, L=L, head_dim=hd, scale=scale, lse=S["lse"], drop=drop(s0))
             engine.linear_fwd(ws, o_p, w["wo"], att.final_linear.bias.data, t1, M, E, E, resid=h, drop=drop(s0 + 1))
             z, ff_p = mat(M, F), pl(M, F)
             S.update(x_p=x_p, qkv_p=qkv_p, o_p=o_p, t1=t1, z=z, ff_p=ff_p)
@@ -474,7 +475,7 @@ class TransformerEncoder(nn.Module):
                 raise ValueError("_backward_train(G=...): pass grad_buffers()")
             qkv_blocks = self._gqkv
         partials = ws.vec("ln_partials", ops.LN_BWD_BLOCKS * 2 * E)
-        lse_ws, dsum_ws = ws.vec("attn_lse", B * H * L), ws.vec("attn_dsum", B * H * L)
+        dsum_ws = ws.vec("attn_dsum", B * H * L)
         pre = self.layernorm_positioning == "pre"
         scale = 1.0 / math.sqrt(float(hd))
         big_dqkv = ops.use_gemm256(M, E, 3 * E)     # the QKV input gradient goes through a transposed fp32 concatenation only then
@@ -523,8 +524,8 @@ class TransformerEncoder(nn.Module):
             engine.linear_wgrad(ws, dao_p, S["o_p"], G[att.final_linear.weight], G[att.final_linear.bias], M, E, E)
             do_p, dqkv_p = pl("do_p", M, E), pl("dqkv_p", M, 3 * E)
             engine.linear_dgrad(ws, dao_p, w["wo"], None, M, E, E, out_planes=do_p, w_f32=att.final_linear.weight.data)
-            ops.self_attn_bwd(S["qkv_p"], do_p, seg, dqkv_p, lse_ws, dsum_ws, batch=B, heads=H, L=L, head_dim=hd, scale=scale,
-                              drop=drop(s0))
+            ops.self_attn_bwd(S["qkv_p"], do_p, seg, dqkv_p, S["lse"], dsum_ws, batch=B, heads=H, L=L, head_dim=hd, scale=scale,
+                              drop=drop(s0), o=S["o_p"])
             engine.linear_wgrad(ws, dqkv_p, S["x_p"], qkv_blocks[i][0], qkv_blocks[i][1], M, E, 3 * E)     # = the three gradients
             # the gradient handed back to autograd (layer 0) gets its own storage: it outlives this call
             dprev = torch.empty(M, E, device=dev) if i == 0 else mat("dh%d" % flip, M, E)

@@ -12,7 +12,7 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 OUT = os.path.join(REPO, "tools", "dbg", "micro", "build")
-SETTINGS = [0, 1, 2, 3, 4, 8, 12, 16, 32, 48, 64, 4 | 8 | 64, 1 | 4 | 8 | 64]
+SETTINGS = [0, 1, 2, 3, 4, 8, 12, 16, 32, 48, 64, 65, 4 | 8 | 64, 1 | 4 | 8 | 64]
 EXTRA = [a for a in sys.argv[1:] if a.startswith("-D")]
 
 

@@ -40,7 +40,15 @@ for (batch, heads, L) in ((512, 12, 197), (64, 12, 196), (300, 4, 97), (40, 8, 2
     mask = (1.0 - (seg[sl].view(3, 1, 1, L) > 0).double().cpu()) * -10000.0
     ref = (torch.softmax(q @ k.transpose(-2, -1) / 8.0 + mask, dim=-1) @ v).transpose(1, 2).reshape(3 * L, E)
     err = float((o[sl].double().cpu() - ref).abs().max())
-    ok = same and same_pl and err < 2e-5 and bool(torch.isfinite(o).all())
+    # train mode: probability dropout + the log-sum-exp the backward reads
+    dr = ops.Drop(0.1, 1234, 7)
+    od, lse = torch.empty_like(o), torch.full((batch * heads * L,), float("nan"), device=dev)
+    od2, lse2 = torch.empty_like(o2), torch.full((nb * heads * L,), float("nan"), device=dev)
+    ops.self_attn_fwd(qkv, seg, od, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, lse=lse, drop=dr)
+    ops.self_attn_fwd(qs, seg[:nb * L].contiguous(), od2, batch=nb, heads=heads, L=L, head_dim=64, scale=0.125, lse=lse2, drop=dr)
+    same_drop = torch.equal(od[:nb * L], od2) and torch.equal(lse[:nb * heads * L], lse2) and not torch.equal(od, o)
+    same = same and same_drop
+    ok = same and same_pl and err < 2e-5 and bool(torch.isfinite(o).all()) and bool(torch.isfinite(lse).all())
     bad += 0 if ok else 1
     print(f"batch {batch} heads {heads} L {L}: first {nb} sequences equal the one-pair kernel: {same}; planes output == split(fp32 output): {same_pl}; "
           f"max |err| vs fp64 {err:.2e}  {'ok' if ok else 'MISMATCH'}", flush=True)
