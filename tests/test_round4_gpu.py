@@ -96,3 +96,79 @@ def test_row_split_is_what_runs(dev):
     ops.gemm(ap, wp, out, M, N, K, block_m=256, splits=1, drop=ops.Drop(0.1, 3, 1))
     c3 = _counts()
     assert [c3[i] - c2[i] for i in range(3)] == [1, 0, 0]
+
+
+# ---- persistent attention kernels (csrc/selfattn.hip: self_attn_persist_kernel, self_attn_bwd_{dq,dkv}_persist_kernel) ----
+def _attn_case(dev, batch, heads, L, seed):
+    from lr2ppo_amd import ops
+    E = heads * 64
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(batch * L, 3 * E, generator=g) * 0.7).to(dev)
+    qkv = ops.split_planes(x, ops.Planes.empty(batch * L, 3 * E, dev))
+    seg = (torch.rand(batch, L, generator=g) > 0.2).long()
+    seg[:, 0] = 1
+    return ops, E, qkv, seg.view(-1).to(dev), g, x
+
+
+@pytest.mark.parametrize("batch,heads,L,p", [(300, 4, 97, 0.1), (40, 8, 224, 0.0), (256, 2, 33, 0.1), (64, 12, 196, 0.0)])
+def test_persistent_attention_forward_equals_one_pair_kernel_and_fp64(dev, batch, heads, L, p):
+    """At least one (sequence, head) pair per CU: lr2_self_attn_fwd runs the persistent 16-wave kernel (lr2_self_attn_plan says so);
+    the first sequences alone (fewer pairs than CUs) run the one-pair kernel on the same rows -- context, planes output and
+    log-sum-exp agree BIT FOR BIT (both call attn_phase_a / attn_phase_b; dropout masks are indexed by (sequence, head, query, key));
+    eval-mode context against the fp64 softmax(Q K^T / 8 - 10000 pad) V of the reference (multi_headed_attn.py:61-74)."""
+    ops, E, qkv, seg, g, x = _attn_case(dev, batch, heads, L, 31)
+    nb = max(1, 200 // heads)
+    assert ops.self_attn_plan(batch, heads, L)[0] and not ops.self_attn_plan(nb, heads, L)[0]
+    dr = ops.Drop(p, 1234, 7) if p > 0 else None
+    o, lse = torch.full((batch * L, E), float("nan"), device=dev), torch.full((batch * heads * L,), float("nan"), device=dev)
+    ops.self_attn_fwd(qkv, seg, o, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, lse=lse, drop=dr)
+    op = ops.Planes.empty(batch * L, E, dev)
+    ops.self_attn_fwd(qkv, seg, op, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, drop=dr)
+    assert torch.equal(op.buf, ops.split_planes(o, ops.Planes.empty(batch * L, E, dev)).buf)
+    qs = ops.split_planes(x[:nb * L].contiguous(), ops.Planes.empty(nb * L, 3 * E, dev))
+    o2, lse2 = torch.full((nb * L, E), float("nan"), device=dev), torch.full((nb * heads * L,), float("nan"), device=dev)
+    ops.self_attn_fwd(qs, seg[:nb * L].contiguous(), o2, batch=nb, heads=heads, L=L, head_dim=64, scale=0.125, lse=lse2, drop=dr)
+    assert torch.equal(o[:nb * L], o2) and torch.equal(lse[:nb * heads * L], lse2)
+    assert torch.isfinite(o).all() and torch.isfinite(lse).all()
+    if p == 0.0:
+        sl = slice((batch - 3) * L, batch * L)
+        xx = qkv.to_float()[sl].double().cpu()
+        q, k, v = (t.reshape(3, L, heads, 64).transpose(1, 2) for t in xx.split(E, dim=1))
+        mask = (1.0 - (seg[sl].view(3, 1, 1, L) > 0).double().cpu()) * -10000.0
+        ref = (torch.softmax(q @ k.transpose(-2, -1) / 8.0 + mask, dim=-1) @ v).transpose(1, 2).reshape(3 * L, E)
+        assert (o[sl].double().cpu() - ref).abs().max() < 2e-5                   # measured 1.1e-6 - 2.8e-6
+
+
+@pytest.mark.parametrize("batch,heads,L,p", [(300, 4, 97, 0.1), (40, 8, 224, 0.0), (256, 2, 33, 0.1), (64, 12, 196, 0.1)])
+def test_streaming_attention_backward_matches_recomputing_kernels_and_fp64(dev, batch, heads, L, p):
+    """lr2_self_attn_bwd given the forward's output planes and log-sum-exp (ABI 19: P = exp(S - lse), D = sum_d dO O, persistent 16-wave
+    kernels with half-by-half LDS-DMA refill) against the recomputing kernels (o = None) on the same inputs with the forward's dropout
+    mask -- relative L2 < 2e-5 per gradient (measured 1.9e-6 - 3.5e-6: D is summed over 64 head columns instead of L keys), D itself
+    < 1e-4 -- and, in eval mode, against fp64 autograd of the reference expression (multi_headed_attn.py:61-74)."""
+    ops, E, qkv, seg, g, _ = _attn_case(dev, batch, heads, L, 47)
+    assert ops.self_attn_plan(batch, heads, L)[1]
+    dr = ops.Drop(p, 4321, 3) if p > 0 else None
+    o, lse = ops.Planes.empty(batch * L, E, dev), torch.full((batch * heads * L,), float("nan"), device=dev)
+    ops.self_attn_fwd(qkv, seg, o, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, lse=lse, drop=dr)
+    do = ops.split_planes(torch.randn(batch * L, E, generator=g).to(dev), ops.Planes.empty(batch * L, E, dev))
+    d_new, d_old = ops.Planes.empty(batch * L, 3 * E, dev), ops.Planes.empty(batch * L, 3 * E, dev)
+    d_new.buf.fill_(0x7fc0)                                                     # bf16 NaN: every element must be written
+    ws1, ws2, ws3 = (torch.empty(batch * heads * L, device=dev) for _ in range(3))
+    lse_in = lse.clone()
+    ops.self_attn_bwd(qkv, do, seg, d_new, lse_in, ws1, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, drop=dr, o=o)
+    assert torch.equal(lse_in, lse)                                             # an input: untouched
+    ops.self_attn_bwd(qkv, do, seg, d_old, ws2, ws3, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, drop=dr)
+    gn, go = d_new.to_float(), d_old.to_float()
+    assert torch.isfinite(gn).all()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())      # noqa: E731
+    for i, name in enumerate(("dQ", "dK", "dV")):
+        assert rel(gn[:, i * E:(i + 1) * E], go[:, i * E:(i + 1) * E]) < 2e-5, name
+    assert rel(lse, ws2) < 1e-6 and rel(ws1, ws3) < 1e-4
+    if p == 0.0:
+        sl = slice((batch - 2) * L, batch * L)
+        xx = qkv.to_float()[sl].double().cpu().requires_grad_(True)
+        q, k, v = (t.reshape(2, L, heads, 64).transpose(1, 2) for t in xx.split(E, dim=1))
+        mask = (1.0 - (seg[sl].view(2, 1, 1, L) > 0).double().cpu()) * -10000.0
+        out = (torch.softmax(q @ k.transpose(-2, -1) / 8.0 + mask, dim=-1) @ v).transpose(1, 2).reshape(2 * L, E)
+        out.backward(do.to_float()[sl].double().cpu())
+        assert rel(gn[sl].cpu(), xx.grad) < 2e-5                                # measured 4.9e-6
