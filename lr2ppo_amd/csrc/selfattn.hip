@@ -78,6 +78,12 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   asm volatile("" : "+v"(a));
   return a;
 }
+// A copy of a lane-varying value the optimiser cannot see through: what is derived from it inside a loop is RE-derived every
+// trip (a few integer instructions) instead of being hoisted and kept live -- or spilled -- across the whole persistent loop.
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
 __device__ __forceinline__ bf16x8_t lds_ld16(uint32_t a) {
   return *(__attribute__((address_space(3))) const bf16x8_t*)(uintptr_t)a;
 }
@@ -225,9 +231,11 @@ __device__ __forceinline__ void attn_phase_b(const char* sV, float* slab, const 
         const int qr = sub * 16 + r;
         if (qr < L && (!(LR2_SA_ABLATE & 64) || slab[r] == 12345.f)) {
           const float4 v = *reinterpret_cast<const float4*>(slab + r * (32 + 4) + c);
-          const size_t off = (row0 + qr) * (size_t)ld_o + col0 + 32 * half + c;
-          if (O) *reinterpret_cast<float4*>(O + off) = v;
-          if (Oh) store_planes4(Oh + off, o_lo_off, v);
+          // uniform 64-bit base + 32-bit lane offset: the stores take the scalar-base form (no 64-bit address registers per lane)
+          const size_t ubase = row0 * (size_t)ld_o + col0 + 32 * half;
+          const uint32_t loff = (uint32_t)qr * (uint32_t)ld_o + (uint32_t)c;
+          if (O) *reinterpret_cast<float4*>(O + ubase + loff) = v;
+          if (Oh) store_planes4(Oh + ubase + loff, o_lo_off, v);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -515,15 +523,17 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_persist_kernel(const 
   const int sub = wave;
   // query fragments of this wave's sub-tile of the pair whose first row is row0_ (B operand of S^T = K Q^T)
   auto load_q = [&](size_t row0_, int col0_, bf16x8_t (&fh)[2], bf16x8_t (&fl)[2]) {
-    const int q_row_ = sub * 16 + qn;
+    const int lane_ = opaque(lane);
+    const int q_row_ = sub * 16 + (lane_ & 15);
     const bool ok = q_row_ < L;
-    const size_t o = (row0_ + (ok ? q_row_ : 0)) * (size_t)ld + col0_ + 8 * g;
+    const bf16_t* ub = Qh + row0_ * (size_t)ld + col0_;                      // uniform
+    const uint32_t o = (uint32_t)(ok ? q_row_ : 0) * (uint32_t)ld + 8u * (uint32_t)(lane_ >> 4);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       u32x4_t a = {0, 0, 0, 0}, c = a;
       if (ok) {
-        a = *reinterpret_cast<const u32x4_t*>(Qh + o + 32 * ks);
-        c = *reinterpret_cast<const u32x4_t*>(Qh + o + 32 * ks + lo_off);
+        a = *reinterpret_cast<const u32x4_t*>(ub + o + 32 * ks);
+        c = *reinterpret_cast<const u32x4_t*>(ub + lo_off + o + 32 * ks);
       }
       fh[ks] = __builtin_bit_cast(bf16x8_t, a);
       fl[ks] = __builtin_bit_cast(bf16x8_t, c);
@@ -536,7 +546,7 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_persist_kernel(const 
     const float* mask = sMask + (it & 1) * LP;
     bf16x8_t ph[NT / 2], pl[NT / 2];
     float inv = 0.f;
-    if (!(LR2_SA_ABLATE & 2)) attn_phase_a<NT, DROP>(sK, mask, qh, ql, sub, lane, L, b, h, heads, scale, lse, dr, ph, pl, inv);
+    if (!(LR2_SA_ABLATE & 2)) attn_phase_a<NT, DROP>(sK, mask, qh, ql, sub, opaque(lane), L, b, h, heads, scale, lse, dr, ph, pl, inv);
     phase_barrier();
     const int pn = p + gridDim.x;
     const bool more = pn < n_pairs;
@@ -545,7 +555,7 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_persist_kernel(const 
     // the next pair's queries are requested once the probability registers are dead; they travel under the output's stores and the
     // wait at the barrier
     auto next_q = [&]() { if (more) load_q(row0n, hn * HD, qh, ql); };
-    if (!(LR2_SA_ABLATE & 2)) attn_phase_b<NT, true>(sV, slab, ph, pl, inv, sub, lane, L, row0, col0, O, Oh, o_lo_off, ld_o, next_q);
+    if (!(LR2_SA_ABLATE & 2)) attn_phase_b<NT, true>(sV, slab, ph, pl, inv, sub, opaque(lane), L, row0, col0, O, Oh, o_lo_off, ld_o, next_q);
     if (!more) break;
     phase_barrier();
     p = pn; b = bn; h = hn; row0 = row0n; col0 = hn * HD;
@@ -811,6 +821,21 @@ __device__ __forceinline__ void load_frags(const bf16_t* hi_plane, size_t lo_off
     if (ok) {
       a = *reinterpret_cast<const u32x4_t*>(hi_plane + elem_off + 32 * ks);
       c = *reinterpret_cast<const u32x4_t*>(hi_plane + elem_off + 32 * ks + lo_off);
+    }
+    fh[ks] = __builtin_bit_cast(bf16x8_t, a);
+    fl[ks] = __builtin_bit_cast(bf16x8_t, c);
+  }
+}
+
+// the same with a wave-uniform base pointer + a 32-bit lane offset (scalar-base loads: no 64-bit address registers per lane)
+__device__ __forceinline__ void load_frags_u(const bf16_t* ubase, size_t lo_off, uint32_t lane_off, bool ok, bf16x8_t (&fh)[2],
+                                             bf16x8_t (&fl)[2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    u32x4_t a = {0, 0, 0, 0}, c = a;
+    if (ok) {
+      a = *reinterpret_cast<const u32x4_t*>(ubase + lane_off + 32 * ks);
+      c = *reinterpret_cast<const u32x4_t*>(ubase + lo_off + lane_off + 32 * ks);
     }
     fh[ks] = __builtin_bit_cast(bf16x8_t, a);
     fl[ks] = __builtin_bit_cast(bf16x8_t, c);
@@ -1155,7 +1180,7 @@ __device__ __forceinline__ void store_tile_planes_half(const f32x4_t (&o)[4], fl
       const int r = pass * 8 + (lane >> 3), c = (lane & 7) * 4;
       if (row_first + r < rows_valid) {
         const float4 v = *reinterpret_cast<const float4*>(slab + r * (32 + 4) + c);
-        store_planes4(dst_hi + base + (size_t)(row_first + r) * row_stride + 32 * half + c, lo_off, v);
+        store_planes4(dst_hi + base + 32 * half + ((uint32_t)(row_first + r) * (uint32_t)row_stride + (uint32_t)c), lo_off, v);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1289,18 +1314,19 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_bwd_dq_persist_kernel
   // this wave's rows of pair pp: Q and dO fragments, D = sum_d dO O, lse
   auto fetch = [&](int pp) {
     const int b = pp / heads, h = pp - b * heads;
-    const size_t row = (size_t)b * L + (q_ok ? q_row : 0);
+    const size_t row0_ = (size_t)b * L;
+    const uint32_t lr = (uint32_t)(q_ok ? q_row : 0);
     bf16x8_t oh[2], ol[2];
-    load_frags(A.q, A.lo_off, row * (size_t)A.ld + h * HD + 8 * g, q_ok, qh, ql);
-    load_frags(A.go, A.do_lo_off, row * (size_t)A.ld_do + h * HD + 8 * g, q_ok, gh, gl);
-    load_frags(A.o, A.o_lo_off, row * (size_t)A.ld_o + h * HD + 8 * g, q_ok, oh, ol);
-    const size_t si = ((size_t)b * heads + h) * L + (q_ok ? q_row : 0);
-    lse2 = q_ok ? A.lse[si] * LOG2E : 0.f;
+    load_frags_u(A.q + row0_ * (size_t)A.ld + h * HD, A.lo_off, lr * (uint32_t)A.ld + 8u * g, q_ok, qh, ql);
+    load_frags_u(A.go + row0_ * (size_t)A.ld_do + h * HD, A.do_lo_off, lr * (uint32_t)A.ld_do + 8u * g, q_ok, gh, gl);
+    load_frags_u(A.o + row0_ * (size_t)A.ld_o + h * HD, A.o_lo_off, lr * (uint32_t)A.ld_o + 8u * g, q_ok, oh, ol);
+    const size_t si0 = (size_t)pp * L;
+    lse2 = q_ok ? A.lse[si0 + lr] * LOG2E : 0.f;
     float d = frag_dot(gh[0], gl[0], oh[0], ol[0]) + frag_dot(gh[1], gl[1], oh[1], ol[1]);
     d += __shfl_xor(d, 16, 64);
     d += __shfl_xor(d, 32, 64);
     dD = d;
-    if (g == 0 && q_ok) A.dsum[si] = d;
+    if (g == 0 && q_ok) A.dsum[si0 + lr] = d;
   };
   fetch(p);
   phase_barrier();
@@ -1361,6 +1387,11 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_bwd_dkv_persist_kerne
   float* sLse = reinterpret_cast<float*>(smem + 4 * PLANE);   // [LP] lse * log2(e); +inf for padded queries (P = 0)
   float* sD = sLse + LP;                                      // [LP]
   float* sOut = sD + LP;                                      // [PS_MAX_SUB waves][16][32 + 4]
+  // DROP: the pair's dropout decisions, one byte per (sub-tile, 32-query block, lane) = the 8 (query, key) elements that lane owns in
+  // that block, written by the mover waves one pair ahead (two buffers): the hashes cost the compute waves nothing -- neither issue
+  // slots nor the registers their temporaries would need beside the fragments
+  constexpr int KEEP_BYTES = PS_MAX_SUB * NB * 64;
+  uint8_t* sKeep = reinterpret_cast<uint8_t*>(sOut + PS_MAX_SUB * 16 * (32 + 4));      // [2][KEEP_BYTES]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int heads = A.heads, L = A.L, n_pairs = A.n_pairs;
@@ -1376,8 +1407,29 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_bwd_dkv_persist_kerne
     const uint32_t q_row_bytes = (uint32_t)A.ld * 2u, g_row_bytes = (uint32_t)A.ld_do * 2u;
     auto q_off = [&](int pp) { const int b = pp / heads, h = pp - b * heads; return (uint32_t)(((size_t)b * L * A.ld + h * HD) * 2); };
     auto g_off = [&](int pp) { const int b = pp / heads, h = pp - b * heads; return (uint32_t)(((size_t)b * L * A.ld_do + h * HD) * 2); };
+    // element index of (query q, key) of pair pp = pp L pitch + q pitch + key: pp L pitch is a multiple of 4 and the hash reads the low
+    // 32 bits of (index >> 1) only, so everything per lane is 32-bit arithmetic (the same decisions as dropout_keep on the 64-bit index)
+    auto write_keep = [&](int pp, uint8_t* dst) {
+      const uint32_t pitch32 = (uint32_t)mask_pitch(L);
+      const uint32_t pair_half32 = (uint32_t)(((uint64_t)pp * (uint64_t)L * mask_pitch(L)) >> 1);
+      for (int i = mtid; i < n_sub * NB * 64; i += 64 * PS_MOVERS) {
+        const int sub_ = i / (NB * 64), rem = i - sub_ * (NB * 64), u = rem >> 6, ln = rem & 63;
+        const int key_ = sub_ * 16 + (ln & 15);
+        const uint32_t col = (uint32_t)(key_ < L ? key_ : 0);
+        uint32_t keep = 0;
+#pragma unroll
+        for (int e8 = 0; e8 < 8; ++e8) {
+          const int q = 32 * u + 16 * (e8 >> 2) + 4 * (ln >> 4) + (e8 & 3);
+          const uint32_t x = (uint32_t)(q < L ? q : 0) * pitch32 + col;
+          const uint32_t hsh = dropout_hash(A.dr.key, (uint64_t)(pair_half32 + (x >> 1)));
+          keep |= (uint32_t)(((x & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= A.dr.thr) << e8;
+        }
+        dst[i] = (uint8_t)keep;
+      }
+    };
     dma_rows_k<NT>(q_hi, q_lo, sQ, lane, j0, Halves<NT>::J_END, PS_MOVERS, q_off(p), q_row_bytes, L);
     dma_rows_k<NT>(g_hi, g_lo, sG, lane, j0, Halves<NT>::J_END, PS_MOVERS, g_off(p), g_row_bytes, L);
+    if (DROP && A.dr.thr) write_keep(p, sKeep);
     for (int j = mtid; j < LP; j += 64 * PS_MOVERS) {
       const size_t si = (size_t)p * L + j;
       sLse[j] = j < L ? A.lse[si] * LOG2E : INFINITY;
@@ -1385,13 +1437,14 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_bwd_dkv_persist_kerne
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     phase_barrier();
-    for (;;) {
+    for (int it = 0;; ++it) {
       const int pn = p + gridDim.x;
       const bool more = pn < n_pairs;
       phase_barrier();                                   // mid
       if (more) {
         dma_rows_k<NT>(q_hi, q_lo, sQ, lane, j0, Halves<NT>::J_MID, PS_MOVERS, q_off(pn), q_row_bytes, L);
         dma_rows_k<NT>(g_hi, g_lo, sG, lane, j0, Halves<NT>::J_MID, PS_MOVERS, g_off(pn), g_row_bytes, L);
+        if (DROP && A.dr.thr) write_keep(pn, sKeep + ((it + 1) & 1) * KEEP_BYTES);     // that buffer's readers finished a pair ago
         float l2[MK], dd[MK];
 #pragma unroll
         for (int i = 0; i < MK; ++i) {
@@ -1449,56 +1502,44 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_bwd_dkv_persist_kerne
   const bool k_ok = key < L;
   float* slab = sOut + wave * 16 * (32 + 4);
   const float scale = A.scale, scale2 = A.scale * LOG2E;
+  // fragment / transposed-read bases into sQ; the same row of sG is 2 * PLANE bytes further (added to the block's scalar offset)
   const uint32_t qb[2] = {lds_addr(sQ + d_off(kn, g)), lds_addr(sQ + d_off(kn, g + 4))};
-  const uint32_t gb[2] = {lds_addr(sG + d_off(kn, g)), lds_addr(sG + d_off(kn, g + 4))};
-  const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
-  uint32_t qtb[4], gtb[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    qtb[n] = lds_addr(sQ + d_off(4 * g + tq, 2 * n + (tp >> 1)) + 8 * (tp & 1));
-    gtb[n] = lds_addr(sG + d_off(4 * g + tq, 2 * n + (tp >> 1)) + 8 * (tp & 1));
-  }
+  const uint32_t sq0 = lds_addr(sQ);
   bf16x8_t kh[2], kl[2], vh[2], vl[2];
   float kmask2 = 0.f;
   auto fetch = [&](int pp) {
     const int b = pp / heads, h = pp - b * heads;
-    const size_t row = (size_t)b * L + (k_ok ? key : 0);
-    load_frags(A.k, A.lo_off, row * (size_t)A.ld + h * HD + 8 * g, k_ok, kh, kl);
-    load_frags(A.v, A.lo_off, row * (size_t)A.ld + h * HD + 8 * g, k_ok, vh, vl);
-    kmask2 = k_ok ? ((A.seg[row] > 0) ? 0.f : -10000.0f * LOG2E) : -INFINITY;
+    const size_t row0_ = (size_t)b * L;
+    const int lane_ = opaque(lane);                       // addresses re-derived per pair, not kept live across the block loops
+    const int key_ = sub * 16 + (lane_ & 15);
+    const bool ok_ = key_ < L;
+    const uint32_t lr = (uint32_t)(ok_ ? key_ : 0), lo8 = 8u * (uint32_t)(lane_ >> 4);
+    load_frags_u(A.k + row0_ * (size_t)A.ld + h * HD, A.lo_off, lr * (uint32_t)A.ld + lo8, ok_, kh, kl);
+    load_frags_u(A.v + row0_ * (size_t)A.ld + h * HD, A.lo_off, lr * (uint32_t)A.ld + lo8, ok_, vh, vl);
+    kmask2 = ok_ ? ((A.seg[row0_ + lr] > 0) ? 0.f : -10000.0f * LOG2E) : -INFINITY;
   };
   fetch(p);
   phase_barrier();
-  for (;;) {
+  for (int it = 0;; ++it) {
     const int b = p / heads, h = p - b * heads;
     const size_t row0 = (size_t)b * L;
-    // mask element of (query q, this lane's key): (((b heads + h) L + q) pitch + key
-    const uint64_t pitch = mask_pitch(L);
-    const uint64_t drow_k = ((uint64_t)b * heads + h) * (uint64_t)L * pitch + (uint64_t)(k_ok ? key : 0);
+    const uint8_t* keep_buf = sKeep + (it & 1) * KEEP_BYTES;
     f32x4_t dv[4], dk[4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) dv[n] = dk[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // one 32-query block: rolled loops (an unrolled pair lets the scheduler hoist seven blocks' worth of hashes and fragments)
     auto block = [&](int u) {
-      const uint32_t uo = 4096u * (uint32_t)u;
-      // the block's 8 dropout decisions as one bit mask, taken before the fragments are live
+      const uint32_t uo = 4096u * (uint32_t)u, ug = uo + 2u * PLANE;          // block offsets into sQ / sG (uniform)
+      // the block's 8 dropout decisions: one byte the mover waves left in LDS
       uint32_t keep = 0xffu;
-      if (DROP && A.dr.thr) {
-        keep = 0;
-#pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) {
-          const int q = 32 * u + 16 * (e8 >> 2) + 4 * g + (e8 & 3);
-          keep |= (uint32_t)dropout_keep(A.dr.key, drow_k + (uint64_t)(q < L ? q : 0) * pitch, A.dr.thr) << e8;
-        }
-        asm volatile("" : "+v"(keep));
-      }
+      if (DROP && A.dr.thr) keep = keep_buf[(sub * NB + u) * 64 + opaque(lane)];
       float pd[8], ds[8];
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         f32x4_t a = {0.f, 0.f, 0.f, 0.f}, d = a;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const uint32_t aq = qb[ks] + uo + 2048 * half, ag = gb[ks] + uo + 2048 * half;
+          const uint32_t aq = qb[ks] + uo + 2048 * half, ag = qb[ks] + ug + 2048 * half;
           a = mfma3(lds_ld16(aq), lds_ld16(aq + PLANE), kh[ks], kl[ks], a);   // S[query 32u + 16 half + 4g + r][key kn]
           d = mfma3(lds_ld16(ag), lds_ld16(ag + PLANE), vh[ks], vl[ks], d);   // dPd
         }
@@ -1513,12 +1554,21 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_bwd_dkv_persist_kerne
           ds[4 * half + r] = pr * (d[r] * m - ddv[r]) * scale;
         }
       }
+      // transposed-read bases, re-derived per block from the lane number (a dozen integer instructions against four registers held
+      // live across both loops): row 4g + tq of the block, 16-B unit 2n + (tp >> 1), 8-B half tp & 1
+      uint32_t qtb[4];
+      {
+        const int lane_ = opaque(lane);
+        const int tq = (lane_ >> 2) & 3, tp = lane_ & 3, rr = 4 * (lane_ >> 4) + tq;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) qtb[n] = sq0 + (uint32_t)(d_off(rr, 2 * n + (tp >> 1)) + 8 * (tp & 1));
+      }
       {
         bf16x8_t ph, pl;
         split8(pd, ph, pl);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-          const uint32_t ag = gtb[n] + uo;
+          const uint32_t ag = qtb[n] + ug;
           dv[n] = mfma3(ph, pl, lds_tr_pair(ag, ag + 2048), lds_tr_pair(ag + PLANE, ag + 2048 + PLANE), dv[n]);
         }
       }
@@ -1541,8 +1591,8 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_bwd_dkv_persist_kerne
     const bool more = pn < n_pairs;
     if (more) fetch(pn);
     const size_t base = row0 * (size_t)A.ld_d + h * HD;
-    store_tile_planes_half(dk, slab, lane, sub * 16, L, A.dk, A.d_lo_off, (size_t)A.ld_d, base);
-    store_tile_planes_half(dv, slab, lane, sub * 16, L, A.dv, A.d_lo_off, (size_t)A.ld_d, base);
+    store_tile_planes_half(dk, slab, opaque(lane), sub * 16, L, A.dk, A.d_lo_off, (size_t)A.ld_d, base);
+    store_tile_planes_half(dv, slab, opaque(lane), sub * 16, L, A.dv, A.d_lo_off, (size_t)A.ld_d, base);
     phase_barrier();                                     // end
     if (!more) break;
     p = pn;
@@ -1942,11 +1992,12 @@ int launch_bwd_persist(const AttnArgs& a, const bf16_t* go, size_t do_lo_off, in
   constexpr int LP = 16 * NT;
   const size_t lds1 = (size_t)4 * LP * ROW_B + (size_t)LP * 4 + (size_t)PS_MAX_SUB * 16 * (32 + 4) * 4;
   const size_t lds2 = (size_t)4 * LP * ROW_B + (size_t)LP * 8 + (size_t)PS_MAX_SUB * 16 * (32 + 4) * 4;
+  const size_t lds2_drop = lds2 + (size_t)2 * PS_MAX_SUB * (NT / 2) * 64;       // + the dropout decision bytes of two pairs
   static bool d1 = false, d2 = false, d3 = false, d4 = false;
   if (allow_lds_once(self_attn_bwd_dq_persist_kernel<NT, false>, lds1, d1, "self_attn_bwd_dq(persistent)")) return LR2_ERR_LAUNCH;
   if (allow_lds_once(self_attn_bwd_dq_persist_kernel<NT, true>, lds1, d2, "self_attn_bwd_dq(persistent, dropout)")) return LR2_ERR_LAUNCH;
   if (allow_lds_once(self_attn_bwd_dkv_persist_kernel<NT, false>, lds2, d3, "self_attn_bwd_dkv(persistent)")) return LR2_ERR_LAUNCH;
-  if (allow_lds_once(self_attn_bwd_dkv_persist_kernel<NT, true>, lds2, d4, "self_attn_bwd_dkv(persistent, dropout)")) return LR2_ERR_LAUNCH;
+  if (allow_lds_once(self_attn_bwd_dkv_persist_kernel<NT, true>, lds2_drop, d4, "self_attn_bwd_dkv(persistent, dropout)")) return LR2_ERR_LAUNCH;
   BwdArgs A{};
   A.q = a.q; A.k = a.k; A.v = a.v; A.lo_off = a.lo_off; A.ld = a.ld;
   A.go = go; A.do_lo_off = do_lo_off; A.ld_do = ld_do;
@@ -1959,7 +2010,7 @@ int launch_bwd_persist(const AttnArgs& a, const bf16_t* go, size_t do_lo_off, in
   if (a.dr.thr) {
     LR2_LAUNCH((self_attn_bwd_dq_persist_kernel<NT, true>), dim3(grid), dim3(64 * PS_WAVES), lds1, a.stream, A);
     if (lr2_launch_status("lr2_self_attn_bwd(dq, persistent)")) return LR2_ERR_LAUNCH;
-    LR2_LAUNCH((self_attn_bwd_dkv_persist_kernel<NT, true>), dim3(grid), dim3(64 * PS_WAVES), lds2, a.stream, A);
+    LR2_LAUNCH((self_attn_bwd_dkv_persist_kernel<NT, true>), dim3(grid), dim3(64 * PS_WAVES), lds2_drop, a.stream, A);
   } else {
     LR2_LAUNCH((self_attn_bwd_dq_persist_kernel<NT, false>), dim3(grid), dim3(64 * PS_WAVES), lds1, a.stream, A);
     if (lr2_launch_status("lr2_self_attn_bwd(dq, persistent)")) return LR2_ERR_LAUNCH;
