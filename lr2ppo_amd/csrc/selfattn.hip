@@ -22,7 +22,8 @@ namespace {
 
 #ifndef LR2_SA_ABLATE
 #define LR2_SA_ABLATE 0         // diagnostics (tools/dbg/attn_ablate.py builds variants of this file): bit 1 no K / V global loads, 2 no
-#endif                          // sub-tile work, 4 no softmax arithmetic, 8 no lo split of P, 16 no P V product, 32 no S product, 64 no store
+#endif                          // sub-tile work, 4 no softmax arithmetic, 8 no lo split of P, 16 no P V product, 32 no S product, 64 no store,
+                                // 128 no fragment loads of the persistent backward's compute waves (bits 1, 64, 128 apply to the backward)
 constexpr int HD = 64;          // head dim
 constexpr int ROW_B = HD * 2;   // bytes of one K / V row in one LDS plane
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
@@ -1137,7 +1138,7 @@ __device__ __forceinline__ void dma_rows_k(const __amdgpu_buffer_rsrc_t& hi, con
                                            int j_begin, int j_end, int jstep, uint32_t pair_off, uint32_t row_bytes, int L) {
   constexpr int LP = 16 * NT, PLANE = LP * ROW_B;
   const int rl = lane >> 3, sl = lane & 7;
-  for (int j = j_begin; j < j_end; j += jstep) {
+  for (int j = j_begin; j < ((LR2_SA_ABLATE & 1) ? 0 : j_end); j += jstep) {
     const int r = 8 * j + rl;
     const int u = sl ^ d_swz(r);
     const uint32_t v = r < L ? pair_off + (uint32_t)r * row_bytes + (uint32_t)u * 16u : 0xFFFFFF00u;
@@ -1178,7 +1179,7 @@ __device__ __forceinline__ void store_tile_planes_half(const f32x4_t (&o)[4], fl
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int r = pass * 8 + (lane >> 3), c = (lane & 7) * 4;
-      if (row_first + r < rows_valid) {
+      if (row_first + r < rows_valid && (!(LR2_SA_ABLATE & 64) || slab[r] == 12345.f)) {
         const float4 v = *reinterpret_cast<const float4*>(slab + r * (32 + 4) + c);
         store_planes4(dst_hi + base + 32 * half + ((uint32_t)(row_first + r) * (uint32_t)row_stride + (uint32_t)c), lo_off, v);
       }
@@ -1317,9 +1318,10 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_bwd_dq_persist_kernel
     const size_t row0_ = (size_t)b * L;
     const uint32_t lr = (uint32_t)(q_ok ? q_row : 0);
     bf16x8_t oh[2], ol[2];
-    load_frags_u(A.q + row0_ * (size_t)A.ld + h * HD, A.lo_off, lr * (uint32_t)A.ld + 8u * g, q_ok, qh, ql);
-    load_frags_u(A.go + row0_ * (size_t)A.ld_do + h * HD, A.do_lo_off, lr * (uint32_t)A.ld_do + 8u * g, q_ok, gh, gl);
-    load_frags_u(A.o + row0_ * (size_t)A.ld_o + h * HD, A.o_lo_off, lr * (uint32_t)A.ld_o + 8u * g, q_ok, oh, ol);
+    const bool ld_ok = q_ok && !(LR2_SA_ABLATE & 128);
+    load_frags_u(A.q + row0_ * (size_t)A.ld + h * HD, A.lo_off, lr * (uint32_t)A.ld + 8u * g, ld_ok, qh, ql);
+    load_frags_u(A.go + row0_ * (size_t)A.ld_do + h * HD, A.do_lo_off, lr * (uint32_t)A.ld_do + 8u * g, ld_ok, gh, gl);
+    load_frags_u(A.o + row0_ * (size_t)A.ld_o + h * HD, A.o_lo_off, lr * (uint32_t)A.ld_o + 8u * g, ld_ok, oh, ol);
     const size_t si0 = (size_t)pp * L;
     lse2 = q_ok ? A.lse[si0 + lr] * LOG2E : 0.f;
     float d = frag_dot(gh[0], gl[0], oh[0], ol[0]) + frag_dot(gh[1], gl[1], oh[1], ol[1]);
@@ -1514,8 +1516,9 @@ __global__ __launch_bounds__(64 * PS_WAVES) void self_attn_bwd_dkv_persist_kerne
     const int key_ = sub * 16 + (lane_ & 15);
     const bool ok_ = key_ < L;
     const uint32_t lr = (uint32_t)(ok_ ? key_ : 0), lo8 = 8u * (uint32_t)(lane_ >> 4);
-    load_frags_u(A.k + row0_ * (size_t)A.ld + h * HD, A.lo_off, lr * (uint32_t)A.ld + lo8, ok_, kh, kl);
-    load_frags_u(A.v + row0_ * (size_t)A.ld + h * HD, A.lo_off, lr * (uint32_t)A.ld + lo8, ok_, vh, vl);
+    const bool ld_ok = ok_ && !(LR2_SA_ABLATE & 128);
+    load_frags_u(A.k + row0_ * (size_t)A.ld + h * HD, A.lo_off, lr * (uint32_t)A.ld + lo8, ld_ok, kh, kl);
+    load_frags_u(A.v + row0_ * (size_t)A.ld + h * HD, A.lo_off, lr * (uint32_t)A.ld + lo8, ld_ok, vh, vl);
     kmask2 = ok_ ? ((A.seg[row0_ + lr] > 0) ? 0.f : -10000.0f * LOG2E) : -INFINITY;
   };
   fetch(p);

@@ -12,7 +12,8 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 OUT = os.path.join(REPO, "tools", "dbg", "micro", "build")
-SETTINGS = [0, 1, 2, 3, 4, 8, 12, 16, 32, 48, 64, 65, 4 | 8 | 64, 1 | 4 | 8 | 64]
+BWD = "--bwd" in sys.argv      # the persistent backward: bits 1 (no LDS-DMA), 64 (no stores), 128 (no fragment loads of the compute waves)
+SETTINGS = [0, 1, 64, 128, 129, 193] if BWD else [0, 1, 2, 3, 4, 8, 12, 16, 32, 48, 64, 65, 4 | 8 | 64, 1 | 4 | 8 | 64]
 EXTRA = [a for a in sys.argv[1:] if a.startswith("-D")]
 
 
@@ -46,6 +47,35 @@ def main():
     q, k, v = ops._qkv_ptrs(qkv, E)
     sig = _native.SIGNATURES["lr2_self_attn_fwd"]
     res = {}
+    if BWD:
+        do = ops.split_planes(torch.randn(batch * L, E, device=dev, generator=g), ops.Planes.empty(batch * L, E, dev))
+        dqkv = ops.Planes.empty(batch * L, 3 * E, dev)
+        lse, dsum = torch.zeros(batch * heads * L, device=dev), torch.zeros(batch * heads * L, device=dev)
+        ops.self_attn_fwd(qkv, seg, o, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, lse=lse)
+        dq, dk, dv = ops._qkv_ptrs(dqkv, E)
+        sigb = _native.SIGNATURES["lr2_self_attn_bwd"]
+        p_drop = 0.1 if "--drop" in sys.argv else 0.0
+        for rep in range(2):
+            for kset in SETTINGS:
+                lib = C.CDLL(os.path.join(OUT, f"libsa_{kset}.so"))
+                fn = lib.lr2_self_attn_bwd
+                fn.argtypes, fn.restype = sigb, C.c_int
+                call = lambda: fn(q, k, v, qkv.lo_off, qkv.cols, do.data_ptr(), do.lo_off, do.cols, seg.data_ptr(), dq, dk, dv,  # noqa: E731
+                                  dqkv.lo_off, dqkv.cols, o.data_ptr(), o.lo_off, o.cols, lse.data_ptr(), dsum.data_ptr(), p_drop, 7, 1,
+                                  batch, heads, L, 64, 0.125, torch.cuda.current_stream().cuda_stream)
+                for _ in range(2):
+                    assert call() == 0
+                torch.cuda.synchronize()
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                for _ in range(6):
+                    call()
+                e.record()
+                torch.cuda.synchronize()
+                res.setdefault(kset, []).append(s.elapsed_time(e) / 6 * 1e3)
+        for kset in SETTINGS:
+            print(f"backward (dQ + dK/dV kernels), dropout {p_drop}, ablate {kset:3d}: {min(res[kset]):7.1f} us", flush=True)
+        return
     for rep in range(2):
         for kset in SETTINGS:
             lib = C.CDLL(os.path.join(OUT, f"libsa_{kset}.so"))
