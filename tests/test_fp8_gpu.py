@@ -244,6 +244,31 @@ def test_bf16_attention_matches_fp64_on_its_own_operands(dev, batch, heads, L):
         ops.self_attn_fwd_bf16(qkv.to(dev), seg.to(dev).view(-1), batch=batch, heads=heads, L=300, head_dim=64, scale=0.125, out=out)
 
 
+@pytest.mark.parametrize("batch,heads,L", [(80, 4, 257), (300, 2, 197), (520, 1, 40)])
+def test_persistent_bf16_attention_equals_the_one_pair_kernel(dev, batch, heads, L):
+    """At least one (sequence, head) pair per CU: lr2_self_attn_fwd_bf16 runs the persistent 12-wave kernel (K / V by LDS-DMA from two mover
+    waves under the compute); the first sequences alone (fewer pairs than CUs) run the one-pair kernel on the same rows: fp32 context
+    and MX-FP8 bytes / scales agree BIT FOR BIT (same arithmetic in the same order)."""
+    from lr2ppo_amd import ops
+    g = torch.Generator().manual_seed(3 * L + heads)
+    E = heads * 64
+    qkv = (torch.randn(batch * L, 3 * E, generator=g) * 0.6).to(torch.bfloat16).to(dev)
+    seg = (torch.rand(batch, L, generator=g) > 0.15).long()
+    seg[:, 0] = 1
+    seg = seg.view(-1).to(dev)
+    out, mx = torch.full((batch * L, E), float("nan"), device=dev), ops.Mx8.empty(batch * L, E, dev)
+    ops.self_attn_fwd_bf16(qkv, seg, batch=batch, heads=heads, L=L, head_dim=64, scale=0.125, out=out, out_mx=mx)
+    nb = max(1, 120 // heads)
+    out2, mx2 = torch.full((nb * L, E), float("nan"), device=dev), ops.Mx8.empty(nb * L, E, dev)
+    ops.self_attn_fwd_bf16(qkv[:nb * L].contiguous(), seg[:nb * L].contiguous(), batch=nb, heads=heads, L=L, head_dim=64, scale=0.125, out=out2,
+                           out_mx=mx2)
+    assert torch.isfinite(out).all()
+    assert torch.equal(out[:nb * L], out2)
+    assert torch.equal(mx.q.view(-1)[:nb * L * E], mx2.q.view(-1)) and torch.equal(mx.s.view(-1)[:nb * L * E // 32], mx2.s.view(-1))
+    want = ops.quant_mxfp8(out)
+    assert torch.equal(mx.s, want.s) and torch.equal(mx.q, want.q)
+
+
 def test_product_can_leave_as_one_bf16_plane(dev):
     """gemm_mxfp8(out_bf16=...): the round-to-nearest bf16 of the fp32 row it would have stored, on both product kernels."""
     from lr2ppo_amd import ops
