@@ -118,11 +118,19 @@ def self_launch(gpus: int, argv, script: str = os.path.abspath(__file__)) -> int
     back, or when the line does not report n_gpus == gpus."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import time
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), LR2_BENCH_CHILD="1")
-    p = subprocess.run(launcher_command(gpus, argv, script, port), env=env, stdout=subprocess.PIPE, text=True)
+    for attempt in range(2):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        t0 = time.time()
+        p = subprocess.run(launcher_command(gpus, argv, script, port), env=env, stdout=subprocess.PIPE, text=True)
+        # a rendezvous that dies within seconds (the free port was taken between the probe above and the launcher's bind) is started
+        # once more on another port; a run that fails after it got going is a failure
+        if p.returncode == 0 or time.time() - t0 > 20.0 or attempt == 1:
+            break
+        print(f"[bench] the launcher exited with code {p.returncode} after {time.time() - t0:.1f} s: one more try on another port", file=sys.stderr)
     line = None
     for ln in p.stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
@@ -741,7 +749,8 @@ def main():
                        f"({fb * 16} frames + {fb * a.tags} sequences) and scaled linearly to the batch: {fe:.1f}s -> {total:.1f}s per step")
         out["cpu_baseline"] = {"value": round(1.0 / total, 5), "unit": "PPO steps/s", "cores": r["threads"], "kind": "port",
                                "sample": sample, "head_only_value": round(1.0 / r["total_s"], 5)}
-    print(json.dumps(out))
+    sys.stdout.write(json.dumps(out) + "\n")          # one write: under a launcher the ranks share the pipe
+    sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -33,9 +33,9 @@ def test_self_launch_starts_n_ranks_and_relays_rank0_line(tmp_path, capfd):
         import torch.distributed as dist
         dist.init_process_group("gloo")
         assert os.environ["LR2_BENCH_CHILD"] == "1" and sys.argv[1:] == ["--gpus", "2", "--steps", "3"]
-        print("chatter from rank", dist.get_rank())
+        os.write(1, ("chatter from rank %d" % dist.get_rank() + os.linesep).encode())      # ONE write per line: two ranks share the pipe
         if dist.get_rank() == 0:
-            print(json.dumps({"metric": "ppo_steps_per_sec", "n_gpus": dist.get_world_size(), "value": 1.0}))
+            os.write(1, (json.dumps({"metric": "ppo_steps_per_sec", "n_gpus": dist.get_world_size(), "value": 1.0}) + os.linesep).encode())
         dist.destroy_process_group()
     """)
     assert bench.self_launch(2, ["--gpus", "2", "--steps", "3"], script=s) == 0
