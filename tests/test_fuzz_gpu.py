@@ -26,3 +26,13 @@ def test_randomised_round4_kernels_match_fp64(dev):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "no mismatch" in r.stdout
+
+
+def test_fixed_seed_sweep_of_the_persistent_attention_kernels():
+    """tools/dbg/fuzz_attn_persist.py with a fixed seed: random (batch, heads, L <= 224, masks, dropout) with 1-7 (sequence, head) pairs per
+    workgroup -- persistent forward == the one-pair kernel chunk by chunk (bit for bit), streaming backward within 2e-5 of the recomputing
+    kernels, every element written; the MX-FP8 mode's persistent attention (L <= 288) == its one-pair kernel, bytes and scales."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "dbg", "fuzz_attn_persist.py"), "--n", "12", "--seed", "5"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "no mismatch" in r.stdout
