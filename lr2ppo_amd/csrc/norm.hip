@@ -113,8 +113,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
     const float mean = mean_in[r], rstd = rstd_in[r];
     const size_t doff = mapped_row_offset(r, group, group_stride, D);
-    float4 xh[MAXV], g[MAXV];
+    float4 xh[MAXV], g[MAXV], rgv[MAXV];
     float s1 = 0.f, s2 = 0.f;
+    // the residual gradient is requested with x and dy (it is only added at the end: its latency hides behind the two wave sums)
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int e = (i * 64 + lane) * 4;
+      rgv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < D && resid_grad) rgv[i] = *reinterpret_cast<const float4*>(resid_grad + (size_t)r * D + e);
+    }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int e = (i * 64 + lane) * 4;
@@ -136,14 +143,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
       const int e = (i * 64 + lane) * 4;
       if (e < D) {
         float4 d;
-        d.x = rstd * (g[i].x - c1 - xh[i].x * c2);
-        d.y = rstd * (g[i].y - c1 - xh[i].y * c2);
-        d.z = rstd * (g[i].z - c1 - xh[i].z * c2);
-        d.w = rstd * (g[i].w - c1 - xh[i].w * c2);
+        const float tx = g[i].x - c1 - xh[i].x * c2, ty = g[i].y - c1 - xh[i].y * c2;
+        const float tz = g[i].z - c1 - xh[i].z * c2, tw = g[i].w - c1 - xh[i].w * c2;
         const size_t o = (size_t)r * D + e;
-        if (resid_grad) {
-          const float4 rg = *reinterpret_cast<const float4*>(resid_grad + o);
-          d.x += rg.x; d.y += rg.y; d.z += rg.z; d.w += rg.w;
+        {
+          // product and sum rounded separately, as in rounds 1-3 (there the residual gradient was loaded in a block of its own and the
+          // compiler could not fuse the two; now that the load is issued early it would): moving a load must not move a bit
+#pragma clang fp contract(off)
+          d.x = rstd * tx; d.y = rstd * ty; d.z = rstd * tz; d.w = rstd * tw;
+          if (resid_grad) {
+            const float4 rg = rgv[i];
+            d.x = d.x + rg.x; d.y = d.y + rg.y; d.z = d.z + rg.z; d.w = d.w + rg.w;
+          }
         }
         if (dx_f32) *reinterpret_cast<float4*>(dx_f32 + o) = d;
         if (dxm_hi) {

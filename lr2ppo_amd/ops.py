@@ -432,7 +432,7 @@ def layernorm_fwd(x, gamma, beta, out, mean=None, rstd=None, *, rows, D, eps=1e-
 
 # workgroups of the LayerNorm backward (each leaves one partial row of d gamma / d beta): 4 per CU.  With one per CU (round 2) the
 # kernel kept 24 KB of loads in flight per CU and ran at 3.4 TB/s on the encoders' [100864, 768] rows (rocprofv3, profiles/r03_*).
-LN_BWD_BLOCKS = 1024
+LN_BWD_BLOCKS = 512       # workgroups of 4 rows-at-a-time waves: 2 per CU measured best at the encoder shapes (tools/dbg/ln_bwd_time.py)
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, partials, dgamma, dbeta, *, rows, D, group=0, group_stride=0,
