@@ -509,6 +509,42 @@ def main():
             "mfma_issue_frac": out["dual_encoder_train_mfma_frac"], "passes": a.passes,
             "workload": f"ViT-B/16 over {a.batch * 16} frames + RoBERTa-base over {a.batch * a.tags} sequences, forward (saving, dropout "
                         "0.1) + hand-written backward incl. embeddings: 3 x the forward's matrix flops (dgrad + wgrad)"}
+        # stage 3 with the encoders trained THROUGH the PPO step (features.finetune_ppo_step: rollout on eval-mode features, update on
+        # train-mode features, the heads hand d (policy + value loss) / d features back, encoder + embedding backward, AdamW over both
+        # stacks): the metric's step plus a second (training) pass of both stacks and their backward -- single rank only
+        if world == 1 and not a.no_stage1:
+            from lr2ppo_amd.finetune.features import build_encoder_optimizer, finetune_ppo_step
+            eargs = argparse.Namespace(**{**vars(margs), "train_steps": 1000, "batch_size": a.batch})
+            eopt3, esch3 = build_encoder_optimizer(eargs, fx)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for _ in range(20):
+                    esch3.step()
+
+            def stage3_finetune(i):
+                frames, ids, seg, tg = raw[i % len(raw)]
+                return finetune_ppo_step(margs, fx, model, reward, opt, copt, eopt3, frames, ids, seg, tg)
+
+            for i in range(2):
+                m3 = stage3_finetune(i)
+            fence()
+            n3 = max(3, min(a.steps, 5))
+            t0 = time.perf_counter()
+            for i in range(n3):
+                m3 = stage3_finetune(i)
+            fence()
+            dt3 = time.perf_counter() - t0
+            if not torch.isfinite(m3).all():
+                raise SystemExit("bench: non-finite PPO metrics in the stage-3 fine-tune step")
+            fx.text.embedding.check_ids()
+            out["stage3_finetune_steps_per_sec"] = round(n3 / dt3, 3)
+            out["config"]["stage3_ppo_with_encoder_finetune"] = {
+                "ms_per_step": round(dt3 / n3 * 1e3, 3), "steps_per_sec": round(n3 / dt3, 3), "steps": n3, "measured": True,
+                "workload": f"the metric's PPO step ({a.batch} items x {a.tags} tags) with ViT-B/16 + RoBERTa-base TRAINED through it: "
+                            "eval-mode extraction -> rollout; train-mode extraction (activations kept) -> update with input gradients -> "
+                            "encoder + embedding backward -> AdamW over both stacks (beyond the reference, which trains stage 3 on "
+                            "pre-extracted features)"}
+            del eopt3, esch3
         fx.eval()
         torch.cuda.empty_cache()
         # BASELINE configs[1] as written: ViT-B/16 + RoBERTa-base in front of finetune/pointwise.py's Classifier (the Actor

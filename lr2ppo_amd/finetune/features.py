@@ -351,6 +351,51 @@ def synthetic_raw_batch(batch: int, tags: int, n_img: int = 16, seq_length: int 
 IMAGE_TOWERS = {"vit_base_16_224": VIT_CONFIG, "vit_large_14_224": VIT_L14_CONFIG}
 
 
+def finetune_ppo_step(args, fx: FeatureExtractor, model, reward_model, optimizer, critic_optim, enc_optimizer, frames, ids, seg, tgts):
+    """One PPO step (a rollout timestep + an update minibatch) with the encoders TRAINED through it -- the stage-3 twin of
+    finetune_pointwise_step, an explicit schedule (no autograd graph):
+        rollout    frames + ids -> both stacks in EVAL mode, no gradient -> ppo.rollout_step (finetune/ppo.py:844-883 on its features)
+        update     the same inputs -> both stacks in TRAIN mode, activations kept -> ppo.update_minibatch on those features
+                   (finetune/ppo.py:518-598; actor / critic AdamW inside) with the heads handing back d loss / d features
+                   (policy loss through the actor, value loss through the critic, summed) -> encoder + embedding backward ->
+                   AdamW over both stacks.
+    The reference trains stage 3 on pre-extracted features only (finetune/ppo.py:827-835); the composition is its own
+    `encoder(embedding(src, seg), seg)` (tencentpretrain/models/model.py:32-41) in front of its train_model body.  Gradients are
+    averaged over ranks before the steps (the text stack's all-reduce travels under the image stack's backward).
+    -> the update's 10 metrics (device tensor)."""
+    import torch.distributed as dist
+    from . import ppo
+    dp = ppo._DataParallel()
+    dev = frames.device
+    was_training = (model.training, fx.training)
+    model.eval(), fx.eval()
+    with torch.no_grad():
+        text0, img0 = fx.extract(frames, ids, seg)
+        record = ppo.rollout_step(model, reward_model, text0, img0, tgts.to(dev))
+    del text0, img0
+    model.train(), fx.train()
+    model.actor.bind_grads(), model.critic.bind_grads()
+    fx.bind_grads()
+    text_emb, img_emb, ctx = fx.forward_train(frames, ids, seg)
+    record = tuple(record[:5]) + (text_emb, img_emb, record[7])
+    metrics, d_text, d_img = ppo.update_minibatch(args, model, optimizer, critic_optim, record, dp, input_grads=True)
+    del text_emb, record
+    works = []
+
+    def exchange(part):
+        if dp.active:
+            for g in fx.grad_flats(part):
+                g.div_(dp.world)
+                works.append(dist.all_reduce(g, async_op=True))
+    fx.backward_train(ctx, d_text, d_img, after_text=lambda: exchange("text"))
+    exchange("image")
+    for w in works:
+        w.wait()
+    enc_optimizer.step()
+    model.train(was_training[0]), fx.train(was_training[1])
+    return metrics
+
+
 def raw_input_opts(parser):
     """Flags of this build (not in the reference, whose loaders read pre-extracted features: finetune/ppo.py:115-148): run the
     encoder stacks in front of a stage's head.  The reference's launchers already carry --pretrained_model_path /

@@ -835,10 +835,13 @@ class _DataParallel:
         self.finish(self.reduce_start(head))
 
 
-def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
+def update_minibatch(args, model, optimizer, critic_optim, record, dp=None, input_grads: bool = False):
     """The body of one train_model iteration (finetune/ppo.py:518-598) on one stored rollout record:
     actor + critic train forwards, fused PPO loss, actor backward + AdamW, critic backward + AdamW.
-    Returns the 10 logged metrics of this minibatch as a device tensor (no host sync)."""
+    Returns the 10 logged metrics of this minibatch as a device tensor (no host sync).
+    input_grads: -> (metrics, d text_emb, d img_emb): the gradient of (policy loss + value loss) with respect to the record's
+    features, actor's and critic's contributions summed, in the shapes of record[5] / record[6] -- what the reference's autograd
+    would hand to an encoder in front of the heads (features.finetune_ppo_step)."""
     state, next_state, old_scores, rewards, old_value, text, img, tgts = record
     dev = text.device
     dp = dp or _DataParallel()
@@ -876,11 +879,12 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
         dscores = ops.cls_scores_bwd(probs, scores.view(-1), dscores.view(-1), torch.empty_like(probs), rows=bs * tags,
                                      C=actor.n_out)
     side.fork_point()
-    actor.engine_backward(dscores, dp, fc1_update=fa)
+    ga = actor.engine_backward(dscores, dp, fc1_update=fa, input_grads=input_grads)
     wa = dp.reduce_start(actor)            # overlaps the critic's backward
     with side.run():                       # the critic's backward, gradient exchange and optimizer step beside the actor's
         # (its out_layer.fc1 update first, the actor's last: the two HBM-bound passes fall beside the other model's GEMMs)
-        critic.engine_backward(dvalue, dp, fc1_update=fc, fc1_early=side.on and os.environ.get("LR2_FC1_EARLY", "1") != "0")
+        gc = critic.engine_backward(dvalue, dp, fc1_update=fc, fc1_early=side.on and os.environ.get("LR2_FC1_EARLY", "1") != "0",
+                                    input_grads=input_grads)
         wc = dp.reduce_start(critic)
         if side.on:
             dp.finish(wc)
@@ -897,6 +901,10 @@ def update_minibatch(args, model, optimizer, critic_optim, record, dp=None):
     if dp.active:              # the reference's 10 logging all-reduces (ppo.py:589-598), packed into one
         metrics.div_(dp.world)
         dist.all_reduce(metrics)
+    if input_grads:            # after side.join(): both models' input gradients are complete on the main stream
+        d_text = ga[0].add_(gc[0])
+        d_img = None if ga[1] is None else ga[1].add_(gc[1])
+        return metrics, d_text, d_img
     return metrics
 
 
