@@ -67,16 +67,16 @@ __device__ __forceinline__ void issue_part(const Ctx& c, int tile, int stage) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(IS_A ? c.a_lo : c.b_lo, LDS_PTR(dst + PLANE), 16, v, 0, 0, 0);
 }
 
-template <int SLOT>
-__device__ __forceinline__ void read_a_half(uint32_t base, bf16x8_t (&hi)[4], bf16x8_t (&lo)[4]) {
+template <int SLOT, int MIH>
+__device__ __forceinline__ void read_a_half(uint32_t base, bf16x8_t (&hi)[MIH], bf16x8_t (&lo)[MIH]) {
   hi[0] = lds_read16<SLOT * PART + 0 * 1024>(base);
   hi[1] = lds_read16<SLOT * PART + 1 * 1024>(base);
   hi[2] = lds_read16<SLOT * PART + 2 * 1024>(base);
-  hi[3] = lds_read16<SLOT * PART + 3 * 1024>(base);
+  if constexpr (MIH == 4) hi[3] = lds_read16<SLOT * PART + 3 * 1024>(base);
   lo[0] = lds_read16<SLOT * PART + PLANE + 0 * 1024>(base);
   lo[1] = lds_read16<SLOT * PART + PLANE + 1 * 1024>(base);
   lo[2] = lds_read16<SLOT * PART + PLANE + 2 * 1024>(base);
-  lo[3] = lds_read16<SLOT * PART + PLANE + 3 * 1024>(base);
+  if constexpr (MIH == 4) lo[3] = lds_read16<SLOT * PART + PLANE + 3 * 1024>(base);
 }
 template <int SLOT>
 __device__ __forceinline__ void read_b_half(uint32_t base, bf16x8_t (&hi)[2], bf16x8_t (&lo)[2]) {
@@ -100,25 +100,25 @@ __device__ __forceinline__ void end_load_section() {
 
 // 24 MFMAs of one accumulator quadrant: products lo*hi, hi*lo, hi*hi, eight independent accumulators between two
 // updates of the same one.
-template <int AH, int BH>
-__device__ __forceinline__ void mfma_section(f32x4_t (&acc)[8][4], const bf16x8_t (&ahi)[4], const bf16x8_t (&alo)[4],
+template <int AH, int BH, int MIH>
+__device__ __forceinline__ void mfma_section(f32x4_t (&acc)[2 * MIH][4], const bf16x8_t (&ahi)[MIH], const bf16x8_t (&alo)[MIH],
                                              const bf16x8_t (&bhi)[2], const bf16x8_t (&blo)[2]) {
   __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      acc[AH * 4 + i][BH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi[j], acc[AH * 4 + i][BH * 2 + j], 0, 0, 0);
+    for (int i = 0; i < MIH; ++i)
+      acc[AH * MIH + i][BH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[i], bhi[j], acc[AH * MIH + i][BH * 2 + j], 0, 0, 0);
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      acc[AH * 4 + i][BH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo[j], acc[AH * 4 + i][BH * 2 + j], 0, 0, 0);
+    for (int i = 0; i < MIH; ++i)
+      acc[AH * MIH + i][BH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], blo[j], acc[AH * MIH + i][BH * 2 + j], 0, 0, 0);
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      acc[AH * 4 + i][BH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi[j], acc[AH * 4 + i][BH * 2 + j], 0, 0, 0);
+    for (int i = 0; i < MIH; ++i)
+      acc[AH * MIH + i][BH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[i], bhi[j], acc[AH * MIH + i][BH * 2 + j], 0, 0, 0);
   __builtin_amdgcn_s_setprio(0);
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
@@ -132,36 +132,41 @@ __device__ __forceinline__ void mfma_section(f32x4_t (&acc)[8][4], const bf16x8_
 //   V = 1: in the two light sections only (no section carries 12 fragment reads AND DMA issue):
 //          1: B0(t+1), A0(t+2)   3: B1(t+2), A1(t+2)
 // The counted waits leave exactly the parts issued after the one the NEXT section reads in flight (2 pieces per part).
-template <int S, int V>
-__device__ __forceinline__ void k_step(const Ctx& c, int t, f32x4_t (&acc)[8][4]) {
-  bf16x8_t ahi[4], alo[4], bhi[2], blo[2];
+template <int S, int V, int MIH>
+__device__ __forceinline__ void k_step(const Ctx& c, int t, f32x4_t (&acc)[2 * MIH][4]) {
+  bf16x8_t ahi[MIH], alo[MIH], bhi[2], blo[2];
   // phase 0: quadrant (A0, B0)
   if (V == 0) issue_part<SLOT_B0, false, 0>(c, t + 1, S ^ 1);
-  read_a_half<SLOT_A0>(c.rd_a[S], ahi, alo);
+  read_a_half<SLOT_A0, MIH>(c.rd_a[S], ahi, alo);
   read_b_half<SLOT_B0>(c.rd_b[S], bhi, blo);
   end_load_section<V == 0 ? 12 : 10>();
-  mfma_section<0, 0>(acc, ahi, alo, bhi, blo);
+  mfma_section<0, 0, MIH>(acc, ahi, alo, bhi, blo);
   // phase 1: (A0, B1)
   if (V == 1) issue_part<SLOT_B0, false, 0>(c, t + 1, S ^ 1);
   issue_part<SLOT_A0, true, 0>(c, t + 2, S);
   read_b_half<SLOT_B1>(c.rd_b[S], bhi, blo);
   end_load_section<12>();
-  mfma_section<0, 1>(acc, ahi, alo, bhi, blo);
+  mfma_section<0, 1, MIH>(acc, ahi, alo, bhi, blo);
   // phase 2: (A1, B1)
   if (V == 0) issue_part<SLOT_B1, false, 1>(c, t + 2, S);
-  read_a_half<SLOT_A1>(c.rd_a[S], ahi, alo);
+  read_a_half<SLOT_A1, MIH>(c.rd_a[S], ahi, alo);
   end_load_section<V == 0 ? 12 : 10>();
-  mfma_section<1, 1>(acc, ahi, alo, bhi, blo);
+  mfma_section<1, 1, MIH>(acc, ahi, alo, bhi, blo);
   // phase 3: (A1, B0)
   if (V == 1) issue_part<SLOT_B1, false, 1>(c, t + 2, S);
   issue_part<SLOT_A1, true, 1>(c, t + 2, S);
   read_b_half<SLOT_B0>(c.rd_b[S], bhi, blo);
   end_load_section<6>();
-  mfma_section<1, 0>(acc, ahi, alo, bhi, blo);
+  mfma_section<1, 0, MIH>(acc, ahi, alo, bhi, blo);
 }
 
-template <int V>
+// MIH = accumulator tiles per half of a wave's rows: 4 -> the 256 x 256 tile; 3 -> a 192 x 256 tile (wave tile 96 x 64) for launches
+// of less than one round of 256-row tiles that fit one round of 192-row tiles too (M = 12 544, N = 768: 147 -> 198 workgroups, each
+// with three quarters of the work).  Same ring: an A part then holds 96 rows, the two waves whose 16-row pieces fall beyond them issue
+// out-of-range requests (zeros into the unused quarter of the part), so every wave's counted waits stay as they are.
+template <int V, int MIH = 4>
 __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
+  constexpr int BMT = 64 * MIH, WMT = 32 * MIH;      // tile rows, wave-tile rows
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
 
   int tm, tn;
   tile_coords(g.tiles_m, g.tiles_n, blockIdx.x, tm, tn, g.strip_n > 0 ? g.strip_n : 8);
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BMT, n0 = tn * BN;
 
   Ctx c;
   c.smem = smem;
@@ -187,11 +192,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
     const uint32_t ku = (uint32_t)((lane & 3) ^ swz(lr)) * 16u;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int arow = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);   // part A(h): rows wr*128 + h*64 + [0, 64) of both wr
+      // part A(h): rows wr*WMT + h*(WMT/2) + [0, WMT/2) of both wr (part-local row lr = wr*(WMT/2) + that index)
+      const int awr = lr / (WMT / 2), ain = lr - awr * (WMT / 2);
+      const int arow = m0 + awr * WMT + h * (WMT / 2) + ain;
       const int bcol = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);    // part B(h): cols wc*64 + h*32 + [0, 32) of all wc
       const uint64_t oa = (uint64_t)arow * (uint64_t)g.lda * 2u + ku;
       const uint64_t ob = (uint64_t)bcol * (uint64_t)g.ldb * 2u + ku;
-      c.voff_a[h] = oa < (uint64_t)OOB ? (uint32_t)oa : OOB;
+      c.voff_a[h] = (lr < WMT && oa < (uint64_t)OOB) ? (uint32_t)oa : OOB;
       c.voff_b[h] = ob < (uint64_t)OOB ? (uint32_t)ob : OOB;
     }
     const int r16 = lane & 15;
@@ -199,14 +206,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
     const uint32_t sm = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      c.rd_a[s] = sm + s * STAGE + wr * 4096 + lane_off;     // A part: local row wr*64 + i*16 + r16
+      c.rd_a[s] = sm + s * STAGE + wr * (MIH * 1024) + lane_off;     // A part: local row wr*(16 MIH) + i*16 + r16
       c.rd_b[s] = sm + s * STAGE + wc * 2048 + lane_off;     // B part: local row wc*32 + j*16 + r16
     }
   }
 
-  f32x4_t acc[8][4];
+  f32x4_t acc[2 * MIH][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 2 * MIH; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -231,8 +238,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
     tr0 = __builtin_amdgcn_s_memrealtime();
   }
   for (int t = 0; t < c.nt; t += 2) {
-    k_step<0, V>(c, t, acc);
-    if (t + 1 < c.nt) k_step<1, V>(c, t + 1, acc);
+    k_step<0, V, MIH>(c, t, acc);
+    if (t + 1 < c.nt) k_step<1, V, MIH>(c, t + 1, acc);
   }
   if ((g.ablate & 32) && g.partial && tid == 0) {
     const uint64_t tc1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
@@ -252,10 +259,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_nt_kernel(GemmParams g) {
   if (g.ablate & 8) {
     GemmParams g2 = g;
     g2.M = 0;
-    epilogue_wave<128, 64, 8, 4, 1>(g2, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, nullptr);
+    epilogue_wave<WMT, 64, 2 * MIH, 4, 1>(g2, acc, slab, m0 + wr * WMT, n0 + wc * 64, lane, nullptr);
     return;
   }
-  epilogue_wave<128, 64, 8, 4, 1>(g, acc, slab, m0 + wr * 128, n0 + wc * 64, lane, nullptr);
+  epilogue_wave<WMT, 64, 2 * MIH, 4, 1>(g, acc, slab, m0 + wr * WMT, n0 + wc * 64, lane, nullptr);
 }
 
 
@@ -371,21 +378,21 @@ __device__ __forceinline__ void k_step(const Ctx& c, int t, f32x4_t (&acc)[8][4]
   read_a_half<0, S>(c, ahi, alo);
   read_b_half<0, S>(c, bhi, blo);
   end_load_section<12>();
-  mfma_section<0, 0>(acc, ahi, alo, bhi, blo);
+  mfma_section<0, 0, 4>(acc, ahi, alo, bhi, blo);
   issue_part<true, 0>(c, t + 2, S);               // phase 1: (A0, B1)
   read_b_half<1, S>(c, bhi, blo);
   if (do_cs) colsum_frags<0>(cs, wc, ahi, alo);
   end_load_section<12>();
-  mfma_section<0, 1>(acc, ahi, alo, bhi, blo);
+  mfma_section<0, 1, 4>(acc, ahi, alo, bhi, blo);
   issue_part<false, 1>(c, t + 2, S);              // phase 2: (A1, B1)
   read_a_half<1, S>(c, ahi, alo);
   end_load_section<12>();
-  mfma_section<1, 1>(acc, ahi, alo, bhi, blo);
+  mfma_section<1, 1, 4>(acc, ahi, alo, bhi, blo);
   issue_part<true, 1>(c, t + 2, S);               // phase 3: (A1, B0)
   read_b_half<0, S>(c, bhi, blo);
   if (do_cs) colsum_frags<1>(cs, wc, ahi, alo);
   end_load_section<6>();
-  mfma_section<1, 0>(acc, ahi, alo, bhi, blo);
+  mfma_section<1, 0, 4>(acc, ahi, alo, bhi, blo);
 }
 
 __global__ __launch_bounds__(512, 2) void gemm256_tn_kernel(GemmParams g) {
@@ -521,24 +528,36 @@ int launch_gemm256_tn(const GemmParams& p_in, int splits, hipStream_t stream) {
 
 // Host entry for gemm.hip's dispatcher.  Requirements (checked by the caller): planes x planes, NT, passes == 3,
 // K % 32 == 0, no split-K, operand extents < 4 GiB - 512 B.
+// rows per tile the NT launcher picks for a shape: 192 when one round of 256-row tiles would leave CUs idle that a round of 192-row
+// tiles fills (LR2_GEMM_192=0: always 256; read once per process)
+int gemm256_nt_tile_rows(int M, int N) {
+  static const bool on = !(getenv("LR2_GEMM_192") && atoi(getenv("LR2_GEMM_192")) == 0);
+  const int tn = (N + g256::BN - 1) / g256::BN;
+  const int t256 = ((M + 255) / 256) * tn, t192 = ((M + 191) / 192) * tn;
+  return (on && t256 < 256 && t192 <= 256 && t192 > t256) ? 192 : 256;
+}
+
 int launch_gemm256_nt(const GemmParams& p_in, hipStream_t stream) {
   using namespace g256;
   GemmParams p = p_in;
-  p.tiles_m = (p.M + BM - 1) / BM;
+  const int bm = gemm256_nt_tile_rows(p.M, p.N);
+  p.tiles_m = (p.M + bm - 1) / bm;
   p.tiles_n = (p.N + BN - 1) / BN;
   if (!(p.ablate & 32)) p.partial = nullptr;
   static bool attr_set = false;
   if (!attr_set) {
-    if (lr2_allow_dynamic_lds(gemm256_nt_kernel<0>, LDS_BYTES, "gemm256")) return LR2_ERR_LAUNCH;
-    if (lr2_allow_dynamic_lds(gemm256_nt_kernel<1>, LDS_BYTES, "gemm256")) return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(gemm256_nt_kernel<0, 4>, LDS_BYTES, "gemm256")) return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(gemm256_nt_kernel<1, 4>, LDS_BYTES, "gemm256")) return LR2_ERR_LAUNCH;
+    if (lr2_allow_dynamic_lds(gemm256_nt_kernel<0, 3>, LDS_BYTES, "gemm256(192 rows)")) return LR2_ERR_LAUNCH;
     attr_set = true;
   }
   const char* se = getenv("LR2_GEMM_STRIP");          // read per call: strip width of the tile order (A/B inside one process)
   p.strip_n = se ? atoi(se) : 0;
   const char* ve = getenv("LR2_GEMM256_VARIANT");     // read per call: tools A/B the variants inside one process
   const int variant = ve ? atoi(ve) : 0;
-  if (variant == 1) LR2_LAUNCH(gemm256_nt_kernel<1>, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS_BYTES, stream, p);
-  else LR2_LAUNCH(gemm256_nt_kernel<0>, dim3(p.tiles_m * p.tiles_n), dim3(512), LDS_BYTES, stream, p);
+  if (bm == 192) LR2_LAUNCH((gemm256_nt_kernel<0, 3>), dim3(p.tiles_m * p.tiles_n), dim3(512), LDS_BYTES, stream, p);
+  else if (variant == 1) LR2_LAUNCH((gemm256_nt_kernel<1, 4>), dim3(p.tiles_m * p.tiles_n), dim3(512), LDS_BYTES, stream, p);
+  else LR2_LAUNCH((gemm256_nt_kernel<0, 4>), dim3(p.tiles_m * p.tiles_n), dim3(512), LDS_BYTES, stream, p);
   return lr2_launch_status(__func__);
 }
 

@@ -388,7 +388,7 @@ __device__ __forceinline__ void epilogue_pipeline(const GemmParams& g, f32x4_t (
 template <int WM, int WN, int MI, int NI, int NS = 3, int WIDE = (NS == 1 ? 2 : 0)>
 __device__ __forceinline__ void epilogue_wave(const GemmParams& g, f32x4_t (&acc)[MI][NI], float* slab, int mw, int nw,
                                               int lane, float* partial) {
-  static_assert(WM == 32 || WM == 64 || WM == 128, "wave tile rows");
+  static_assert(WM == 32 || WM == 64 || WM == 96 || WM == 128, "wave tile rows");
   constexpr bool PIPE = false;   // cross-slab prefetch (NS == 1) measured 256 VGPRs + spills in gemm256: per-slab requests only
   const int n = nw + (lane % (WN / 4)) * 4;
   float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -278,7 +278,13 @@ def _use_gemm256(M: int, N: int, K: int, passes: int) -> bool:
     # one partial round, long contraction (M = 12544, N = 768, K = 3072: 147 tiles): each CU runs one tile at the 256 x 256 kernel's
     # main-loop rate and the epilogue is amortised over 96 K steps -- 182 us against 197 (64-row tiles) / 212 (128-row), round 3;
     # round 4: also three quarters of a round at K >= 1024 (M = 12544, N = 1024, K = 1024: 196 tiles, 77 us against 86)
-    return (128 <= tiles <= 256 and K >= 2304) or (192 <= tiles <= 256 and K >= 1024)
+    if (128 <= tiles <= 256 and K >= 2304) or (192 <= tiles <= 256 and K >= 1024):
+        return True
+    # round 4, late: the kernel's 192-row tile (gemm256.hip, MIH = 3; the launcher takes it when a round of 192-row tiles fills CUs a
+    # round of 256-row tiles leaves idle): M = 12544, N = 768: 147 -> 198 workgroups -- K = 768: 50 us against 56 (64-row tiles),
+    # K = 1536: 80 against 94 (tools/dbg/gemm192_ab.py)
+    t192 = ((M + 191) // 192) * ((N + 255) // 256)
+    return tiles < 256 and 192 <= t192 <= 256 and t192 > tiles and K >= 768 and os.environ.get("LR2_GEMM_192", "1") != "0"
 
 
 @functools.lru_cache(maxsize=4096)

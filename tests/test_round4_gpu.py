@@ -172,3 +172,30 @@ def test_streaming_attention_backward_matches_recomputing_kernels_and_fp64(dev, 
         out = (torch.softmax(q @ k.transpose(-2, -1) / 8.0 + mask, dim=-1) @ v).transpose(1, 2).reshape(2 * L, E)
         out.backward(do.to_float()[sl].double().cpu())
         assert rel(gn[sl].cpu(), xx.grad) < 2e-5                                # measured 4.9e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(12544, 768, 768), (12500, 700, 1536), (6000, 512, 256), (200, 256, 64), (12544, 768, 3072)])
+def test_192_row_tile_of_the_256_kernel_matches_fp64(dev, M, N, K):
+    """Less than one round of 256-row tiles that a round of 192-row tiles fills better: the NT launcher runs gemm256_nt_kernel<0, 3>
+    (wave tile 96 x 64; csrc/gemm256.hip).  Ragged M / N, every epilogue family against fp64, planes output == split(fp32 output)."""
+    from lr2ppo_amd import ops
+    from test_kernels_gpu import _close
+    assert ((M + 255) // 256) * ((N + 255) // 256) < ((M + 191) // 192) * ((N + 255) // 256) <= 256      # the launcher's condition
+    g = torch.Generator().manual_seed(M + K)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1
+    bias, resid = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ap, wp = _planes(ops, a, dev), _planes(ops, w, dev)
+    z_ref = a.double() @ w.double().t()
+    atol = 6e-5 * math.sqrt(K)
+    out = torch.full((M, N), float("nan"), device=dev)
+    ops.gemm(ap, wp, out, M, N, K, block_m=256, splits=1)
+    _close(out, z_ref, atol, 5e-5, "plain")
+    pl = ops.Planes.empty(M, N, dev)
+    ops.gemm(ap, wp, out, M, N, K, bias=bias.to(dev), act=1, out_planes=pl, block_m=256, splits=1)
+    _close(out, O.gelu_erf(z_ref + bias.double()), atol, 5e-5, "gelu")
+    assert torch.equal(pl.buf, ops.split_planes(out, ops.Planes.empty(M, N, dev)).buf)
+    ops.gemm(ap, wp, out, M, N, K, bias=bias.to(dev), resid=resid.to(dev), block_m=256, splits=1)
+    _close(out, z_ref + bias.double() + resid.double(), atol, 5e-5, "resid")
+    out.copy_(resid.to(dev))
+    ops.gemm(ap, wp, out, M, N, K, accumulate=True, alpha=0.5, block_m=256, splits=1)
+    _close(out, 0.5 * z_ref + resid.double(), atol, 5e-5, "accumulate")
