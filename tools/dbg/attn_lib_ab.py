@@ -40,6 +40,8 @@ for rep in range(3):
                                                  batch, heads, L, 64, 0.125, st()),
             "fwd": lambda: lib.lr2_self_attn_fwd(q, k, v, qkv.lo_off, qkv.cols, seg.data_ptr(), None, o.data_ptr(), o.lo_off, E, None, 0.0, 0, 0,
                                                  batch, heads, L, 64, 0.125, st()),
+            "fwd, dropout 0.1 + lse": lambda: lib.lr2_self_attn_fwd(q, k, v, qkv.lo_off, qkv.cols, seg.data_ptr(), None, o.data_ptr(), o.lo_off, E,
+                                                                    lse.data_ptr(), 0.1, 7, 1, batch, heads, L, 64, 0.125, st()),
         }
         for what, call in calls.items():
             for _ in range(2):
