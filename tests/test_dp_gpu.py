@@ -41,3 +41,13 @@ def test_bench_gpus_2_starts_two_ranks_and_reports_them(dev):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["backend"] == "gloo" and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["head_only_steps_per_sec"] > 0
+
+
+def test_two_rank_encoder_finetune_keeps_replicas_identical(dev):
+    """finetune_ppo_step + finetune_pointwise_step on two gloo ranks sharing the GPU, a different batch per rank: the averaged encoder /
+    embedding / head gradients leave both replicas with the same bits, and they moved (tests/workers/dp_finetune_worker.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29613", os.path.join(REPO, "tests", "workers", "dp_finetune_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "DP_FINETUNE_REPLICAS_IDENTICAL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
