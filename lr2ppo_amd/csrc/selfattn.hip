@@ -2099,33 +2099,45 @@ __global__ __launch_bounds__(FT_THREADS) void first_token_attn_kernel(const floa
                                                                        const bf16_t* __restrict__ v_hi, size_t lo_off, int ld,
                                                                        const int64_t* __restrict__ seg, float* __restrict__ o,
                                                                        int ld_o, int heads, int L, float scale) {
+  // Round 4: 8 threads per key row (16 B of the hi plane + 16 B of the lo plane each: the 128-byte row segment of a head is one
+  // coalesced request), 32 rows per sweep of the workgroup, for the scores AND for P V -- the first version read a row per thread
+  // (64 cache lines per wave instruction) and V two bytes per lane: 245 us at 512 x 12 x 197 = 2.5 TB/s.
   __shared__ float sq[HD];
   __shared__ float sp[FT_MAXL];
   __shared__ float red[FT_THREADS / 64];
-  __shared__ float so[FT_THREADS / 64][HD];
+  __shared__ float so[FT_THREADS / 8][HD + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rr = tid >> 3, c8 = (tid & 7) * 8;            // row within a sweep, first of this thread's 8 head columns
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const size_t row0 = (size_t)b * L;
   if (tid < HD) sq[tid] = q[(size_t)b * ld_q + h * HD + tid];
   __syncthreads();
-  // scores: one key per thread and sweep
-  float mx = -INFINITY;
-  for (int j = tid; j < L; j += FT_THREADS) {
-    const bf16_t* kr = k_hi + (row0 + j) * (size_t)ld + h * HD;
-    float acc = 0.f;
+  float qv[8];
 #pragma unroll
-    for (int c = 0; c < HD / 8; ++c) {
-      const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(kr + c * 8);
-      const u32x4_t lv = *reinterpret_cast<const u32x4_t*>(kr + lo_off + c * 8);
+  for (int i = 0; i < 8; ++i) qv[i] = sq[c8 + i];
+  float mx = -INFINITY;
+  for (int j0 = 0; j0 < L; j0 += FT_THREADS / 8) {
+    const int j = j0 + rr;
+    float acc = 0.f;
+    if (j < L) {
+      const bf16_t* kr = k_hi + (row0 + j) * (size_t)ld + h * HD + c8;
+      const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(kr);
+      const u32x4_t lv = *reinterpret_cast<const u32x4_t*>(kr + lo_off);
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        acc = __builtin_fmaf(sq[c * 8 + 2 * w], bf_lo(hv[w]) + bf_lo(lv[w]), acc);
-        acc = __builtin_fmaf(sq[c * 8 + 2 * w + 1], bf_hi(hv[w]) + bf_hi(lv[w]), acc);
+        acc = __builtin_fmaf(qv[2 * w], bf_lo(hv[w]) + bf_lo(lv[w]), acc);
+        acc = __builtin_fmaf(qv[2 * w + 1], bf_hi(hv[w]) + bf_hi(lv[w]), acc);
       }
     }
-    const float sc = acc * scale + ((seg[row0 + j] > 0) ? 0.f : -10000.0f);
-    sp[j] = sc;
-    mx = fmaxf(mx, sc);
+    // the row's 8 partial sums sit in 8 consecutive lanes
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (j < L) {
+      const float sc = acc * scale + ((seg[row0 + j] > 0) ? 0.f : -10000.0f);
+      if ((tid & 7) == 0) sp[j] = sc;
+      mx = fmaxf(mx, sc);
+    }
   }
   mx = wave_max(mx);
   if (lane == 0) red[wave] = mx;
@@ -2142,15 +2154,30 @@ __global__ __launch_bounds__(FT_THREADS) void first_token_attn_kernel(const floa
   if (lane == 0) red[wave] = sum;
   __syncthreads();
   sum = (red[0] + red[1]) + (red[2] + red[3]);
-  // O = P V: lane = head column, each wave a quarter of the keys (coalesced 128-B rows)
-  float acc = 0.f;
-  for (int j = wave; j < L; j += FT_THREADS / 64) {
-    const bf16_t* vr = v_hi + (row0 + j) * (size_t)ld + h * HD + lane;
-    acc = __builtin_fmaf(sp[j], bf2f(vr[0]) + bf2f(vr[lo_off]), acc);
+  // O = P V: thread (rr, c8) sums its 8 columns over the rows rr, rr + 32, ...; the 32 row groups are combined through LDS
+  float ov[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ov[i] = 0.f;
+  for (int j = rr; j < L; j += FT_THREADS / 8) {
+    const bf16_t* vr = v_hi + (row0 + j) * (size_t)ld + h * HD + c8;
+    const u32x4_t hv = *reinterpret_cast<const u32x4_t*>(vr);
+    const u32x4_t lv = *reinterpret_cast<const u32x4_t*>(vr + lo_off);
+    const float pj = sp[j];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      ov[2 * w] = __builtin_fmaf(pj, bf_lo(hv[w]) + bf_lo(lv[w]), ov[2 * w]);
+      ov[2 * w + 1] = __builtin_fmaf(pj, bf_hi(hv[w]) + bf_hi(lv[w]), ov[2 * w + 1]);
+    }
   }
-  so[wave][lane] = acc;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) so[rr][c8 + i] = ov[i];
   __syncthreads();
-  if (tid < HD) o[(size_t)b * ld_o + h * HD + tid] = ((so[0][tid] + so[1][tid]) + (so[2][tid] + so[3][tid])) / sum;
+  if (tid < HD) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < FT_THREADS / 8; ++r) t += so[r][tid];
+    o[(size_t)b * ld_o + h * HD + tid] = t / sum;
+  }
 }
 
 }  // namespace
