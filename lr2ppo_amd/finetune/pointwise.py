@@ -20,7 +20,7 @@ import torch.nn as nn
 from torch.utils.data import DataLoader, Dataset
 from torch.utils.data.distributed import DistributedSampler
 
-from .. import ops
+from .. import h5lite, ops
 from ..ndcg import AverageNDCGMeter, ndcg_rows
 from ..tencentpretrain.model_saver import save_model
 from ..tencentpretrain.opts import adv_opts, finetune_opts, tokenizer_opts
@@ -71,16 +71,12 @@ def train_tag_index(targets, max_tags: int):
 
 
 class MovieNet(Dataset):
-    """LRMovieNet reader of stage 1 (finetune/pointwise.py:77-167).  Needs h5py + LRMovieNet/clean_feat.h5."""
+    """LRMovieNet reader of stage 1 (finetune/pointwise.py:77-167).  Reads LRMovieNet/clean_feat.h5 (h5py, or `lr2ppo_amd.h5lite` on libhdf5)."""
 
     def __init__(self, args, path, is_train=False):
-        try:
-            import h5py
-        except ImportError as e:
-            raise RuntimeError("MovieNet needs h5py (absent in this image); use --synthetic_items for synthetic data") from e
         with open(path) as f:
             self.data = json.load(f)
-        self.embed_data = h5py.File(os.path.join("LRMovieNet", "clean_feat.h5"), "r")
+        self.embed_data = h5lite.open_file(os.path.join("LRMovieNet", "clean_feat.h5"), "r")    # h5py, or libhdf5 via ctypes
         self.max_imgs, self.is_train, self.max_tags = args.max_imgs, is_train, args.max_tags
         self.items = []
         for item in self.data:

@@ -7,7 +7,8 @@ the width of the batch, in front of pointwise_trad's sequence-length-1 head (XiT
 out_layer = Mlp(1536, 3072, 768), Linear(768, 1)); SmoothL1(beta = 0.3), AdamW, per-batch scheduler.  The projection that a
 batch does not use gets NO gradient upstream (`.grad is None`: AdamW skips it, no weight decay either): reproduced by
 unbinding its gradients for that step.  Same kernels as every other head (`engine.feature_proj_forward / backward`,
-`engine.trad_trunk_forward / backward`); mode 'reg'.  The LETOR h5 readers are not rebuilt.  No CPU fallback.
+`engine.trad_trunk_forward / backward`); mode 'reg'.  `LTRDataset` (pointwise_2data_trad.py:87-108) = pointwise_trad's reader, one
+instance per data set (`--train_path`, `--train_path2`).  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -18,7 +19,7 @@ import torch.nn as nn
 
 from .. import engine, ops, runtime
 from . import pointwise_trad as pt
-from .pointwise_trad import OUT_FC1, OUT_FC2, build_optimizer, load_or_initialize_parameters  # noqa: F401
+from .pointwise_trad import OUT_FC1, OUT_FC2, LTRDataset, build_optimizer, load_or_initialize_parameters  # noqa: F401
 from .ppo import FEAT, Mlp
 from .xit import XiT
 

@@ -5,8 +5,8 @@
 document serves as both streams of the XiT block, is concatenated behind the block's output, and goes through
 out_layer = Mlp(1536, 3072, 768) and a Linear(768, 1) head; SmoothL1(beta=0.3) against the relevance label, AdamW,
 per-batch scheduler.  Same kernels and engine schedule as stage 3 (`engine.xit_forward / xit_backward`, fused GEMM epilogues,
-`lr2_smooth_l1`, `lr2_adamw_multi`); mode 'reg' only.  The LETOR h5 reader (`LTRDataset`, needs h5py + pandas-made files)
-is not rebuilt: `SyntheticLTR` provides data of its shapes.  No CPU fallback.
+`lr2_smooth_l1`, `lr2_adamw_multi`); mode 'reg' only.  `LTRDataset` (pointwise_trad.py:88-109) reads the LETOR `train.h5` /
+`test.h5` files (`finetune/letor.py`); `SyntheticLTR` provides data of its shapes.  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -18,6 +18,7 @@ from torch.utils.data import Dataset
 
 from .. import engine, ops, runtime
 from ..tencentpretrain.utils.optimizers import str2optimizer, str2scheduler
+from .letor import QueryRows
 from .ppo import FEAT, Mlp, _grouped, _init_normal
 from .xit import XiT
 
@@ -161,6 +162,10 @@ def train_model(args, model, optimizer, scheduler, text_emb_batch, img_emb_batch
     optimizer.step()
     scheduler.step()
     return loss[0]
+
+
+class LTRDataset(QueryRows):
+    """pointwise_trad.py:88-109: LTRDataset(args, path, is_train) over `path`/train.h5 | test.h5, one item per query."""
 
 
 class SyntheticLTR(Dataset):

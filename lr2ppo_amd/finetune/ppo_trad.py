@@ -7,8 +7,8 @@ Mlp(1536, 3072, 768); Critic / Reward add pos_emb, the second XiT over the docum
 no-op mask) and read the head at the last position.  The rollout / update / loss / optimizer code is finetune/ppo.py's own
 (`rollout_step`, `update_minibatch`, `train_model`, `build_optimizer`: ppo_trad.py:309-345,431-560,760-829 repeat ppo.py line
 for line with `img_emb = None`), on the same HIP kernels: `engine.trad_trunk_forward / backward`, `engine.xit_forward /
-backward`, `lr2_ppo_loss`, `lr2_adamw_multi`.  The LETOR h5 reader (`LTRDataset`, ppo_trad.py:63-98: h5py + pandas-made files)
-is not rebuilt; `SyntheticLTR` provides queries of its shape.  No CPU fallback.
+backward`, `lr2_ppo_loss`, `lr2_adamw_multi`.  `LTRDataset` (ppo_trad.py:63-98) reads the LETOR `train.h5` / `test.h5`
+files (`finetune/letor.py`: h5py, or libhdf5 through `lr2ppo_amd.h5lite`); `SyntheticLTR` provides queries of its shape.  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -18,6 +18,7 @@ import torch.nn as nn
 from . import ppo
 from torch.utils.data import Dataset
 
+from .letor import QueryPairs
 from .ppo import RankLoss, clipped_value_loss, build_optimizer, rollout_step, update_minibatch   # noqa: F401
 
 
@@ -80,6 +81,11 @@ def evaluate(args, val_loader, step=0, split="test", num_tasks=None):
     return ppo.evaluate(args, _Loader(as_ppo_batches), step, split=split, num_tasks=num_tasks)
 
 
+class LTRDataset(QueryPairs):
+    """ppo_trad.py:63-98: LTRDataset(args, path, is_train, max_tags=20) -- training items are random ordered document pairs
+    (max_tags per query), validation items whole queries."""
+
+
 class SyntheticLTR(Dataset):
     """Queries of LTRDataset's item layout (ppo_trad.py:89-94): (ground_truths [docs], query_id, features [docs, 768]); every
     query resampled to exactly `docs` documents like datasets_trad/convert_to_h5py.py:17-23.  pairs=True: training items, a
@@ -101,15 +107,13 @@ class SyntheticLTR(Dataset):
 
 
 def main(argv=None):
-    """Entry point: finetune/ppo_trad.py's loop (:700-849 = finetune/ppo.py's) over SyntheticLTR queries -- the LETOR h5
-    files need h5py + the pandas-made conversion of datasets_trad/.
+    """Entry point: finetune/ppo_trad.py's loop (:700-849 = finetune/ppo.py's) over the LETOR files under --train_path /
+    --dev_path (each a directory holding train.h5 / test.h5, ppo_trad.py:712-713,746) or over SyntheticLTR queries:
         python -m lr2ppo_amd.finetune.ppo_trad --synthetic_items 64 --batch_size 8 --update_timesteps 4 --max_cycles 2 ..."""
     import argparse
     from . import misc
     parser = ppo.build_parser()
     args = parser.parse_args(argv)
-    if args.synthetic_items <= 0:
-        raise SystemExit("ppo_trad: only --synthetic_items N is available here (the LETOR h5 reader is not rebuilt)")
     args.labels_num = 3
     args.fuse_fc1_update = False
     misc.init_distributed_mode(args)
@@ -117,7 +121,9 @@ def main(argv=None):
     args.is_master = misc.is_main_process()
 
     def make_sets():
-        return (SyntheticLTR(args.synthetic_items, 20, args.seed, pairs=True), SyntheticLTR(args.synthetic_val_items, 20, args.seed + 1))
+        if args.synthetic_items > 0:
+            return (SyntheticLTR(args.synthetic_items, 20, args.seed, pairs=True), SyntheticLTR(args.synthetic_val_items, 20, args.seed + 1))
+        return LTRDataset(args, args.train_path, is_train=True), LTRDataset(args, args.dev_path, is_train=False)
 
     def batch_map(b):
         ground_truths, _, features = b

@@ -25,7 +25,7 @@ import torch.distributed as dist
 from torch.utils.data import DataLoader, Dataset
 from torch.utils.data.distributed import DistributedSampler
 
-from .. import ops
+from .. import h5lite, ops
 from ..tencentpretrain.model_saver import save_model
 from ..tencentpretrain.opts import adv_opts, finetune_opts, tokenizer_opts
 from ..tencentpretrain.utils.config import load_hyperparam
@@ -52,16 +52,12 @@ def get_index(tag_list):
 class MovieNet(Dataset):
     """LRMovieNet reader of stage 2 (reward_pair_dataloader.py:87-211).  Training items are the ranked tag pairs stored
     under item["index"], shown in either order with probability 1/2; validation draws max_tags=100 label-stratified
-    triples per item and orders two of them with get_index.  Needs h5py + LRMovieNet/clean_feat.h5."""
+    triples per item and orders two of them with get_index.  Reads LRMovieNet/clean_feat.h5 (h5py, or `lr2ppo_amd.h5lite` on libhdf5)."""
 
     def __init__(self, args, path, is_train=False):
-        try:
-            import h5py
-        except ImportError as e:
-            raise RuntimeError("MovieNet needs h5py (absent in this image); use --synthetic_items for synthetic data") from e
         with open(path) as f:
             self.data = json.load(f)
-        self.embed_data = h5py.File(os.path.join("LRMovieNet", "clean_feat.h5"), "r")
+        self.embed_data = h5lite.open_file(os.path.join("LRMovieNet", "clean_feat.h5"), "r")    # h5py, or libhdf5 via ctypes
         self.max_imgs, self.is_train = args.max_imgs, is_train
         self.max_tags = args.max_tags if is_train else 100
         self.items = []       # (item id, tag index, labels, chosen, reject)

@@ -5,8 +5,8 @@
 with itself, out_layer = Mlp(1536, 3072, 768), the second XiT over the 4 indexed documents, head at the last position.
 `train_model` (:263-281): chosen / reject scores, hinge relu(0.01 - (s+ - s-)) (margin 0.01, not stage 2's 1), AdamW step,
 scheduler step -- `reward_pair_dataloader.train_model` with that margin and `img_emb = None` ([chosen ; reject] as one batch,
-`lr2_pair_hinge`).  `evaluate` (:283-322): fraction of validation pairs with chosen > reject.  The LETOR h5 reader is not
-rebuilt (`SyntheticTradPairs` provides its item layout).  No CPU fallback.
+`lr2_pair_hinge`).  `evaluate` (:283-322): fraction of validation pairs with chosen > reject.  `LTRDataset` (:87-134) draws the
+label-stratified pairs from the LETOR h5 files (`finetune/letor.py`); `SyntheticTradPairs` provides its item layout.  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -14,6 +14,7 @@ import torch
 from torch.utils.data import Dataset
 
 from . import ppo_trad
+from .letor import RewardPairs
 from . import reward_pair_dataloader as rp
 from .ppo import FEAT
 from .reward_pair_dataloader import build_optimizer  # noqa: F401  (reward_trad.py:238-260 == reward_pair_dataloader.py:321-344)
@@ -40,6 +41,10 @@ def evaluate(args, model, dataloader, step=0, split="test", num_tasks=None):
         for ground_truths, _, features, chosen_index, reject_index in dataloader:
             yield features.to(torch.float32), None, ground_truths, chosen_index, reject_index
     return rp.evaluate(args, model, ppo_trad._Loader(as_stage2), step, split=split, num_tasks=num_tasks)
+
+
+class LTRDataset(RewardPairs):
+    """reward_trad.py:87-134: LTRDataset(args, path, is_train, max_tags=20)."""
 
 
 class SyntheticTradPairs(Dataset):

@@ -729,6 +729,70 @@ def gen_readers():
     print("wrote readers.json", {k: v["len"] for k, v in out.items()})
 
 
+def gen_letor_readers():
+    """Outputs of the reference's four `LTRDataset` classes (pointwise_trad / pointwise_2data_trad / ppo_trad / reward_trad)
+    on REAL HDF5 files: oracle.fake_letor tables written in datasets_trad/convert_to_h5py.py's layout through
+    lr2ppo_amd.h5lite (libhdf5), and `h5py.File` inside the reference bound to h5lite.File -- so the fixture also pins that
+    the h5py surface the reference uses (File, keys, len, [name][()]) behaves under the reference's own code.  Also re-runs
+    the three LRMovieNet readers on a real clean_feat.h5 and checks them against readers.json (made on the dict stand-in)."""
+    import random
+    import tempfile
+    import pointwise_trad
+    import pointwise_2data_trad
+    import ppo_trad
+    import reward_trad
+    from lr2ppo_amd import h5lite
+    from lr2ppo_amd.finetune import letor
+    sys.modules["h5py"].File = h5lite.File
+    out = {"hdf5": list(h5lite.library()[1])}
+    with tempfile.TemporaryDirectory() as root:
+        letor.write_split(root, True, O.fake_letor(seed=5, n_queries=6))
+        letor.write_split(root, False, O.fake_letor(seed=6, n_queries=4, feats=136))
+        for name, mod, kw in (("pointwise_trad", pointwise_trad, {}), ("pointwise_2data_trad", pointwise_2data_trad, {}),
+                              ("ppo_trad", ppo_trad, {"max_tags": 3}), ("reward_trad", reward_trad, {"max_tags": 4})):
+            for is_train in (True, False):
+                random.seed(21), np.random.seed(22), torch.manual_seed(23)
+                ds = mod.LTRDataset(_ns(), root, is_train=is_train, **kw)
+                n = len(ds)
+                out[f"{name}_{'train' if is_train else 'val'}"] = {"len": n, "kw": kw,
+                                                                  "items": [O.describe_letor_item(ds[i]) for i in range(min(n, 14))]}
+        # the LRMovieNet readers on a real file
+        import ppo
+        import pointwise
+        import reward_pair_dataloader as rp
+        items, h5 = O.fake_movienet()
+        os.makedirs(os.path.join(root, "LRMovieNet"))
+        with h5lite.File(os.path.join(root, "LRMovieNet", "clean_feat.h5"), "w") as f:
+            for key, members in h5.items():
+                g = f.create_group(key)
+                for k, v in members.items():
+                    g.create_dataset(k, data=v)
+        with open(os.path.join(root, "split.json"), "w") as f:
+            json.dump(items, f)
+        with open(os.path.join(GOLD, "readers.json")) as f:
+            gold = json.load(f)
+        cwd = os.getcwd()
+        os.chdir(root)                                     # the readers open "LRMovieNet/clean_feat.h5" relative to the cwd
+        try:
+            for name, mod in (("ppo", ppo), ("pointwise", pointwise), ("reward_pair", rp)):
+                for is_train in (True, False):
+                    g = gold[f"{name}_{'train' if is_train else 'val'}"]
+                    random.seed(11), np.random.seed(12), torch.manual_seed(13)
+                    a = _ns(is_master=False, max_imgs=16, max_tags=g["max_tags"])
+                    ds = mod.MovieNet(a, "split.json", is_train=is_train)
+                    assert isinstance(ds.embed_data, h5lite.File)            # the real file, not a stand-in
+                    torch.manual_seed(14)
+                    assert len(ds) == g["len"]
+                    for i, want in enumerate(g["items"]):
+                        assert O.describe_reader_item(ds[i]) == want, (name, is_train, i)
+        finally:
+            os.chdir(cwd)
+        out["movienet_on_real_hdf5"] = "reference readers on a libhdf5-written clean_feat.h5 == readers.json"
+    with open(os.path.join(GOLD, "letor_readers.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote letor_readers.json", {k: v["len"] for k, v in out.items() if isinstance(v, dict)})
+
+
 def gen_trad():
     """BASELINE configs[0]: finetune/pointwise_trad.py's Classifier (seq-len-1 XiT head on 768-d document features),
     the config SURVEY 8d describes (2 queries x 20 documents): three train_model steps in eval mode + an inference pass."""
@@ -941,7 +1005,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls, ppo_trad=gen_ppo_trad, reward_trad=gen_reward_trad, trad2=gen_trad2)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, letor_readers=gen_letor_readers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls, ppo_trad=gen_ppo_trad, reward_trad=gen_reward_trad, trad2=gen_trad2)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -674,6 +674,34 @@ def describe_reader_item(sample):
     return out
 
 
+def fake_letor(seed: int = 5, n_queries: int = 6, docs: int = 20, feats: int = 46):
+    """A small LETOR split in the layout datasets_trad/convert_to_h5py.py:17-43 writes: {query id: float64 [docs, 2 + feats]}
+    with column 0 = label (0..4), column 1 = query id, column 2 = 1000 * query number + row (so a reader's row selection can be
+    read back from its output), the rest seeded noise.  Ids are chosen so that name order differs from numeric order."""
+    rng = np.random.RandomState(seed)
+    ids = [10002, 7, 345, 18, 9001, 23, 4, 77, 1200, 31][:n_queries]
+    tables = {}
+    for qn, qid in enumerate(ids):
+        t = rng.standard_normal((docs, 2 + feats))
+        t[:, 0] = rng.randint(0, 5, size=docs)
+        if qn == 1:
+            t[:, 0] = 2.0                                          # one query with a single relevance class: reward_trad keeps no pair
+        t[:, 1] = qid
+        t[:, 2] = 1000 * qn + np.arange(docs)
+        tables[qid] = t
+    return tables
+
+
+def describe_letor_item(sample):
+    """LTRDataset item -> plain numbers: labels, query id, the row-identifying feature column, shape / dtype, index layouts."""
+    gt, qid, feats = (np.asarray(sample[0]), sample[1], np.asarray(sample[2]))
+    out = {"gt": [int(v) for v in gt.tolist()], "qid": str(qid), "rows": [int(round(v)) for v in feats[:, 0].tolist()],
+           "shape": list(feats.shape), "dtype": str(feats.dtype), "checksum": float(np.round(feats.sum(), 6))}
+    if len(sample) > 3:
+        out["chosen"], out["reject"] = [int(v) for v in np.asarray(sample[3]).tolist()], [int(v) for v in np.asarray(sample[4]).tolist()]
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json configs[0] ("plumbing" case): the *_trad Classifier -- the same XiT / Mlp head on one pre-projected
 # 768-d feature per document, sequence length 1 (finetune/pointwise_trad.py:132-177).

@@ -1,0 +1,202 @@
+"""A13 / SURVEY 8(f)-3: the readers on REAL HDF5 files.
+
+`lr2ppo_amd.h5lite` binds the HDF5 C library the image ships (no h5py here); these tests write LRMovieNet- and LETOR-shaped
+files through it, check them with the library's own `h5dump` where that tool exists, and run the product's readers against
+fixtures the REFERENCE's reader classes produced on the same real files (tests/golden/letor_readers.json, readers.json;
+oracle/gen_golden.py::gen_letor_readers, gen_readers).  CPU except the last test (ppo_trad's entry point on LETOR files).
+"""
+import argparse
+import json
+import os
+import random
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+try:
+    from lr2ppo_amd import h5lite
+    h5lite.library()
+    HAVE_HDF5 = True
+except ImportError:
+    HAVE_HDF5 = False
+needs_hdf5 = pytest.mark.skipif(not HAVE_HDF5, reason="no HDF5 C library on this host")
+
+
+@needs_hdf5
+def test_h5lite_round_trip_and_h5py_surface(tmp_path):
+    """File / Group / Dataset behave like the h5py calls the reference makes: name-ordered keys, len, `in`, [name], [:], [()],
+    integer / slice indices, KeyError for a missing member, errors for a missing or foreign file, read-only protection."""
+    path = str(tmp_path / "a.h5")
+    rng = np.random.RandomState(0)
+    arrays = {"f4": rng.standard_normal((3, 2, 4)).astype(np.float32), "f8": rng.standard_normal((20, 48)),
+              "i8": rng.randint(-5, 5, size=(7,)).astype(np.int64), "u1": rng.randint(0, 255, size=(2, 3, 5)).astype(np.uint8),
+              "i4": np.arange(6, dtype=np.int32).reshape(2, 3), "empty": np.zeros((0, 4), np.float32),
+              "scalar": np.float64(2.5)}
+    with h5lite.File(path, "w") as f:
+        g = f.create_group("12")
+        for k, v in arrays.items():
+            g.create_dataset(k, data=v)
+        for name in ("10002", "7", "345"):
+            f.create_dataset(name, data=np.full((2, 2), float(name)))
+        with pytest.raises(ValueError):
+            f.create_dataset("7", data=np.zeros(1))                     # exists already
+    f = h5lite.File(path)                                                # default mode 'r'
+    assert f.keys() == ["10002", "12", "345", "7"] == list(f) and len(f) == 4
+    assert "12" in f and "12/f4" in f and "nope" not in f and "12/nope" not in f and "nope/x" not in f
+    g = f["12"]
+    assert sorted(g.keys()) == sorted(arrays) and len(g) == len(arrays)
+    for k, v in arrays.items():
+        d = g[k]
+        assert d.shape == np.shape(v) and d.dtype == np.asarray(v).dtype, k
+        assert np.array_equal(d[()], v) and np.array_equal(np.asarray(d), v), k
+        if d.shape:
+            assert np.array_equal(d[:], v) and np.array_equal(d[...], v) and len(d) == v.shape[0], k
+    assert np.array_equal(g["f4"][:][0], arrays["f4"][0]) and np.array_equal(g["f8"][3:5, 2:], arrays["f8"][3:5, 2:])
+    assert np.array_equal(f["12/i8"][1], arrays["i8"][1]) and float(g["scalar"][()]) == 2.5
+    assert float(f["7"][()][0, 0]) == 7.0
+    with pytest.raises(KeyError):
+        f["nope"]
+    with pytest.raises(ValueError):
+        f.create_dataset("new", data=np.zeros(2))                        # opened read-only
+    f.close()
+    with pytest.raises(FileNotFoundError):
+        h5lite.File(str(tmp_path / "missing.h5"))
+    (tmp_path / "text.h5").write_text("not an hdf5 file")
+    with pytest.raises(OSError):
+        h5lite.File(str(tmp_path / "text.h5"))
+    with pytest.raises(TypeError):
+        with h5lite.File(str(tmp_path / "s.h5"), "w") as w:
+            w.create_dataset("s", data=np.array(["a", "b"]))             # numeric arrays only
+
+
+@needs_hdf5
+def test_h5lite_files_are_valid_hdf5_by_the_librarys_own_dump_tool(tmp_path):
+    """The HDF5 distribution's `h5dump` (an independent reader of the format) lists the same tree, types, shapes and values."""
+    tool = shutil.which("h5dump") or os.path.join(os.path.dirname(os.path.dirname(h5lite.library()[0])), "bin", "h5dump")
+    if not os.path.exists(tool):
+        pytest.skip("h5dump not installed")
+    path = str(tmp_path / "clean_feat.h5")
+    with h5lite.File(path, "w") as f:
+        g = f.create_group("41")
+        g.create_dataset("text_emb", data=np.arange(24, dtype=np.float32).reshape(3, 2, 4))
+        g.create_dataset("img_emb", data=np.arange(10, dtype=np.float32).reshape(1, 5, 2))
+        f.create_dataset("7", data=np.arange(6, dtype=np.float64).reshape(2, 3))
+    head = subprocess.run([tool, "-H", path], capture_output=True, text=True, check=True).stdout
+    for want in ('GROUP "41"', 'DATASET "text_emb"', "H5T_IEEE_F32LE", "( 3, 2, 4 )", 'DATASET "img_emb"', "( 1, 5, 2 )",
+                 'DATASET "7"', "H5T_IEEE_F64LE", "( 2, 3 )"):
+        assert want in head, (want, head)
+    data = subprocess.run([tool, "-d", "/41/img_emb", path], capture_output=True, text=True, check=True).stdout
+    assert "(0,0,0): 0, 1," in data and "(0,4,0): 8, 9" in data, data
+
+
+def _write_movienet(root):
+    from oracle import lr2ppo_oracle as O
+    items, h5 = O.fake_movienet()
+    os.makedirs(os.path.join(root, "LRMovieNet"))
+    with h5lite.File(os.path.join(root, "LRMovieNet", "clean_feat.h5"), "w") as f:
+        for key, members in h5.items():
+            g = f.create_group(key)
+            for k, v in members.items():
+                g.create_dataset(k, data=v)
+    with open(os.path.join(root, "split.json"), "w") as f:
+        json.dump(items, f)
+
+
+@needs_hdf5
+def test_movienet_readers_match_reference_on_a_real_hdf5_file(tmp_path, monkeypatch):
+    """The three LRMovieNet readers (stage 1, 2, 3; both splits) open LRMovieNet/clean_feat.h5 -- a real HDF5 file, no stand-in
+    for h5py -- and return the reference readers' items (tests/golden/readers.json; the generator re-ran the reference's own
+    readers on the same real file and got the same items)."""
+    from oracle import lr2ppo_oracle as O
+    from lr2ppo_amd.finetune import pointwise as pw, ppo, reward_pair_dataloader as rp
+    if "h5py" in sys.modules and not hasattr(sys.modules["h5py"], "__file__"):
+        monkeypatch.delitem(sys.modules, "h5py")
+    _write_movienet(str(tmp_path))
+    monkeypatch.chdir(tmp_path)                                            # the readers open the file relative to the cwd, as upstream
+    with open(os.path.join(GOLD, "readers.json")) as f:
+        gold = json.load(f)
+    for name, mod in (("ppo", ppo), ("pointwise", pw), ("reward_pair", rp)):
+        for split in ("train", "val"):
+            g = gold[f"{name}_{split}"]
+            random.seed(11), np.random.seed(12), torch.manual_seed(13)
+            ds = mod.MovieNet(argparse.Namespace(is_master=False, max_imgs=16, max_tags=g["max_tags"]), "split.json",
+                              is_train=split == "train")
+            assert type(ds.embed_data).__module__.split(".")[0] in ("lr2ppo_amd", "h5py")
+            torch.manual_seed(14)
+            assert len(ds) == g["len"], (name, split)
+            for i, want in enumerate(g["items"]):
+                assert O.describe_reader_item(ds[i]) == want, (name, split, i)
+    # through the loader the launchers build (forked workers read the file): shapes of a stage-3 batch
+    ds = ppo.MovieNet(argparse.Namespace(is_master=False, max_imgs=16, max_tags=2), "split.json", is_train=True)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, num_workers=2)
+    text, img, tgt = next(iter(loader))
+    assert text.shape == (2, 2, 2, 4) and img.shape == (2, 16, 768) and tgt.shape == (2, 2) and text.dtype == torch.float32
+
+
+@needs_hdf5
+def test_letor_readers_match_the_references_ltrdataset_classes(tmp_path):
+    """`LTRDataset` of pointwise_trad / pointwise_2data_trad / ppo_trad / reward_trad on train.h5 / test.h5 in the layout
+    datasets_trad/convert_to_h5py.py writes, seeded like the generator: query order, drawn pairs, index layouts, label and
+    feature rows, shapes and dtypes equal the reference classes' (tests/golden/letor_readers.json)."""
+    from oracle import lr2ppo_oracle as O
+    from lr2ppo_amd.finetune import letor, pointwise_2data_trad, pointwise_trad, ppo_trad, reward_trad
+    root = str(tmp_path)
+    letor.write_split(root, True, O.fake_letor(seed=5, n_queries=6))
+    letor.write_split(root, False, O.fake_letor(seed=6, n_queries=4, feats=136))
+    with open(os.path.join(GOLD, "letor_readers.json")) as f:
+        gold = json.load(f)
+    for name, mod in (("pointwise_trad", pointwise_trad), ("pointwise_2data_trad", pointwise_2data_trad), ("ppo_trad", ppo_trad),
+                      ("reward_trad", reward_trad)):
+        for split in ("train", "val"):
+            g = gold[f"{name}_{split}"]
+            random.seed(21), np.random.seed(22), torch.manual_seed(23)
+            ds = mod.LTRDataset(argparse.Namespace(), root, is_train=split == "train", **g["kw"])
+            assert len(ds) == g["len"], (name, split)
+            for i, want in enumerate(g["items"]):
+                assert O.describe_letor_item(ds[i]) == want, (name, split, i)
+    assert gold["reward_trad_train"]["len"] < 6 * 4                        # the one-class query contributed no pair
+    # collated like the launchers' loaders: ppo_trad training batches are [bs, 2] labels and [bs, 2, F] float64 features
+    random.seed(1)
+    loader = torch.utils.data.DataLoader(ppo_trad.LTRDataset(None, root, is_train=True, max_tags=2), batch_size=4, num_workers=2)
+    gt, qid, feats = next(iter(loader))
+    assert gt.shape == (4, 2) and feats.shape == (4, 2, 46) and feats.dtype == torch.float64 and len(qid) == 4
+    gt, qid, feats = next(iter(torch.utils.data.DataLoader(pointwise_trad.LTRDataset(None, root, is_train=False), batch_size=2)))
+    assert gt.shape == (2, 20) and feats.shape == (2, 20, 136) and list(qid) == ["10002", "18"]
+
+
+@needs_hdf5
+@pytest.mark.gpu
+def test_ppo_trad_entry_point_trains_from_letor_h5_files(tmp_path):
+    """`python -m lr2ppo_amd.finetune.ppo_trad --train_path DIR --dev_path DIR` (no --synthetic_items): one PPO cycle and one
+    validation pass over real train.h5 / test.h5 files of 768-wide document features, checkpoint written, NDCG logged."""
+    from oracle import lr2ppo_oracle as O
+    from lr2ppo_amd.finetune import letor
+    root = str(tmp_path)
+    letor.write_split(root, True, O.fake_letor(seed=8, n_queries=3, feats=768))
+    letor.write_split(root, False, O.fake_letor(seed=9, n_queries=3, feats=768))
+    for split in ("train", "test"):                                        # labels of {0, 1, 2}, as the 3-class heads expect
+        with h5lite.File(os.path.join(root, f"{split}.h5")) as f:
+            tables = {k: f[k][()] for k in f.keys()}
+        for t in tables.values():
+            t[:, 0] = np.minimum(t[:, 0], 2)
+        letor.write_split(root, split == "train", tables)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29683", PYTHONPATH=REPO)
+    cmd = [sys.executable, "-m", "lr2ppo_amd.finetune.ppo_trad", "--config_path", "lr2ppo_amd/configs/roberta_base.json",
+           "--vit_config_path", "lr2ppo_amd/configs/vit_base_16_224.json", "--train_path", root, "--dev_path", root, "--seq_length", "196",
+           "--max_imgs", "16", "--visual_feat_dim", "768", "--learning_rate", "1e-4", "--batch_size", "4", "--mode", "reg", "--epochs_num", "2",
+           "--critic_learning_rate", "1e-4", "--max_timesteps", "1", "--update_timesteps", "2", "--kl_div_loss_weight", "0.001",
+           "--entropy_weight", "0.001", "--value_clip", "0.5", "--max_cycles", "1", "--output_model_path", os.path.join(root, "m.bin"),
+           "--log_path", os.path.join(root, "log.txt")]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    log = open(os.path.join(root, "log.txt")).read()
+    assert "The number of training instances: 60" in log and "NDCG@3" in log, log[-2000:]     # 3 queries x 20 pairs
+    assert os.path.exists(os.path.join(root, "m.bin"))
