@@ -174,7 +174,14 @@ def evaluate(args, model, dataloader, step, split="test", num_tasks=None):
                                     C=logits.shape[1], softmax=False)
         scores.append(logits.view(-1))
         golds.append(tgts.view(-1))
-    mine = ndcg_rows(scores, golds, args.device, tuple(ndcg_obj.ndcg_at_k))   # one kernel + one copy for the whole split
+    return report_ndcg(args, ndcg_obj, scores, golds, num_tasks)
+
+
+def report_ndcg(args, ndcg_obj, scores, golds, num_tasks=None):
+    """Tail of every pointwise `evaluate` (finetune/pointwise.py:352-412, pointwise_trad.py:296-340): NDCG@k per item -- one
+    kernel + one copy for the whole split --, gathered over ranks in the reference's item order, averaged and logged by the
+    master -> (NDCG@all, 0), (None, None) on the other ranks."""
+    mine = ndcg_rows(scores, golds, args.device, tuple(ndcg_obj.ndcg_at_k))
     world = num_tasks or 1
     if world > 1 and dist.is_initialized():
         gathered = [None] * world
@@ -323,41 +330,55 @@ def main(argv=None):
         trainset, valset = MovieNet(args, args.train_path, is_train=True), MovieNet(args, args.dev_path, is_train=False)
     train_loader = get_dataloader(args, trainset, num_tasks, global_rank, is_train=True)
     val_loader = get_dataloader(args, valset, num_tasks, global_rank, is_train=False)
-    args.train_steps = int(len(trainset) * args.epochs_num / args.batch_size) + 1
+    return run_training(args, model, [train_loader], val_loader, len(trainset), num_tasks)
+
+
+def run_training(args, model, train_loaders, val_loader, instances_num, num_tasks, *, build_optimizer=build_optimizer,
+                 train_model=train_model, evaluate=evaluate, batch_map=None):
+    """The epoch loop of finetune/pointwise.py:515-584 -- and of pointwise_trad.py:479-538 / pointwise_2data_trad.py:470-535, which
+    repeat it over LETOR queries: optimizer + schedule from `instances_num`, one `train_model` step per batch (per batch of EACH of
+    the zipped loaders, in turn, for the two-data-set twin), loss averaged over ranks for the log, validation + best-NDCG checkpoint
+    every `report_steps` iterations.  batch_map: loader batch -> (text_emb, img_emb | None, tgts)."""
+    args.train_steps = int(instances_num * args.epochs_num / args.batch_size) + 1
     if args.is_master:
         args.logger.info("Batch size: {}".format(args.batch_size))
-        args.logger.info("The number of training instances: {}".format(len(trainset)))
+        args.logger.info("The number of training instances: {}".format(instances_num))
     optimizer, scheduler = build_optimizer(args, model)
     args.model = model
     total_loss, best_result, step = 0.0, 0.0, 0
     if args.is_master:
         args.logger.info("Start training.")
     for epoch in range(1, args.epochs_num + 1):
-        train_loader.sampler.set_epoch(epoch)
+        for loader in train_loaders:
+            loader.sampler.set_epoch(epoch)
         model.train()
-        for i, (text_emb, img_emb, tgts) in enumerate(train_loader):
-            loss = train_model(args, model, optimizer, scheduler, text_emb.to(args.device), img_emb.to(args.device),
-                               tgts.to(args.device))
-            if num_tasks > 1:
-                dist.all_reduce(loss.div_(num_tasks))
-            total_loss += loss.item()
-            step += 1
-            if (i + 1) % args.report_steps == 0 or (args.max_steps and step >= args.max_steps):
-                if args.is_master:
-                    args.logger.info("Epoch id: {}, Training steps: {}, Avg loss: {:.3f}".format(
-                        epoch, i + 1, total_loss / args.report_steps))
-                    args.logger.info("Val set evaluation.")
-                total_loss = 0.0
-                result, _ = evaluate(args, model, val_loader, step, split="val", num_tasks=num_tasks)
-                if args.is_master:
-                    if result.item() > best_result:
-                        best_result = result.item()
-                        save_model(model, args.output_model_path)
-                        args.logger.info("Best NDCG until now!\n")
-                    args.logger.info("Best NDCG: {}".format(best_result))
-                model.train()
-            if args.max_steps and step >= args.max_steps:
-                return best_result
+        for i, batches in enumerate(zip(*train_loaders)):
+            for j, batch in enumerate(batches):
+                text_emb, img_emb, tgts = batch if batch_map is None else batch_map(batch)
+                loss = train_model(args, model, optimizer, scheduler, text_emb.to(args.device),
+                                   img_emb.to(args.device) if img_emb is not None else None, tgts.to(args.device))
+                if num_tasks > 1:
+                    dist.all_reduce(loss.div_(num_tasks))
+                total_loss += loss.item()
+                step += 1
+                last = j == len(batches) - 1
+                stop = bool(getattr(args, "max_steps", 0)) and step >= args.max_steps
+                if ((i + 1) % args.report_steps == 0 and last) or stop:
+                    if args.is_master:
+                        args.logger.info("Epoch id: {}, Training steps: {}, Avg loss: {:.3f}".format(
+                            epoch, i + 1, total_loss / args.report_steps))
+                        args.logger.info("Val set evaluation.")
+                    total_loss = 0.0
+                    result, _ = evaluate(args, model, val_loader, step, split="val", num_tasks=num_tasks)
+                    if args.is_master:
+                        if result.item() > best_result:
+                            best_result = result.item()
+                            save_model(model, args.output_model_path)
+                            args.logger.info("Best NDCG until now!\n")
+                        args.logger.info("Best NDCG: {}".format(best_result))
+                    model.train()
+                if stop:
+                    return best_result
     return best_result
 
 

@@ -97,6 +97,20 @@ def train_model(args, model, optimizer, scheduler, text_emb_batch, img_emb_batch
     target = tgts_batch.to(device=dev, dtype=torch.float32).contiguous().view(-1)
     ops.smooth_l1(logits.view(-1), target, loss, dlogits.view(-1), n=logits.numel(), beta=0.3)
     model.engine_backward(dlogits)
+    pt.average_grads(model)
     optimizer.step()
     scheduler.step()
     return loss[0]
+
+
+evaluate, get_dataloader = pt.evaluate, pt.get_dataloader        # pointwise_2data_trad.py:255-372 == pointwise_trad's
+
+
+def main(argv=None):
+    """Entry point: finetune/pointwise_2data_trad.py:374-535 -- two LETOR training sets (--train_path: MQ2008, 46 features;
+    --train_path2: MSLR-WEB10K, 136 features), one step from each per iteration through the projection of its width."""
+    return pt.main(argv, classifier=Classifier, step_fn=train_model, two_sets=True)
+
+
+if __name__ == "__main__":
+    main()

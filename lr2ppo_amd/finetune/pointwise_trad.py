@@ -14,7 +14,9 @@ from typing import Dict, Optional
 
 import torch
 import torch.nn as nn
-from torch.utils.data import Dataset
+import torch.distributed as dist
+from torch.utils.data import DataLoader, Dataset
+from torch.utils.data.distributed import DistributedSampler
 
 from .. import engine, ops, runtime
 from ..tencentpretrain.utils.optimizers import str2optimizer, str2scheduler
@@ -159,9 +161,115 @@ def train_model(args, model, optimizer, scheduler, text_emb_batch, img_emb_batch
     loss, dlogits = torch.empty(1, device=dev), torch.empty_like(logits)
     ops.smooth_l1(logits, target, loss, dlogits, n=logits.numel(), beta=0.3)
     model.engine_backward(dlogits)
+    average_grads(model)
     optimizer.step()
     scheduler.step()
     return loss[0]
+
+
+def average_grads(model):
+    """Mean of the bound gradients over the ranks before the step -- what DistributedDataParallel does for the reference
+    (pointwise_trad.py:446-448, the one DDP use under finetune/); a no-op on one rank.  The twins' models are small (no 2-GB
+    matrix): one all-reduce per gradient buffer."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    world = dist.get_world_size()
+    works = [dist.all_reduce(p.grad.div_(world), async_op=True) for p in model.parameters() if p.grad is not None]
+    for w in works:
+        w.wait()
+
+
+@torch.no_grad()
+def evaluate(args, model, dataloader, step=0, split="test", num_tasks=None):
+    """pointwise_trad.py:257-340, mode 'reg': `dataloader` yields (ground_truths [1, docs], query_id, features [1, docs, F]) like
+    LTRDataset; per query the NDCG@k of the labels re-ordered by predicted score -> (NDCG@all, 0) on the master."""
+    from .pointwise import report_ndcg
+    from ..ndcg import AverageNDCGMeter
+    model.eval()
+    scores, golds = [], []
+    for ground_truths, _, features in dataloader:
+        logits = model.engine_forward(features.to(device=args.device, dtype=torch.float32), save=False)
+        scores.append(logits.view(-1))
+        golds.append(ground_truths.view(-1).to(torch.int64))
+    return report_ndcg(args, AverageNDCGMeter(), scores, golds, num_tasks)
+
+
+def get_dataloader(args, dataset, num_tasks, global_rank, is_train=False):
+    """pointwise_trad.py:342-357: shuffled batches of args.batch_size without the ragged last one, validation one query at a time."""
+    sampler = DistributedSampler(dataset, num_replicas=num_tasks, rank=global_rank, shuffle=is_train)
+    return DataLoader(dataset=dataset, batch_size=args.batch_size if is_train else 1, sampler=sampler,
+                      num_workers=getattr(args, "num_workers", 2), drop_last=is_train)
+
+
+def letor_batch(batch):
+    """LTRDataset batch (ground_truths, query ids, features f64) -> (text_emb f32, None, tgts) (pointwise_trad.py:489-491)."""
+    ground_truths, _, features = batch
+    return features.to(torch.float32), None, ground_truths
+
+
+def build_parser():
+    """finetune/pointwise_trad.py:376-404 = finetune/pointwise.py's flags (+ this build's --synthetic_items / --max_steps)."""
+    from .pointwise import build_parser as stage1_parser
+    parser = stage1_parser()
+    parser.add_argument("--train_path2", type=str, required=False, help="second training set (pointwise_2data_trad.py:401)")
+    return parser
+
+
+def main(argv=None, classifier=None, step_fn=None, two_sets=False):
+    """Entry point: finetune/pointwise_trad.py:376-538 -- BASELINE configs[0].  --train_path / --dev_path name directories that hold
+    train.h5 / test.h5 (LTRDataset); --synthetic_items N runs on seeded queries instead.
+        python -m lr2ppo_amd.finetune.pointwise_trad --train_path DATA --dev_path DATA --batch_size 8 --epochs_num 1 --report_steps 10 ..."""
+    import argparse
+    from copy import copy
+    from . import misc, pointwise as pw
+    from ..tencentpretrain.utils.config import load_hyperparam
+    from ..tencentpretrain.utils.logging import init_logger
+    args = build_parser().parse_args(argv)
+    vit_args_dict = copy(vars(args))
+    for k, v in vars(args).items():
+        if "vit_" in k:
+            vit_args_dict[k[4:]] = v
+    args = load_hyperparam(args)
+    args.labels_num = 3
+    misc.init_distributed_mode(args)
+    misc.setup_seed(args.seed + misc.get_rank())
+    args.is_master = misc.is_main_process()
+    num_tasks, global_rank = misc.get_world_size(), misc.get_rank()
+    model = (classifier or Classifier)(args, argparse.Namespace(**vit_args_dict))
+    load_or_initialize_parameters(args, model)
+    if args.is_master:
+        args.logger = init_logger(args)
+    args.device = torch.device("cuda", torch.cuda.current_device())
+    model = model.to(args.device)
+    if num_tasks > 1:          # DDP broadcasts rank 0's parameters when it wraps the model (pointwise_trad.py:448)
+        for p in model.parameters():
+            dist.broadcast(p.data, src=0)
+    if args.synthetic_items > 0:
+        widths = (46, 136) if two_sets else (FEAT,)          # the two-data-set twin projects raw LETOR rows (46 | 136 features)
+        trainsets = [_SyntheticRows(args.synthetic_items, 20, args.seed + 7 * k, w) for k, w in enumerate(widths)]
+        valset = _SyntheticRows(args.synthetic_val_items, 20, args.seed + 1, widths[0])
+    else:
+        paths = [args.train_path, args.train_path2] if two_sets else [args.train_path]
+        trainsets = [LTRDataset(args, path, is_train=True) for path in paths]
+        valset = LTRDataset(args, args.dev_path, is_train=False)
+    loaders = [get_dataloader(args, ts, num_tasks, global_rank, is_train=True) for ts in trainsets]
+    val_loader = get_dataloader(args, valset, num_tasks, global_rank, is_train=False)
+    return pw.run_training(args, model, loaders, val_loader, len(trainsets[0]), num_tasks, build_optimizer=build_optimizer,
+                           train_model=step_fn or train_model, evaluate=evaluate, batch_map=letor_batch)
+
+
+class _SyntheticRows(Dataset):
+    """SyntheticLTR in LTRDataset's item order: (ground_truths [docs], query id, features [docs, 768])."""
+
+    def __init__(self, n_queries, docs=20, seed=7, width=FEAT):
+        self.inner, self.width = SyntheticLTR(n_queries, docs, seed), width
+
+    def __len__(self):
+        return len(self.inner)
+
+    def __getitem__(self, i):
+        feats, _, gt = self.inner[i]
+        return gt, str(i), feats[:, :self.width].contiguous()
 
 
 class LTRDataset(QueryRows):
@@ -181,3 +289,7 @@ class SyntheticLTR(Dataset):
     def __getitem__(self, i):
         g = torch.Generator().manual_seed(self.seed * 1000003 + i)
         return torch.randn(self.docs, FEAT, generator=g), torch.zeros(1), torch.randint(0, 3, (self.docs,), generator=g)
+
+
+if __name__ == "__main__":
+    main()

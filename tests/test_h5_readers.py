@@ -200,3 +200,44 @@ def test_ppo_trad_entry_point_trains_from_letor_h5_files(tmp_path):
     log = open(os.path.join(root, "log.txt")).read()
     assert "The number of training instances: 60" in log and "NDCG@3" in log, log[-2000:]     # 3 queries x 20 pairs
     assert os.path.exists(os.path.join(root, "m.bin"))
+
+
+def _letor_dirs(tmp_path, widths):
+    from oracle import lr2ppo_oracle as O
+    from lr2ppo_amd.finetune import letor
+    dirs = []
+    for k, width in enumerate(widths):
+        d = str(tmp_path / f"set{k}")
+        for is_train, seed in ((True, 30 + k), (False, 40 + k)):
+            tables = O.fake_letor(seed=seed, n_queries=6, feats=width)
+            for t in tables.values():
+                t[:, 0] = np.minimum(t[:, 0], 2)
+            letor.write_split(d, is_train, tables)
+        dirs.append(d)
+    return dirs
+
+
+_TRAD_FLAGS = ["--config_path", "lr2ppo_amd/configs/roberta_base.json", "--vit_config_path", "lr2ppo_amd/configs/vit_base_16_224.json",
+               "--seq_length", "196", "--max_imgs", "16", "--visual_feat_dim", "768", "--learning_rate", "1e-4", "--batch_size", "2",
+               "--mode", "reg", "--epochs_num", "1", "--report_steps", "2"]
+
+
+@needs_hdf5
+@pytest.mark.gpu
+@pytest.mark.parametrize("twin", ["pointwise_trad", "pointwise_2data_trad"])
+def test_pointwise_trad_entry_points_train_from_letor_h5_files(tmp_path, twin):
+    """BASELINE configs[0] end to end: `python -m lr2ppo_amd.finetune.pointwise_trad` on train.h5 / test.h5 of 768-wide document
+    features, and the two-data-set twin on a 46-wide (MQ2008) + a 136-wide (MSLR-WEB10K) set through its two projections: 3 batches
+    of 2 queries, validation NDCG over the 6 test queries after batch 2, best checkpoint written with the twin's own keys."""
+    two = twin.endswith("2data_trad")
+    dirs = _letor_dirs(tmp_path, (46, 136) if two else (768,))
+    out, log = str(tmp_path / "m.bin"), str(tmp_path / "log.txt")
+    cmd = [sys.executable, "-m", f"lr2ppo_amd.finetune.{twin}", *_TRAD_FLAGS, "--train_path", dirs[0], "--dev_path", dirs[0],
+           "--output_model_path", out, "--log_path", log] + (["--train_path2", dirs[1]] if two else [])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29684", PYTHONPATH=REPO)
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    text = open(log).read()
+    assert "The number of training instances: 6" in text and "Training steps: 2" in text and "NDCG@3=" in text, text[-2000:]
+    keys = set(torch.load(out, map_location="cpu").keys())
+    assert "out_layer.fc1.weight" in keys and ("text_proj3.fc1.weight" in keys) == two
