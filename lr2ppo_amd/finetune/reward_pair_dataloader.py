@@ -301,10 +301,18 @@ def main(argv=None):
     val_loader = get_dataloader(args, valset, num_tasks, global_rank, is_train=False)
     if fx is not None:
         train_loader, val_loader = ExtractingLoader(train_loader, fx, args.device), ExtractingLoader(val_loader, fx, args.device)
-    args.train_steps = int(len(trainset) * args.epochs_num / args.batch_size) + 1
+    return run_training(args, model, train_loader, val_loader, len(trainset), num_tasks)
+
+
+def run_training(args, model, train_loader, val_loader, instances_num, num_tasks, *, train_model=train_model, evaluate=evaluate,
+                 batch_map=None):
+    """The epoch loop of reward_pair_dataloader.py:531-592 -- and of reward_trad.py:440-503, which repeats it over LETOR pairs:
+    one `train_model` step per batch, loss / accuracy averaged over ranks for the log, validation + best-accuracy checkpoint every
+    `report_steps` batches.  batch_map: loader batch -> (text_emb, img_emb | None, tgts, chosen_index, reject_index)."""
+    args.train_steps = int(instances_num * args.epochs_num / args.batch_size) + 1
     if args.is_master:
         args.logger.info("Batch size: {}".format(args.batch_size))
-        args.logger.info("The number of training instances: {}".format(len(trainset)))
+        args.logger.info("The number of training instances: {}".format(instances_num))
     optimizer, scheduler = build_optimizer(args, model)
     args.model = model
     total_loss, total_acc, total_cnt, best_acc, step = 0.0, 0.0, 0, 0.0, 0
@@ -313,8 +321,10 @@ def main(argv=None):
     for epoch in range(1, args.epochs_num + 1):
         train_loader.sampler.set_epoch(epoch)
         model.train()
-        for i, (text_emb, img_emb, tgts, chosen_index, reject_index) in enumerate(train_loader):
-            loss, acc = train_model(args, model, optimizer, scheduler, text_emb.to(args.device), img_emb.to(args.device),
+        for i, batch in enumerate(train_loader):
+            text_emb, img_emb, tgts, chosen_index, reject_index = batch if batch_map is None else batch_map(batch)
+            loss, acc = train_model(args, model, optimizer, scheduler, text_emb.to(args.device),
+                                    img_emb.to(args.device) if img_emb is not None else None,
                                     tgts.to(args.device), chosen_index.to(args.device), reject_index.to(args.device))
             if num_tasks > 1:
                 dist.all_reduce(loss.div_(num_tasks))
@@ -323,7 +333,8 @@ def main(argv=None):
             total_acc += acc.item()
             total_cnt += 1
             step += 1
-            if (i + 1) % args.report_steps == 0 or (args.max_steps and step >= args.max_steps):
+            stop = bool(getattr(args, "max_steps", 0)) and step >= args.max_steps
+            if (i + 1) % args.report_steps == 0 or stop:
                 if args.is_master:
                     args.logger.info("Epoch id: {}, Training steps: {}, Avg loss: {:.3f}, Acc: {:.3f}".format(
                         epoch, i + 1, total_loss / total_cnt, total_acc / total_cnt))
@@ -337,7 +348,7 @@ def main(argv=None):
                         args.logger.info("Best Acc until now!\n")
                     args.logger.info("Best Acc: {}".format(best_acc))
                 model.train()
-            if args.max_steps and step >= args.max_steps:
+            if stop:
                 return best_acc
     return best_acc
 

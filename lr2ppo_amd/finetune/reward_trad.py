@@ -63,3 +63,55 @@ class SyntheticTradPairs(Dataset):
         chosen = torch.randint(0, self.docs, (4,), generator=g)
         reject = torch.randint(0, self.docs, (4,), generator=g)
         return gt, i, feats, chosen, reject
+
+
+def letor_batch(batch):
+    """LTRDataset batch -> (text_emb f32, None, tgts, chosen_index, reject_index) (reward_trad.py:458-463)."""
+    ground_truths, _, features, chosen_index, reject_index = batch
+    return features.to(torch.float32), None, ground_truths, chosen_index, reject_index
+
+
+def main(argv=None):
+    """Entry point: finetune/reward_trad.py:352-503 -- the pairwise reward model on LETOR queries.  --train_path / --dev_path
+    name directories holding train.h5 / test.h5 (LTRDataset draws max_tags = 20 label-stratified pairs per query for either
+    split); --synthetic_items N runs on seeded pairs instead.
+        python -m lr2ppo_amd.finetune.reward_trad --train_path DATA --dev_path DATA --batch_size 8 --epochs_num 1 --report_steps 10 ..."""
+    import argparse
+    from copy import copy
+    from . import misc
+    from ..tencentpretrain.utils.config import load_hyperparam
+    from ..tencentpretrain.utils.logging import init_logger
+    args = rp.build_parser().parse_args(argv)
+    vit_args_dict = copy(vars(args))
+    for k, v in vars(args).items():
+        if "vit_" in k:
+            vit_args_dict[k[4:]] = v
+    args = load_hyperparam(args)
+    args.labels_num = 3
+    args.fuse_fc1_update = False                 # no 2-GB out_layer.fc1 at sequence length 1: every gradient through lr2_adamw_multi
+    misc.init_distributed_mode(args)
+    misc.setup_seed(args.seed + misc.get_rank())
+    args.is_master = misc.is_main_process()
+    num_tasks, global_rank = misc.get_world_size(), misc.get_rank()
+    model = Classifier(args, argparse.Namespace(**vit_args_dict))
+    load_or_initialize_parameters(args, model)
+    if args.is_master:
+        args.logger = init_logger(args)
+    args.device = torch.device("cuda", torch.cuda.current_device())
+    model = model.to(args.device)
+    if num_tasks > 1:
+        import torch.distributed as dist
+        for p in model.parameters():
+            dist.broadcast(p.data, src=0)
+    if args.synthetic_items > 0:
+        trainset, valset = SyntheticTradPairs(args.synthetic_items, 20, args.seed), SyntheticTradPairs(args.synthetic_val_items, 20, args.seed + 1)
+    else:
+        trainset, valset = LTRDataset(args, args.train_path, is_train=True), LTRDataset(args, args.dev_path, is_train=False)
+    train_loader = rp.get_dataloader(args, trainset, num_tasks, global_rank, is_train=True)
+    val_loader = rp.get_dataloader(args, valset, num_tasks, global_rank, is_train=False)
+    return rp.run_training(args, model, train_loader, val_loader, len(trainset), num_tasks, train_model=train_model,
+                           evaluate=evaluate, batch_map=letor_batch)
+
+
+if __name__ == "__main__":
+    main()

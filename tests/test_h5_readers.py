@@ -241,3 +241,21 @@ def test_pointwise_trad_entry_points_train_from_letor_h5_files(tmp_path, twin):
     assert "The number of training instances: 6" in text and "Training steps: 2" in text and "NDCG@3=" in text, text[-2000:]
     keys = set(torch.load(out, map_location="cpu").keys())
     assert "out_layer.fc1.weight" in keys and ("text_proj3.fc1.weight" in keys) == two
+
+
+@needs_hdf5
+@pytest.mark.gpu
+def test_reward_trad_entry_point_trains_from_letor_h5_files(tmp_path):
+    """`python -m lr2ppo_amd.finetune.reward_trad` (stage 2 at sequence length 1) on real train.h5 / test.h5: LTRDataset's
+    label-stratified pairs, hinge steps, validation accuracy logged, best checkpoint written."""
+    (d,) = _letor_dirs(tmp_path, (768,))
+    out, log = str(tmp_path / "r.bin"), str(tmp_path / "log.txt")
+    flags = [f if f != "2" or _TRAD_FLAGS[i - 1] != "--batch_size" else "8" for i, f in enumerate(_TRAD_FLAGS)]
+    cmd = [sys.executable, "-m", "lr2ppo_amd.finetune.reward_trad", *flags, "--train_path", d, "--dev_path", d,
+           "--output_model_path", out, "--log_path", log]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29685", PYTHONPATH=REPO)
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    text = open(log).read()
+    assert "The number of training instances: 100" in text and "Training steps: 2" in text and "val accuracy:" in text, text[-2000:]
+    assert "pos_emb.weight" in torch.load(out, map_location="cpu")
