@@ -51,3 +51,14 @@ def test_two_rank_encoder_finetune_keeps_replicas_identical(dev):
            "--master-port", "29613", os.path.join(REPO, "tests", "workers", "dp_finetune_worker.py")]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "DP_FINETUNE_REPLICAS_IDENTICAL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_two_rank_trad_pointwise_steps_match_the_whole_batch_step(dev):
+    """pointwise_trad / pointwise_2data_trad on two gloo ranks sharing the GPU (the script the reference runs under DDP): gradients
+    averaged over the ranks -> replicas bit-identical, and equal to one step on the concatenated batch up to summation order
+    (tests/workers/dp_trad_worker.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29614", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29614", os.path.join(REPO, "tests", "workers", "dp_trad_worker.py")]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "DP_TRAD_REPLICAS_IDENTICAL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
