@@ -22,6 +22,13 @@ echo "== stage 3 at sequence length 1 (ppo_trad twin), synthetic LETOR-shaped qu
 python -m lr2ppo_amd.finetune.ppo_trad $COMMON --mode reg --epochs_num 2 --critic_learning_rate 1e-4 --max_timesteps 1 \
   --update_timesteps 2 --kl_div_loss_weight 0.001 --entropy_weight 0.001 --value_clip 0.5 --synthetic_items 8 \
   --synthetic_val_items 3 --max_cycles 1 --output_model_path "$OUT/stage3_trad.bin" --log_path "$OUT/stage3_trad.log"
+echo "== BASELINE configs[0]: the _trad pointwise / pairwise twins (sequence length 1), synthetic LETOR-shaped queries"
+python -m lr2ppo_amd.finetune.pointwise_trad $COMMON --mode reg --epochs_num 1 --report_steps 2 --synthetic_items 8 \
+  --synthetic_val_items 3 --max_steps 2 --output_model_path "$OUT/trad1.bin" --log_path "$OUT/trad1.log"
+python -m lr2ppo_amd.finetune.pointwise_2data_trad $COMMON --mode reg --epochs_num 1 --report_steps 2 --synthetic_items 8 \
+  --synthetic_val_items 3 --max_steps 4 --output_model_path "$OUT/trad2.bin" --log_path "$OUT/trad2.log"
+python -m lr2ppo_amd.finetune.reward_trad $COMMON --mode reg --epochs_num 1 --report_steps 2 --synthetic_items 8 \
+  --synthetic_val_items 4 --max_steps 2 --output_model_path "$OUT/trad_reward.bin" --log_path "$OUT/trad_reward.log"
 echo "== stage 1 on RAW inputs: ViT + RoBERTa stacks (2 layers each here) in front of the head, trained end to end"
 python -m lr2ppo_amd.finetune.pointwise $COMMON --mode reg --max_tags 2 --epochs_num 1 --report_steps 2 --synthetic_items 4 \
   --synthetic_val_items 2 --max_steps 2 --raw_inputs --finetune_encoders --encoder_layers 2 \
