@@ -81,6 +81,8 @@ def _load():
             "H5Tget_class": (ctypes.c_int, [_hid]), "H5Tget_size": (ctypes.c_size_t, [_hid]), "H5Tget_sign": (ctypes.c_int, [_hid]),
             "H5Tget_native_type": (_hid, [_hid, ctypes.c_int]), "H5Tclose": (ctypes.c_int, [_hid]),
             "H5Pcreate": (_hid, [_hid]), "H5Pset_fclose_degree": (ctypes.c_int, [_hid, ctypes.c_int]), "H5Pclose": (ctypes.c_int, [_hid]),
+            "H5Pset_chunk": (ctypes.c_int, [_hid, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]),
+            "H5Pset_deflate": (ctypes.c_int, [_hid, ctypes.c_uint]), "H5Zfilter_avail": (ctypes.c_int, [ctypes.c_int]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(lib, name)
@@ -249,15 +251,35 @@ class Group:
             raise ValueError(f"Unable to create group '{name}' (exists already, or the file is read-only)")
         return Group(gid, f"{self.name.rstrip('/')}/{name}", self.file)
 
-    def create_dataset(self, name, data=None, shape=None, dtype=None):
+    def create_dataset(self, name, data=None, shape=None, dtype=None, chunks=None, compression=None, compression_opts=4):
+        """h5py's create_dataset for numeric arrays.  chunks: a chunk shape (or True: one chunk per leading index);
+        compression="gzip" (needs chunks; h5py picks them itself, here True is implied) with level `compression_opts`."""
         lib = _load()
         arr = np.array(np.zeros(shape, dtype or "f4") if data is None else data, dtype=dtype, order="C")   # 0-d stays 0-d
         tid = _native_id(arr.dtype)
         dims = (ctypes.c_uint64 * max(arr.ndim, 1))(*arr.shape)
+        if compression not in (None, "gzip"):
+            raise ValueError("h5lite writes compression=None or 'gzip'")
+        if compression and not chunks:
+            chunks = True
+        dcpl = 0
         with _lock:
+            if chunks and arr.ndim and arr.size:
+                cshape = ((1,) + arr.shape[1:]) if chunks is True else tuple(int(c) for c in chunks)
+                if len(cshape) != arr.ndim or min(cshape) < 1:
+                    raise ValueError("chunks must give one positive extent per dimension")
+                dcpl = lib.H5Pcreate(_hid.in_dll(lib, "H5P_CLS_DATASET_CREATE_ID_g").value)
+                lib.H5Pset_chunk(dcpl, arr.ndim, (ctypes.c_uint64 * arr.ndim)(*cshape))
+                if compression:
+                    if lib.H5Zfilter_avail(1) <= 0:                      # H5Z_FILTER_DEFLATE
+                        lib.H5Pclose(dcpl)
+                        raise ValueError("this HDF5 library was built without the gzip filter")
+                    lib.H5Pset_deflate(dcpl, int(compression_opts))
             space = lib.H5Screate_simple(arr.ndim, dims, None) if arr.ndim else lib.H5Screate(0)      # 0: H5S_SCALAR
-            did = lib.H5Dcreate2(self._id, name.encode(), tid, space, 0, 0, 0)
+            did = lib.H5Dcreate2(self._id, name.encode(), tid, space, 0, dcpl, 0)
             lib.H5Sclose(space)
+            if dcpl:
+                lib.H5Pclose(dcpl)
             if did < 0:
                 raise ValueError(f"Unable to create dataset '{name}' (exists already, or the file is read-only)")
             if arr.size and lib.H5Dwrite(did, tid, 0, 0, 0, arr.ctypes.data_as(ctypes.c_void_p)) < 0:

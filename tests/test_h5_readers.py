@@ -3,7 +3,7 @@
 `lr2ppo_amd.h5lite` binds the HDF5 C library the image ships (no h5py here); these tests write LRMovieNet- and LETOR-shaped
 files through it, check them with the library's own `h5dump` where that tool exists, and run the product's readers against
 fixtures the REFERENCE's reader classes produced on the same real files (tests/golden/letor_readers.json, readers.json;
-oracle/gen_golden.py::gen_letor_readers, gen_readers).  CPU except the last test (ppo_trad's entry point on LETOR files).
+oracle/gen_golden.py::gen_letor_readers, gen_readers).  The `gpu`-marked tests run the four `_trad` entry points on LETOR files.
 """
 import argparse
 import json
@@ -95,6 +95,29 @@ def test_h5lite_files_are_valid_hdf5_by_the_librarys_own_dump_tool(tmp_path):
         assert want in head, (want, head)
     data = subprocess.run([tool, "-d", "/41/img_emb", path], capture_output=True, text=True, check=True).stdout
     assert "(0,0,0): 0, 1," in data and "(0,4,0): 8, 9" in data, data
+
+
+@needs_hdf5
+def test_h5lite_reads_chunked_and_gzip_compressed_datasets(tmp_path):
+    """Files made elsewhere may store features chunked / deflated (h5py's compression="gzip"): the library decodes them on read;
+    h5dump confirms the storage really is chunked + deflated."""
+    path = str(tmp_path / "z.h5")
+    rng = np.random.RandomState(1)
+    text = np.round(rng.standard_normal((5, 196, 768)), 1).astype(np.float32)       # compressible
+    table = rng.standard_normal((20, 138))
+    with h5lite.File(path, "w") as f:
+        g = f.create_group("3")
+        g.create_dataset("text_emb", data=text, compression="gzip")
+        g.create_dataset("img_emb", data=text[:1, :16], chunks=(1, 4, 768))
+        f.create_dataset("77", data=table, chunks=True, compression="gzip", compression_opts=9)
+    assert os.path.getsize(path) < 0.6 * text.nbytes
+    with h5lite.File(path) as f:
+        assert np.array_equal(f["3"]["text_emb"][:], text) and np.array_equal(f["3"]["img_emb"][:][0], text[0, :16])
+        assert np.array_equal(f["77"][()], table)
+    tool = shutil.which("h5dump") or os.path.join(os.path.dirname(os.path.dirname(h5lite.library()[0])), "bin", "h5dump")
+    if os.path.exists(tool):
+        props = subprocess.run([tool, "-p", "-H", path], capture_output=True, text=True, check=True).stdout
+        assert "CHUNKED" in props and "COMPRESSION DEFLATE { LEVEL 9 }" in props and "COMPRESSION DEFLATE { LEVEL 4 }" in props, props
 
 
 def _write_movienet(root):
