@@ -729,6 +729,78 @@ def gen_readers():
     print("wrote readers.json", {k: v["len"] for k, v in out.items()})
 
 
+def _layout_digest(state_dict):
+    import hashlib
+    text = ";".join(f"{k}:{tuple(v.shape)}:{str(v.dtype).replace('torch.', '')}" for k, v in state_dict.items())
+    return hashlib.sha256(text.encode()).hexdigest()
+
+
+def gen_bin_interchange():
+    """SURVEY 8(f)-3, the `.bin` half: checkpoints cross the boundary in BOTH directions, through the two sides' own save / load code.
+    For every model class: the reference module's weights saved by the reference's `save_model` are loaded by the product's loader
+    (`strict=True` where upstream is strict) into the product's module and compared tensor by tensor; the product's checkpoint is loaded
+    `strict=True` into the reference module and compared.  What is frozen is the LAYOUT that made the trip (a digest of names, shapes and
+    dtypes in state_dict order + counts): the CPU test holds the product's current modules to it.  (The authors' released files are not
+    in the image; they are state_dicts of these same reference classes.)"""
+    import tempfile
+    import ppo
+    import ppo_trad
+    import pointwise
+    import pointwise_trad
+    import pointwise_2data_trad
+    import reward_pair_dataloader
+    import reward_trad
+    from tencentpretrain.model_saver import save_model
+    from lr2ppo_amd.finetune import (pointwise as p_pw, pointwise_2data_trad as p_p2, pointwise_trad as p_pt, ppo as p_ppo,
+                                     ppo_trad as p_ppt, reward_pair_dataloader as p_rp, reward_trad as p_rt)
+    from lr2ppo_amd.tencentpretrain.model_saver import save_model as p_save
+    args = _ns(**HEAD_ARGS)
+    cases = [("ppo.Actor", ppo.Actor, p_ppo.Actor, p_ppo.load_or_initialize_parameters, "pretrained_model_path"),
+             ("ppo.Critic", ppo.Critic, p_ppo.Critic, p_ppo.load_or_initialize_parameters_reward, "reward_model_path"),
+             ("ppo.Reward", ppo.Reward, p_ppo.Reward, p_ppo.load_or_initialize_parameters_reward, "reward_model_path"),
+             ("pointwise.Classifier", pointwise.Classifier, p_pw.Classifier, None, None),
+             ("reward_pair_dataloader.Classifier", reward_pair_dataloader.Classifier, p_rp.Classifier, None, None),
+             ("ppo_trad.Actor", ppo_trad.Actor, p_ppt.Actor, p_ppt.load_or_initialize_parameters, "pretrained_model_path"),
+             ("ppo_trad.Critic", ppo_trad.Critic, p_ppt.Critic, p_ppt.load_or_initialize_parameters_reward, "reward_model_path"),
+             ("ppo_trad.Reward", ppo_trad.Reward, p_ppt.Reward, p_ppt.load_or_initialize_parameters_reward, "reward_model_path"),
+             ("pointwise_trad.Classifier", pointwise_trad.Classifier, p_pt.Classifier, None, None),
+             ("pointwise_2data_trad.Classifier", pointwise_2data_trad.Classifier, p_p2.Classifier, None, None),
+             ("reward_trad.Classifier", reward_trad.Classifier, p_rt.Classifier, None, None)]
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, ref_cls, prod_cls, loader, flag in cases:
+            torch.manual_seed(abs(hash(name)) % 1000)
+            ref = ref_cls(args, None)
+            with torch.no_grad():
+                for q in ref.parameters():
+                    q.normal_(0, 0.02)
+            path = os.path.join(tmp, "ref.bin")
+            save_model(ref, path)                                             # the reference's own writer
+            prod = prod_cls(args, None)
+            if loader is not None:                                            # the product's own strict loader
+                loader(_ns(**{flag: path}), prod)
+            else:
+                prod.load_state_dict(torch.load(path, map_location="cpu"), strict=True)
+            rs, ps = ref.state_dict(), prod.state_dict()
+            assert list(rs.keys()) == list(ps.keys()), name
+            assert all(torch.equal(rs[k], ps[k]) for k in rs), name
+            with torch.no_grad():
+                for q in prod.parameters():
+                    q.mul_(1.5)
+            back = os.path.join(tmp, "prod.bin")
+            p_save(prod, back)                                                # the product's writer
+            ref2 = ref_cls(args, None)
+            ref2.load_state_dict(torch.load(back, map_location="cpu"), strict=True)   # upstream's strict load (ppo.py:360-361)
+            assert all(torch.equal(ref2.state_dict()[k], prod.state_dict()[k]) for k in rs), name
+            out[name] = {"tensors": len(rs), "elements": int(sum(v.numel() for v in rs.values())), "layout_sha256": _layout_digest(rs),
+                         "reference_to_product": "strict load, every tensor equal", "product_to_reference": "strict load, every tensor equal"}
+            print(name, out[name]["tensors"], out[name]["elements"], flush=True)
+            del ref, prod, ref2, rs, ps
+    with open(os.path.join(GOLD, "bin_interchange.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote bin_interchange.json")
+
+
 def gen_letor_readers():
     """Outputs of the reference's four `LTRDataset` classes (pointwise_trad / pointwise_2data_trad / ppo_trad / reward_trad)
     on REAL HDF5 files: oracle.fake_letor tables written in datasets_trad/convert_to_h5py.py's layout through
@@ -1005,7 +1077,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, letor_readers=gen_letor_readers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls, ppo_trad=gen_ppo_trad, reward_trad=gen_reward_trad, trad2=gen_trad2)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, letor_readers=gen_letor_readers, bin_interchange=gen_bin_interchange, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls, ppo_trad=gen_ppo_trad, reward_trad=gen_reward_trad, trad2=gen_trad2)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -237,6 +237,33 @@ def test_stage1_stage2_modules_mirror_the_reference_surface():
     assert lab[ch[2]] >= lab[ch[3]]
 
 
+def test_checkpoint_layouts_are_the_ones_that_crossed_to_the_reference_and_back():
+    """SURVEY 8(f)-3, the `.bin` half.  oracle/gen_golden.py::gen_bin_interchange wrote each reference module with the reference's
+    save_model, loaded it strict=True through the product's loader, wrote the product's checkpoint with the product's save_model and
+    loaded THAT strict=True into the reference module -- every tensor equal both ways, for the 11 model classes -- and froze the layout
+    that made the trip (names, shapes, dtypes in state_dict order).  Here: the product's modules still have exactly that layout
+    (built on the meta device: no 2-GB allocations)."""
+    import hashlib
+    from lr2ppo_amd.finetune import (pointwise, pointwise_2data_trad, pointwise_trad, ppo, ppo_trad, reward_pair_dataloader,
+                                     reward_trad)
+    with open(os.path.join(GOLD, "bin_interchange.json")) as f:
+        gold = json.load(f)
+    classes = {"ppo.Actor": ppo.Actor, "ppo.Critic": ppo.Critic, "ppo.Reward": ppo.Reward, "pointwise.Classifier": pointwise.Classifier,
+               "reward_pair_dataloader.Classifier": reward_pair_dataloader.Classifier, "ppo_trad.Actor": ppo_trad.Actor,
+               "ppo_trad.Critic": ppo_trad.Critic, "ppo_trad.Reward": ppo_trad.Reward, "pointwise_trad.Classifier": pointwise_trad.Classifier,
+               "pointwise_2data_trad.Classifier": pointwise_2data_trad.Classifier, "reward_trad.Classifier": reward_trad.Classifier}
+    assert set(gold) == set(classes)
+    args = argparse.Namespace(mode="reg", labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768)
+    for name, cls in classes.items():
+        with torch.device("meta"):
+            sd = cls(args, None).state_dict()
+        text = ";".join(f"{k}:{tuple(v.shape)}:{str(v.dtype).replace('torch.', '')}" for k, v in sd.items())
+        g = gold[name]
+        assert (len(sd), sum(v.numel() for v in sd.values())) == (g["tensors"], g["elements"]), name
+        assert hashlib.sha256(text.encode()).hexdigest() == g["layout_sha256"], name
+        assert g["reference_to_product"] == g["product_to_reference"] == "strict load, every tensor equal"
+
+
 def test_stage_launcher_arguments_parse():
     """Argument lists of pointwise.sh and reward_pair_dataloader.sh (paths shortened)."""
     from lr2ppo_amd.finetune import pointwise as pw, reward_pair_dataloader as rp
