@@ -799,6 +799,51 @@ def gen_bin_interchange():
     with open(os.path.join(GOLD, "bin_interchange.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("wrote bin_interchange.json")
+    gen_bin_towers()
+
+
+def gen_bin_towers():
+    """The encoder half of gen_bin_interchange (merged into the same fixture): reference-written tower checkpoints through
+    FeatureExtractor.load_pretrained."""
+    import tempfile
+    from tencentpretrain.model_saver import save_model
+    with open(os.path.join(GOLD, "bin_interchange.json")) as f:
+        out = json.load(f)
+    with tempfile.TemporaryDirectory() as tmp:
+        # the two pre-trained towers: TencentPretrain checkpoints = state_dict of a module holding `embedding`, `encoder` and a
+        # `target` head (models/model.py:9-30); FeatureExtractor.load_pretrained takes the first two strict and drops the third
+        from tencentpretrain.embeddings import Embedding, str2embedding
+        from tencentpretrain.encoders import str2encoder
+        from lr2ppo_amd.finetune.features import FeatureExtractor, encoder_args, TEXT_CONFIG, VIT_CONFIG
+        paths = {}
+        refs = {}
+        for tower, cfg in (("vit", "models/vit/base-16-224_config.json"), ("roberta", "models/xlm-roberta/base_config.json")):
+            a = _encoder_args(cfg)
+            emb = Embedding(a)
+            for e in a.embedding:
+                emb.update(str2embedding[e](a, 50265), e)
+            holder = torch.nn.Module()
+            holder.embedding, holder.encoder, holder.target = emb, str2encoder[a.encoder](a), torch.nn.Linear(4, 4)
+            torch.manual_seed(len(tower))
+            with torch.no_grad():
+                for q in holder.parameters():
+                    q.normal_(0, 0.02)
+            paths[tower] = os.path.join(tmp, tower + ".bin")
+            save_model(holder, paths[tower])
+            refs[tower] = {k: v for k, v in holder.state_dict().items() if not k.startswith("target.")}
+        fx = FeatureExtractor(encoder_args(VIT_CONFIG), encoder_args(TEXT_CONFIG))
+        fx.load_pretrained(paths["vit"], paths["roberta"])
+        for tower, stack in (("vit", fx.image), ("roberta", fx.text)):
+            ps = stack.state_dict()
+            assert list(ps.keys()) == list(refs[tower].keys()), tower
+            assert all(torch.equal(ps[k], refs[tower][k]) for k in ps), tower
+            out["tower." + tower] = {"tensors": len(ps), "elements": int(sum(v.numel() for v in ps.values())),
+                                     "layout_sha256": _layout_digest(ps),
+                                     "reference_to_product": "load_pretrained (strict on embedding.* / encoder.*, target.* dropped), every tensor equal"}
+            print("tower", tower, out["tower." + tower]["tensors"], out["tower." + tower]["elements"], flush=True)
+    with open(os.path.join(GOLD, "bin_interchange.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("merged the towers into bin_interchange.json")
 
 
 def gen_letor_readers():
@@ -1077,7 +1122,7 @@ def gen_encoder_full():
 
 GENS = dict(keys=gen_keys, xit_small=gen_xit_small, losses=gen_losses, adamw_sched=gen_adamw_sched, ndcg=gen_ndcg,
             encoder_small=gen_encoder_small, embeddings_small=gen_embeddings_small, encoder_full=gen_encoder_full,
-            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, letor_readers=gen_letor_readers, bin_interchange=gen_bin_interchange, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls, ppo_trad=gen_ppo_trad, reward_trad=gen_reward_trad, trad2=gen_trad2)
+            head_fwd=gen_head_fwd, train_step=gen_train_step, stage1=gen_stage1, stage2=gen_stage2, encoder_bwd=gen_encoder_bwd, embeddings_bwd=gen_embeddings_bwd, readers=gen_readers, letor_readers=gen_letor_readers, bin_interchange=gen_bin_interchange, bin_towers=gen_bin_towers, trad=gen_trad, encoder_bwd_wide=gen_encoder_bwd_wide, dual=gen_dual, cls=gen_cls, ppo_trad=gen_ppo_trad, reward_trad=gen_reward_trad, trad2=gen_trad2)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

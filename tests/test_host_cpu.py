@@ -252,7 +252,13 @@ def test_checkpoint_layouts_are_the_ones_that_crossed_to_the_reference_and_back(
                "reward_pair_dataloader.Classifier": reward_pair_dataloader.Classifier, "ppo_trad.Actor": ppo_trad.Actor,
                "ppo_trad.Critic": ppo_trad.Critic, "ppo_trad.Reward": ppo_trad.Reward, "pointwise_trad.Classifier": pointwise_trad.Classifier,
                "pointwise_2data_trad.Classifier": pointwise_2data_trad.Classifier, "reward_trad.Classifier": reward_trad.Classifier}
-    assert set(gold) == set(classes)
+    assert set(gold) == set(classes) | {"tower.vit", "tower.roberta"}
+    from lr2ppo_amd.finetune.features import TEXT_CONFIG, VIT_CONFIG, EncoderStack, encoder_args
+    for tower, cfg in (("tower.vit", VIT_CONFIG), ("tower.roberta", TEXT_CONFIG)):   # released ViT-B/16 / RoBERTa-base checkpoints' layout
+        with torch.device("meta"):
+            sd = EncoderStack(encoder_args(cfg), 50265).state_dict()
+        text = ";".join(f"{k}:{tuple(v.shape)}:{str(v.dtype).replace('torch.', '')}" for k, v in sd.items())
+        assert (len(sd), hashlib.sha256(text.encode()).hexdigest()) == (gold[tower]["tensors"], gold[tower]["layout_sha256"]), tower
     args = argparse.Namespace(mode="reg", labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768)
     for name, cls in classes.items():
         with torch.device("meta"):
