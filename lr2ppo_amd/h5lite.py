@@ -30,6 +30,7 @@ _H5T_INTEGER, _H5T_FLOAT = 0, 1
 _NATIVE = {"f4": "H5T_NATIVE_FLOAT_g", "f8": "H5T_NATIVE_DOUBLE_g", "i1": "H5T_NATIVE_INT8_g", "i2": "H5T_NATIVE_INT16_g",
            "i4": "H5T_NATIVE_INT32_g", "i8": "H5T_NATIVE_INT64_g", "u1": "H5T_NATIVE_UINT8_g", "u2": "H5T_NATIVE_UINT16_g",
            "u4": "H5T_NATIVE_UINT32_g", "u8": "H5T_NATIVE_UINT64_g"}
+_ITER_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int64, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p)   # H5L_iterate_t
 _lib = None
 _lock = threading.RLock()          # libhdf5 is not built thread-safe by default: one call at a time, like h5py's global lock
 
@@ -194,10 +195,23 @@ class Group:
         return int(ctypes.c_uint64.from_buffer(info, 8).value)
 
     def keys(self):
+        """Member names in increasing name order.  One H5Literate pass (the by-index lookup walks the group's B-tree from the start
+        for every index: quadratic on the thousands of items of a real clean_feat.h5); by-index only where that symbol is missing."""
         lib, out = _load(), []
+        iterate = getattr(lib, "H5Literate", None) or getattr(lib, "H5Literate1", None)
         with _lock:
+            if iterate is not None:
+                @_ITER_CB
+                def visit(_group, name, _info, _data):
+                    out.append(name.decode("utf-8"))
+                    return 0
+                iterate.restype = ctypes.c_int
+                iterate.argtypes = [_hid, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), _ITER_CB, ctypes.c_void_p]
+                if iterate(self._id, 0, 0, None, visit, None) < 0:                         # H5_INDEX_NAME, H5_ITER_INC
+                    raise OSError(f"{self.name}: H5Literate failed")
+                return out
             for i in range(len(self)):
-                n = lib.H5Lget_name_by_idx(self._id, b".", 0, 0, i, None, 0, 0)           # H5_INDEX_NAME, H5_ITER_INC
+                n = lib.H5Lget_name_by_idx(self._id, b".", 0, 0, i, None, 0, 0)
                 if n < 0:
                     raise OSError(f"{self.name}: H5Lget_name_by_idx failed")
                 buf = ctypes.create_string_buffer(n + 1)
