@@ -282,3 +282,56 @@ def test_reward_trad_entry_point_trains_from_letor_h5_files(tmp_path):
     text = open(log).read()
     assert "The number of training instances: 100" in text and "Training steps: 2" in text and "val accuracy:" in text, text[-2000:]
     assert "pos_emb.weight" in torch.load(out, map_location="cpu")
+
+
+@pytest.mark.gpu
+def test_dimension_projection_entry_point_rewrites_tsv_files(tmp_path):
+    """`python -m lr2ppo_amd.finetune.pointwise_2data_infer_trad` (the step between the 46- / 136-wide LETOR rows and the 768-wide
+    files the other `_trad` twins train on; finetune/pointwise_2data_infer_trad.py:409-447): every row's features go through the
+    checkpoint's text_proj / text_proj3, label and query id are copied as text, row order kept; values against the same Mlp in fp64."""
+    import csv
+    from lr2ppo_amd.finetune import pointwise_2data_trad as p2, ppo
+    torch.manual_seed(3)
+    model = p2.Classifier(argparse.Namespace(mode="reg", labels_num=3), None)
+    ppo._init_normal(model)
+    with torch.no_grad():
+        for q in model.parameters():
+            q.mul_(3.0)                                                    # activations of order 1: GELU is exercised off zero
+    ckpt = str(tmp_path / "proj.bin")
+    torch.save(model.state_dict(), ckpt)
+    rng = np.random.RandomState(4)
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir()
+    tables = {"train.tsv": rng.standard_normal((37, 46)), "test.tsv": rng.standard_normal((21, 136)),
+              "mixed.tsv": None}                                          # one file with both widths, interleaved
+    rows_of = {}
+    for name, feats in tables.items():
+        rows = []
+        if feats is None:
+            for i in range(10):
+                w = 46 if i % 3 else 136
+                rows.append([str(i % 3), str(900 + i)] + [repr(float(v)) for v in rng.standard_normal(w)])
+        else:
+            for i, f in enumerate(feats):
+                rows.append([str(int(rng.randint(0, 3))), str(100 + i // 5)] + [repr(float(v)) for v in f])
+        rows_of[name] = rows
+        with open(src / name, "w") as f:
+            csv.writer(f, delimiter="\t").writerows(rows)
+    env = dict(os.environ, PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable, "-m", "lr2ppo_amd.finetune.pointwise_2data_infer_trad", "--dim_proj_ckpt_path", ckpt,
+                        "--input_dir", str(src), "--output_dir", str(dst), "--train_path", "x", "--dev_path", "x"], cwd=REPO, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    sd = {k: v.double() for k, v in model.state_dict().items()}
+    for name, rows in rows_of.items():
+        with open(dst / name) as f:
+            got = list(csv.reader(f, delimiter="\t"))
+        assert len(got) == len(rows) and all(len(g) == 2 + 768 for g in got), name
+        for g, row in zip(got, rows):
+            assert g[:2] == row[:2]
+            x = torch.tensor([float(v) for v in row[2:]], dtype=torch.float64)
+            pre = "text_proj" if x.numel() == 46 else "text_proj3"
+            h = torch.nn.functional.gelu(sd[pre + ".fc1.weight"] @ x + sd[pre + ".fc1.bias"])
+            want = sd[pre + ".fc2.weight"] @ h + sd[pre + ".fc2.bias"]
+            have = torch.tensor([float(v) for v in g[2:]], dtype=torch.float64)
+            assert ((have - want).norm() / want.norm()).item() < 1e-4, (name, g[:2])     # split-bf16 x 3 products: ~1e-5
