@@ -167,7 +167,11 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL ("nccl") is the product path; LR2_BENCH_BACKEND=gloo exists only to rehearse the N > 1 code on one GPU
-        dist.init_process_group(os.environ.get("LR2_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        # a collective that never completes (a rank that died, a schedule mismatch) aborts the job after this long -- with an error in
+        # the log and a non-zero exit -- instead of hanging until somebody kills it (this path's first multi-rank runs are the driver's)
+        import datetime
+        dist.init_process_group(os.environ.get("LR2_BENCH_BACKEND", "nccl"), rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("LR2_BENCH_PG_TIMEOUT_S", "300"))))
     if a.gpus != world:
         raise SystemExit(f"bench: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     ranks_seen = 1
