@@ -335,3 +335,58 @@ def test_dimension_projection_entry_point_rewrites_tsv_files(tmp_path):
             want = sd[pre + ".fc2.weight"] @ h + sd[pre + ".fc2.bias"]
             have = torch.tensor([float(v) for v in g[2:]], dtype=torch.float64)
             assert ((have - want).norm() / want.norm()).item() < 1e-4, (name, g[:2])     # split-bf16 x 3 products: ~1e-5
+
+
+@needs_hdf5
+@pytest.mark.gpu
+def test_ppo_eval_scores_a_real_lrmovienet_split_and_dumps_the_cases(tmp_path, monkeypatch):
+    """finetune/ppo_eval.py: `evaluate` over LRMovieNet/clean_feat.h5 (real HDF5) + a split json with the clips' records -- NDCG against
+    the oracle's CPU scores with the same weights (north_star: +-0.002), and case/ppo_cases.json: the record fields as the DataLoader
+    collates them, gold labels, the per-clip NDCG vector, tags in the order of the predicted scores."""
+    from oracle import lr2ppo_oracle as O
+    from lr2ppo_amd.finetune import ppo, ppo_eval
+    rng = np.random.RandomState(2)
+    root = tmp_path
+    (root / "LRMovieNet").mkdir()
+    clips = []
+    with h5lite.File(str(root / "LRMovieNet" / "clean_feat.h5"), "w") as f:
+        for i, n_tags in enumerate((4, 6, 3)):
+            cid = f"tt{1000 + i}_{i:04d}"
+            g = f.create_group(cid)
+            g.create_dataset("text_emb", data=rng.standard_normal((n_tags, 196, 768)).astype(np.float32))
+            g.create_dataset("img_emb", data=rng.standard_normal((1, 16, 768)).astype(np.float32))      # 16 frames: the shuffle only permutes them
+            clips.append({"id": cid, "filename": f"clip_{i}.mp4", "description": f"scene {i}",
+                          "tags": [{"tag": f"tag{i}_{t}", "target": int(rng.randint(0, 3))} for t in range(n_tags)]})
+    (root / "dev.json").write_text(json.dumps(clips))
+    monkeypatch.chdir(root)
+    dev = torch.device("cuda", 0)
+    args = argparse.Namespace(mode="reg", labels_num=3, seq_length=196, max_imgs=16, visual_feat_dim=768, is_master=True, device=dev,
+                              max_tags=32, batch_size=1, num_workers=0)
+    model = ppo.ActorCritic(args, None)
+    P = O.seeded_params(O.head_param_spec("actor"), seed=7)
+    model.actor.load_state_dict(P, strict=True)
+    args.model = model.to(dev)
+    ds = ppo_eval.MovieNet(args, "dev.json")
+    torch.manual_seed(21)
+    val = ppo_eval.evaluate(args, ppo_eval.get_dataloader(args, ds, 1, 0), 0, split="val", num_tasks=1)
+    cases = json.load(open(root / "case" / "ppo_cases.json"))
+    assert len(cases) == 3
+    rows = []
+    torch.manual_seed(21)                                                     # the same image shuffles
+    for clip, case in zip(clips, cases):
+        text, img, tgts, _ = ds[clips.index(clip)]
+        n = len(clip["tags"])
+        with torch.no_grad():
+            want = O.actor_forward(P, text.unsqueeze(0), img.unsqueeze(0).unsqueeze(1).repeat(1, n, 1, 1), None).view(-1)
+        assert case["filename"] == [clip["filename"]] and case["id"] == [clip["id"]] and case["description"] == [clip["description"]]
+        assert case["tags"] == [{"tag": [t["tag"]], "target": t["target"]} for t in clip["tags"]]
+        got_scores = torch.tensor([v for _, v in case["predict"]])
+        assert all(a >= b for a, b in zip(got_scores[:-1], got_scores[1:]))                      # sorted by predicted score
+        by_tag = {t["tag"][0]: v for t, v in case["predict"]}
+        have = torch.tensor([by_tag[t["tag"]] for t in clip["tags"]])
+        assert (have - want).abs().max().item() < 1e-3 * max(1.0, want.abs().max().item())     # the 1e-3 bar on the scores
+        assert sorted(t["tag"][0] for t, _ in case["predict"]) == sorted(t["tag"] for t in clip["tags"])
+        ref_row = O.ndcg_vector(want, tgts)
+        rows.append(ref_row)
+        assert max(abs(a - float(b)) for a, b in zip(case["ndcg"], ref_row)) <= 0.002 or (want.sort().values.diff().abs().min() < 1e-3)
+    assert abs(float(val) - float(torch.stack(rows).mean(0)[5])) <= 0.002
