@@ -223,6 +223,16 @@ def test_ppo_trad_entry_point_trains_from_letor_h5_files(tmp_path):
     log = open(os.path.join(root, "log.txt")).read()
     assert "The number of training instances: 60" in log and "NDCG@3" in log, log[-2000:]     # 3 queries x 20 pairs
     assert os.path.exists(os.path.join(root, "m.bin"))
+    # finetune/ppo_eval_trad.py: the evaluation-only entry point loads that checkpoint (the whole ActorCritic, strict) and reports the
+    # same validation NDCG the training run logged for it
+    trained = [ln for ln in log.splitlines() if ln.startswith("NDCG@3=")][-1]
+    cmd2 = [c if c != "lr2ppo_amd.finetune.ppo_trad" else "lr2ppo_amd.finetune.ppo_eval_trad" for c in cmd]
+    cmd2[cmd2.index("--log_path") + 1] = os.path.join(root, "eval_log.txt")
+    r2 = subprocess.run(cmd2 + ["--pretrained_model_path", os.path.join(root, "m.bin")], cwd=REPO, env=env, capture_output=True, text=True,
+                        timeout=900)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+    elog = open(os.path.join(root, "eval_log.txt")).read()
+    assert [ln for ln in elog.splitlines() if ln.startswith("NDCG@3=")][-1] == trained, (trained, elog[-1000:])
 
 
 def _letor_dirs(tmp_path, widths):
