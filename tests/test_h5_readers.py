@@ -235,6 +235,44 @@ def test_ppo_trad_entry_point_trains_from_letor_h5_files(tmp_path):
     assert [ln for ln in elog.splitlines() if ln.startswith("NDCG@3=")][-1] == trained, (trained, elog[-1000:])
 
 
+@needs_hdf5
+def test_tsv_to_h5_conversion_resamples_every_query_to_20_rows(tmp_path):
+    """tools/convert_to_h5py.py (datasets_trad/convert_to_h5py.py's job without h5py): queries of 7, 20 and 33 rows -> 20 rows each,
+    drawn as sklearn.utils.resample(random_state=0) draws them, float64, named by query id; readable by LTRDataset."""
+    import csv
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import convert_to_h5py as conv
+    from sklearn.utils import resample
+    rng = np.random.RandomState(7)
+    src = tmp_path / "tsv"
+    src.mkdir()
+    sizes, rows, rid = {301: 7, 5: 20, 12000: 33}, [], 0
+    for qid, n in sizes.items():
+        for _ in range(n):
+            rows.append([int(rng.randint(0, 3)), qid, float(rid)] + [round(float(v), 6) for v in rng.standard_normal(5)])
+            rid += 1
+    for name in ("train.tsv", "test.tsv"):
+        with open(src / name, "w") as f:
+            csv.writer(f, delimiter="\t").writerows(rows)
+    (src / "notes.txt").write_text("ignored")
+    out = conv.convert(str(src), str(tmp_path / "h5"))
+    assert [os.path.basename(p) for p in out] == ["test.h5", "train.h5"]
+    table = np.array(rows, dtype=np.float64)
+    with h5lite.File(out[1]) as f:
+        assert f.keys() == ["12000", "301", "5"]
+        for qid, n in sizes.items():
+            got, mine = f[str(qid)][()], table[table[:, 1] == qid]
+            assert got.shape == (20, 8) and got.dtype == np.float64 and set(got[:, 1]) == {float(qid)}
+            want = mine if n == 20 else resample(mine, replace=n < 20, n_samples=20, random_state=0)
+            assert np.array_equal(got, want), qid
+            if n > 20:
+                assert len(set(got[:, 2])) == 20                         # without replacement
+    from lr2ppo_amd.finetune import pointwise_trad
+    ds = pointwise_trad.LTRDataset(None, str(tmp_path / "h5"), is_train=True)
+    gt, qid, feats = ds[0]
+    assert len(ds) == 3 and qid == "12000" and feats.shape == (20, 6)
+
+
 def _letor_dirs(tmp_path, widths):
     from oracle import lr2ppo_oracle as O
     from lr2ppo_amd.finetune import letor
